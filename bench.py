@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py -- k-NN mapping throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--m M --n N --d D --k K]
+
+A step = one full k-NN build of the workload: pack the (sharded) references, fused
+distance + top-k on the MFMA pipe, float64 refine, and for N>1 the RCCL exchange + merge.
+Inputs (float64 PCA-like embeddings) are already resident in HBM when the timed region starts.
+Default workload: BASELINE.json configs[2], 1M ref x 1M target, d=50, k=15, Euclidean.
+For N>1 the driver launches this file under torch.distributed.run (one rank per GPU); reference
+rows are sharded, total work is fixed ("strong" scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+
+
+def cpu_baseline(d, k):
+    """The oracle (bit-equal port of the reference's CPU arithmetic + selection), all host
+    cores, on a bounded sample of the same workload."""
+    import oracle
+    from nabo_amd._synth import pca_like
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    n_s, m_s = 100000, 1024
+    Y = pca_like(n_s, d, seed=1003)
+    X = pca_like(m_s, d, seed=2003)
+    oracle.knn(X[:64], Y, k, 0, nthreads=cores)          # warm up threads / page in
+    t0 = time.perf_counter()
+    oracle.knn(X, Y, k, 0, nthreads=cores)
+    dt = time.perf_counter() - t0
+    # scale the sample towards ~10-20 s of CPU work
+    reps = int(max(1, min(16, 12.0 / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.knn(X, Y, k, 0, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": reps * m_s * n_s / dt, "unit": "cell-pair distances/s", "cores": cores, "kind": "port",
+            "sample": "%d x (%d targets x %d refs), d=%d, k=%d, float64 sequential + ordered top-k, OpenMP"
+                      % (reps, m_s, n_s, d, k)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--m", type=int, default=1000000)
+    ap.add_argument("--n", type=int, default=1000000)
+    ap.add_argument("--d", type=int, default=50)
+    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    import nabo_amd
+    from nabo_amd import _knn
+    from nabo_amd._dist import shard_bounds
+    from nabo_amd._synth import pca_like
+    if nabo_amd.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+
+    m, n, d, k = a.m, a.n, a.d, a.k
+    dev = local_rank if world > 1 else 0
+    lo, hi = shard_bounds(n, world, rank)
+    Y = pca_like(n, d, seed=1003)[lo:hi]
+    X = pca_like(m, d, seed=2003)
+
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        from nabo_amd._dist import ShardedKnn, gpu_callables
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        tX = torch.from_numpy(X).to("cuda:%d" % dev)
+        tY = torch.from_numpy(np.ascontiguousarray(Y)).to("cuda:%d" % dev)
+        torch.cuda.synchronize()
+        x_ptr, y_ptr = tX.data_ptr(), tY.data_ptr()
+    else:
+        dX = _knn.DeviceBuffer(X.nbytes, dev).upload(X)
+        dY = _knn.DeviceBuffer(Y.nbytes, dev).upload(np.ascontiguousarray(Y))
+        dI = _knn.DeviceBuffer(m * k * 8, dev)
+        dD = _knn.DeviceBuffer(m * k * 8, dev)
+        x_ptr, y_ptr = dX.ptr, dY.ptr
+
+    index = nabo_amd.KnnIndex(hi - lo, d, metric=nabo_amd.EUCLIDEAN, ref_index_base=lo, device=dev)
+    stats = []
+
+    if world > 1:
+        lk, mg = gpu_callables(index, dev)
+        sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev))
+
+        def step():
+            index.set_ref(y_device_ptr=y_ptr)
+            out = sk.query(tX, m, k, False)
+            stats.append(index.last_stats())
+            return out
+
+        def sync():
+            dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        def step():
+            index.set_ref(y_device_ptr=y_ptr)
+            index.query_device(x_ptr, m, k, False, dI.ptr, dD.ptr)
+            stats.append(index.last_stats())
+
+        def sync():
+            _knn._lib.check(_knn._lib.lib().nabo_dev_synchronize(dev))
+
+    for _ in range(a.warmup):
+        step()
+    stats.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # light self-check outside the timed region (rank 0): sorted rows, valid indices
+    if world == 1:
+        gi = dI.download((m, k), np.int64)
+        gd = dD.download((m, k), np.float64)
+        assert gi.min() >= 0 and gi.max() < n and (np.diff(gd[:: max(1, m // 4096)], axis=1) >= 0).all()
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events, kernel's own stream
+        flops = 2.0 * m * (hi - lo) * d                                       # algorithmic: the -2XY^T term
+        achieved = flops / t_kernel / 1e12
+        line = {
+            "metric": "cell-pair distances/s (k-NN build, 1Mx1M d=50 k=15)" if (m, n, d, k) == (1000000, 1000000, 50, 15)
+                      else "cell-pair distances/s (k-NN build)",
+            "value": m * n * a.steps / dt, "unit": "cell-pair distances/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "knn_build_s": dt / a.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 MFMA filter + f64 refine (results float64-exact)", "data": "synthetic",
+            "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, euclidean, refs sharded %d-way"
+                                   % (n // 1000, m // 1000, d, k, world),
+                       "parallelism": "ref-shard%d" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "l2_topk_kernel (v_mfma_f32_32x32x2_f32)", "kernel_ms": t_kernel * 1e3},
+            "phases_ms": {key: float(np.mean([s[key] for s in stats])) for key in
+                          ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
+            "fallback_rows": int(np.max([s["fallback_rows"] for s in stats])),
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(d, k)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

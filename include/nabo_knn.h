@@ -1,0 +1,128 @@
+/*
+ * nabo_knn.h -- C ABI of libnabo_knn.so, the MI355X (gfx950) implementation of Nabo's
+ * cross-sample k-NN mapping hot path.
+ *
+ * The reference (parashardhapola/nabo v0.4.1) has no FFI: the seam is a Python function
+ * boundary inside nabo/_mapping.py.  Each entry point below names the reference code it
+ * replaces (file:line relative to the reference root).  Plain pointers and sizes only;
+ * no torch / numpy types.  All functions return 0 on success or a negative NABO_E_* code,
+ * with a human-readable message available from nabo_last_error() (thread-local).
+ *
+ * Semantics shared by every k-NN entry point
+ *   - distances are the reference's float64 values, bit for bit:
+ *       metric 0: nabo/_mapping.py:16-26  _euclidean_dist   sqrt(sum_k (x-y)^2), k ascending,
+ *                                         separate multiply/add (no FMA), correctly rounded sqrt
+ *       metric 1: nabo/_mapping.py:29-45  _mod_canberra_dist (asymmetric: x = target, y = reference)
+ *   - ordering replaces the mask + np.argsort of nabo/_mapping.py:135-146: refs flagged in
+ *     ref_mask sort to the END (numpy.ma NaN-fill), all others by (distance ascending,
+ *     reference index ascending) -- the canonical total order where the reference's unstable
+ *     sort leaves ties undefined;
+ *   - drop_first != 0 reproduces the positional `[1:]` of nabo/_mapping.py:142 (intra-reference);
+ *   - out_idx / out_dist are [m, k] row-major: the first k entries of each order row (what
+ *     _calc_snn reads, nabo/_mapping.py:190,193) and their distances.
+ * There is NO CPU fallback: without a usable HIP device every compute call fails with
+ * NABO_E_NODEVICE.
+ */
+#ifndef NABO_KNN_H
+#define NABO_KNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NABO_METRIC_EUCLIDEAN    0   /* nabo/_mapping.py:16-26, selected when intra_ref (:119-121) */
+#define NABO_METRIC_MOD_CANBERRA 1   /* nabo/_mapping.py:29-45, selected otherwise      (:122-124) */
+
+#define NABO_OK            0
+#define NABO_E_INVALID    -1   /* bad argument (the Python shim raises ValueError)            */
+#define NABO_E_NODEVICE   -2   /* no HIP device / device index out of range                   */
+#define NABO_E_HIP        -3   /* a HIP runtime call failed                                   */
+#define NABO_E_NOMEM      -4   /* device or host allocation failed                            */
+#define NABO_E_UNSUPPORTED -5  /* shape outside what the kernels are instantiated for         */
+
+/* Limits of the instantiated kernels. */
+#define NABO_MAX_COMPS      128  /* use_comps (g) for the Euclidean MFMA kernel               */
+#define NABO_MAX_K           56  /* k + drop_first (candidate lists hold 32 or 64 entries)     */
+
+const char *nabo_version(void);
+const char *nabo_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int nabo_device_count(void);
+
+/* ---- coarse seam: replaces the tile loop + mask + sort of _calc_dist -------------------
+ * (nabo/_mapping.py:98-146), array-in / array-out, HOST pointers, synchronous.
+ * X [m,g] targets, Y [n,g] references, row-major float64 (the `[:use_comps]` prefixes the
+ * reference gathers at :105,:113).  ref_mask: n bytes, non-zero = ignored reference
+ * (ignore_ref_cells, :135-138), may be NULL.  Requires 1 <= k, k + drop_first <= n. */
+int nabo_knn(const double *X, int64_t m, const double *Y, int64_t n, int32_t g,
+             int32_t k, int32_t metric, double dist_factor,
+             const uint8_t *ref_mask, int32_t drop_first,
+             int64_t *out_idx, double *out_dist, int32_t device);
+
+/* ---- fine seam: literal a1/a2 kernels (nabo/_mapping.py:16-45, call sites :120-124) -----
+ * D [m,n] float64, caller-allocated host buffers (the reference's caller allocates d, :117). */
+int nabo_pairwise(const double *X, int64_t m, const double *Y, int64_t n, int32_t g,
+                  int32_t metric, double dist_factor, double *D, int32_t device);
+
+/* ---- resident API: references stay in HBM across many target batches -------------------
+ * One nabo_index per (device, reference shard).  ref_index_base is added to every
+ * returned index (reference-row sharding across GPUs: shard r holds rows
+ * [base_r, base_r + n_ref) of the global reference and reports GLOBAL indices). */
+typedef struct nabo_index nabo_index;
+
+int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g,
+                      int32_t metric, double dist_factor, int64_t ref_index_base);
+int nabo_index_destroy(nabo_index *ix);
+
+/* Upload / adopt the reference rows.  Y is [n_ref,g] float64 row-major; when
+ * y_on_device != 0 it is a device pointer on the index's device and is BORROWED (must
+ * outlive the index); otherwise it is copied.  ref_mask is a HOST pointer (n_ref bytes) or NULL. */
+int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device,
+                       const uint8_t *ref_mask);
+
+/* k-NN of m target rows against the resident references.
+ * x_on_device / out_on_device select host or device pointers for X and for
+ * out_idx[m,k] (int64) / out_dist[m,k] (float64).  Work is enqueued on the index's own
+ * HIP stream and the call returns after that stream has drained (results are final). */
+int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m,
+                     int32_t k, int32_t drop_first,
+                     int64_t *out_idx, double *out_dist, int32_t out_on_device);
+
+/* HIP-event timings (ms) and counters of the LAST nabo_index_query on this index.
+ * ms[0] pack targets, ms[1] distance+top-k kernel (the dominant kernel), ms[2] float64
+ * refine, ms[3] exact fallback for guard-flagged rows, ms[4] total on-stream.
+ * counters[0] rows re-solved by the exact fallback, counters[1] candidate lists per row (S),
+ * counters[2] candidates per list (L), counters[3] workgroups of the dominant kernel. */
+int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4]);
+
+/* ---- shard merge (reference rows sharded over GPUs) ---------------
+ * parts_idx / parts_dist: [n_parts, m, kp] DEVICE arrays, each row sorted by the canonical
+ * order with GLOBAL indices (what nabo_index_query(k=kp, drop_first=0) returns on every
+ * shard after the RCCL exchange).  Writes the merged first k entries after the optional
+ * positional drop to out_idx/out_dist [m,k] (device).  Masked references must have been
+ * excluded by the shards (entries with idx < 0 are treated as absent). */
+int nabo_merge_topk(int32_t device, const int64_t *parts_idx, const double *parts_dist,
+                    int32_t n_parts, int64_t m, int32_t kp, int32_t k, int32_t drop_first,
+                    int64_t *out_idx, double *out_dist);
+
+/* ---- SNN edge counts on device (consumer of the top-k: nabo/_mapping.py:186-198) --------
+ * t_idx [m,k], r_idx [n,k] int64 DEVICE arrays (first k of the order rows).  For every
+ * (t, slot s) writes out_snn[t*k+s] = | set(t_idx[t]) & set(r_idx[t_idx[t,s]]) | (int32,
+ * device).  The weight round(snn/(2(k-1)-snn),2) and the snn>0 filter stay with the caller. */
+int nabo_snn_counts(int32_t device, const int64_t *t_idx, int64_t m,
+                    const int64_t *r_idx, int64_t n, int32_t k, int32_t *out_snn);
+
+/* ---- plain device-memory helpers so a ctypes host needs no other GPU binding ------------ */
+int nabo_dev_malloc(int32_t device, void **ptr, size_t bytes);
+int nabo_dev_free(int32_t device, void *ptr);
+int nabo_memcpy_h2d(int32_t device, void *dst, const void *src, size_t bytes);
+int nabo_memcpy_d2h(int32_t device, void *dst, const void *src, size_t bytes);
+int nabo_dev_synchronize(int32_t device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NABO_KNN_H */

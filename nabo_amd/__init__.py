@@ -1,0 +1,10 @@
+"""nabo_amd -- MI355X-native k-NN mapping hot path behind Nabo's Mapping API.
+
+Public names mirror the reference's `nabo` package for this path (`Mapping`), plus the
+array-level entry points of the C ABI (`knn`, `pairwise`, `KnnIndex`)."""
+from ._lib import EUCLIDEAN, MOD_CANBERRA, NaboError, device_count  # noqa: F401
+from ._knn import knn, pairwise, KnnIndex, snn_counts  # noqa: F401
+from ._mapping import Mapping  # noqa: F401
+
+__all__ = ["Mapping", "knn", "pairwise", "KnnIndex", "snn_counts", "device_count", "EUCLIDEAN", "MOD_CANBERRA",
+           "NaboError"]

@@ -1,0 +1,75 @@
+"""Builds libnabo_knn.so (HIP, gfx950) in-tree with hipcc.  No torch, no cmake.
+
+    python -m nabo_amd._build [--force] [--verbose]
+"""
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SO = os.path.join(HERE, "libnabo_knn.so")
+SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "refine.hip", "canberra.hip"]
+# per-file extra flags: keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
+# v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
+FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+HEADERS = [os.path.join(CSRC, "knn_common.h"), os.path.join(HERE, "..", "include", "nabo_knn.h")]
+ARCH = "gfx950"
+FLAGS = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; libnabo_knn.so cannot be built")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(args):
+    src, obj, verbose, extra = args
+    cmd = [hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    if r.returncode != 0 or verbose:
+        sys.stderr.write(r.stdout)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed on %s" % src)
+    return obj
+
+
+def build(force=False, verbose=False, extra=None):
+    extra = list(extra or [])
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs, objs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + HEADERS + [os.path.abspath(__file__)]):
+            jobs.append((src, obj, verbose, extra + FILE_FLAGS.get(s, [])))
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), 6)) as ex:
+            list(ex.map(_compile, jobs))
+    if jobs or force or _stale(SO, objs):
+        cmd = [hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(SO)

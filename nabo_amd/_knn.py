@@ -1,0 +1,170 @@
+"""numpy-facing wrappers over the C ABI: the array-in / array-out form of Nabo's
+`_calc_dist` tile loop + mask + sort (nabo/_mapping.py:98-146).
+
+Everything here runs on the GPU through libnabo_knn.so; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EUCLIDEAN, MOD_CANBERRA  # noqa: F401
+
+
+def _f64(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.ndim != 2:
+        raise ValueError("ERROR: %s must be a 2-D array" % name)
+    return a
+
+
+def _mask(ref_mask, n):
+    if ref_mask is None:
+        return None, None
+    mk = np.ascontiguousarray(ref_mask, dtype=np.uint8)
+    if mk.shape != (n,):
+        raise ValueError("ERROR: ref_mask must have one entry per reference cell")
+    return mk, mk.ctypes.data
+
+
+def knn(X, Y, k, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=False, device=0):
+    """First k entries of every order row + their float64 distances (host arrays in/out).
+
+    X [m,g] targets, Y [n,g] references.  Returns (idx int64 [m,k], dist float64 [m,k])."""
+    X, Y = _f64(X, "X"), _f64(Y, "Y")
+    if X.shape[1] != Y.shape[1]:
+        raise ValueError("ERROR: X and Y must have the same number of components")
+    m, n, g = X.shape[0], Y.shape[0], X.shape[1]
+    mk, mp = _mask(ref_mask, n)
+    idx = np.empty((m, k), dtype=np.int64)
+    dist = np.empty((m, k), dtype=np.float64)
+    rc = _lib.lib().nabo_knn(X.ctypes.data, m, Y.ctypes.data, n, g, int(k), int(metric), float(dist_factor),
+                             mp, int(bool(drop_first)), idx.ctypes.data, dist.ctypes.data, int(device))
+    _lib.check(rc)
+    return idx, dist
+
+
+def pairwise(X, Y, metric=EUCLIDEAN, dist_factor=0.25, device=0):
+    """Literal a1 / a2 (nabo/_mapping.py:16-45): dense float64 D[m,n] computed on the GPU."""
+    X, Y = _f64(X, "X"), _f64(Y, "Y")
+    if X.shape[1] != Y.shape[1]:
+        raise ValueError("ERROR: X and Y must have the same number of components")
+    D = np.empty((X.shape[0], Y.shape[0]), dtype=np.float64)
+    rc = _lib.lib().nabo_pairwise(X.ctypes.data, X.shape[0], Y.ctypes.data, Y.shape[0], X.shape[1], int(metric),
+                                  float(dist_factor), D.ctypes.data, int(device))
+    _lib.check(rc)
+    return D
+
+
+class KnnIndex:
+    """References resident in HBM; query many target batches (nabo_index_* in nabo_knn.h).
+
+    `Y` may be a host array or, with `y_device_ptr`, a raw device pointer (borrowed)."""
+
+    def __init__(self, n_ref, g, metric=EUCLIDEAN, dist_factor=0.25, ref_index_base=0, device=0):
+        self._h = C.c_void_p()
+        self.n_ref, self.g, self.metric, self.device = int(n_ref), int(g), int(metric), int(device)
+        _lib.check(_lib.lib().nabo_index_create(C.byref(self._h), self.device, self.n_ref, self.g, self.metric,
+                                                float(dist_factor), int(ref_index_base)))
+        self._keep = None
+
+    def set_ref(self, Y=None, ref_mask=None, y_device_ptr=None):
+        mk, mp = _mask(ref_mask, self.n_ref)
+        if y_device_ptr is not None:
+            _lib.check(_lib.lib().nabo_index_set_ref(self._h, int(y_device_ptr), 1, mp))
+        else:
+            Y = _f64(Y, "Y")
+            if Y.shape != (self.n_ref, self.g):
+                raise ValueError("ERROR: Y must be [n_ref, g]")
+            _lib.check(_lib.lib().nabo_index_set_ref(self._h, Y.ctypes.data, 0, mp))
+        return self
+
+    def query(self, X, k, drop_first=False):
+        X = _f64(X, "X")
+        if X.shape[1] != self.g:
+            raise ValueError("ERROR: X must have g components")
+        m = X.shape[0]
+        idx = np.empty((m, k), dtype=np.int64)
+        dist = np.empty((m, k), dtype=np.float64)
+        _lib.check(_lib.lib().nabo_index_query(self._h, X.ctypes.data, 0, m, int(k), int(bool(drop_first)),
+                                               idx.ctypes.data, dist.ctypes.data, 0))
+        return idx, dist
+
+    def query_device(self, x_ptr, m, k, drop_first, out_idx_ptr, out_dist_ptr):
+        """Device pointers in and out (X [m,g] f64; out_idx [m,k] i64; out_dist [m,k] f64)."""
+        _lib.check(_lib.lib().nabo_index_query(self._h, int(x_ptr), 1, int(m), int(k), int(bool(drop_first)),
+                                               int(out_idx_ptr), int(out_dist_ptr), 1))
+
+    def last_stats(self):
+        ms = (C.c_double * 5)()
+        cn = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().nabo_index_last_stats(self._h, ms, cn))
+        return {"ms_pack": ms[0], "ms_topk": ms[1], "ms_refine": ms[2], "ms_fallback": ms[3], "ms_total": ms[4],
+                "fallback_rows": int(cn[0]), "splits": int(cn[1]), "list_len": int(cn[2]), "workgroups": int(cn[3])}
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _lib.lib().nabo_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes through the C ABI (for hosts that have no other GPU binding)."""
+
+    def __init__(self, nbytes, device=0):
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = C.c_void_p()
+        _lib.check(_lib.lib().nabo_dev_malloc(self.device, C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        _lib.check(_lib.lib().nabo_memcpy_h2d(self.device, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        _lib.check(_lib.lib().nabo_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            _lib.lib().nabo_dev_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def merge_topk_device(parts_idx_ptr, parts_dist_ptr, n_parts, m, kp, k, drop_first, out_idx_ptr, out_dist_ptr,
+                      device=0):
+    _lib.check(_lib.lib().nabo_merge_topk(int(device), int(parts_idx_ptr), int(parts_dist_ptr), int(n_parts), int(m),
+                                          int(kp), int(k), int(bool(drop_first)), int(out_idx_ptr),
+                                          int(out_dist_ptr)))
+
+
+def snn_counts(t_idx, r_idx, k, device=0):
+    """Shared-neighbour counts of nabo/_mapping.py:190-193 computed on the GPU.
+    t_idx [m,>=k], r_idx [n,>=k] host int arrays -> int32 [m,k]."""
+    t = np.ascontiguousarray(np.asarray(t_idx)[:, :k], dtype=np.int64)
+    r = np.ascontiguousarray(np.asarray(r_idx)[:, :k], dtype=np.int64)
+    m, n = t.shape[0], r.shape[0]
+    dt = DeviceBuffer(t.nbytes, device).upload(t)
+    dr = DeviceBuffer(r.nbytes, device).upload(r)
+    do = DeviceBuffer(m * k * 4, device)
+    try:
+        _lib.check(_lib.lib().nabo_snn_counts(int(device), dt.ptr, m, dr.ptr, n, int(k), do.ptr))
+        return do.download((m, k), np.int32)
+    finally:
+        dt.free(); dr.free(); do.free()

@@ -1,0 +1,77 @@
+"""ctypes binding of libnabo_knn.so (include/nabo_knn.h).  No torch, no CPU fallback:
+if the HIP library is missing or no GPU is visible, every compute entry point raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libnabo_knn.so")
+
+EUCLIDEAN = 0
+MOD_CANBERRA = 1
+MAX_COMPS = 128
+MAX_K = 56
+
+E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
+
+_lib = None
+
+# every symbol include/nabo_knn.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
+    "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_query",
+    "nabo_index_last_stats", "nabo_merge_topk", "nabo_snn_counts", "nabo_dev_malloc", "nabo_dev_free",
+    "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
+]
+
+
+class NaboError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libnabo_knn.so; fail loudly if it has not been built (python -m nabo_amd._build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise NaboError("libnabo_knn.so not found at %s -- build it with `python -m nabo_amd._build` "
+                        "(there is no CPU fallback)" % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.nabo_version.restype = C.c_char_p
+    L.nabo_last_error.restype = C.c_char_p
+    L.nabo_device_count.restype = C.c_int
+    L.nabo_knn.argtypes = [vp, i64, vp, i64, i32, i32, i32, dbl, vp, i32, vp, vp, i32]
+    L.nabo_pairwise.argtypes = [vp, i64, vp, i64, i32, i32, dbl, vp, i32]
+    L.nabo_index_create.argtypes = [C.POINTER(vp), i32, i64, i32, i32, dbl, i64]
+    L.nabo_index_destroy.argtypes = [vp]
+    L.nabo_index_set_ref.argtypes = [vp, vp, i32, vp]
+    L.nabo_index_query.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, i32]
+    L.nabo_index_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.nabo_merge_topk.argtypes = [i32, vp, vp, i32, i64, i32, i32, i32, vp, vp]
+    L.nabo_snn_counts.argtypes = [i32, vp, i64, vp, i64, i32, vp]
+    L.nabo_dev_malloc.argtypes = [i32, C.POINTER(vp), C.c_size_t]
+    L.nabo_dev_free.argtypes = [i32, vp]
+    L.nabo_memcpy_h2d.argtypes = [i32, vp, vp, C.c_size_t]
+    L.nabo_memcpy_d2h.argtypes = [i32, vp, vp, C.c_size_t]
+    L.nabo_dev_synchronize.argtypes = [i32]
+    for name in SYMBOLS:
+        if name not in ("nabo_version", "nabo_last_error"):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Map a C status to the reference's exception convention: bad parameters -> ValueError
+    (nabo/_mapping.py:301,429,520,...), everything else -> NaboError."""
+    if rc == 0:
+        return
+    msg = lib().nabo_last_error().decode("utf-8", "replace")
+    if rc in (E_INVALID, E_UNSUPPORTED):
+        raise ValueError("ERROR: " + msg)
+    raise NaboError("nabo_knn error %d: %s" % (rc, msg))
+
+
+def device_count():
+    return int(lib().nabo_device_count())

@@ -1,0 +1,420 @@
+"""`Mapping` -- drop-in for the reference's nabo.Mapping (nabo/_mapping.py:280-621) whose
+distance + neighbour-selection work runs on the MI355X through libnabo_knn.so.
+
+Kept verbatim from the reference: constructor / method signatures, parameter validation
+rules and exception types, reference-cell ordering (HDF5 name order, :404), the
+`name_stash` / `ref_cells` metadata (:340-355, :543-555), metric dispatch (Euclidean for
+ref<->ref, modified Canberra for target<->ref, :433-440), `ignore_ref_cells` masking
+(:135-138), the positional `[1:]` drop (:142), SNN edge weights (:185-198), the
+disconnected-graph repair (:203-249, :476-492) and the `<uid>_graph` wire format that
+`Graph.load_from_h5` reads (nabo/_graph.py:89-107).
+
+Deliberately different (DESIGN.md "stored layout"): the reference materialises the dense
+N_t x N_r float64 matrix and full int64 order rows on disk (:102-103, :145; 16 TB at 1M
+cells).  Only the first k entries of each order row are ever consumed (:190,:193), so this
+class stores exactly those: `<uid>_sortedDist/<cell>` holds the first k order entries and
+`<uid>_dist/<cell>` their distances (same positions), per cell like the reference, or as
+two [N,k] arrays with `layout='columnar'`.
+"""
+import os
+import random
+import string
+
+import numpy as np
+
+from . import _knn
+from ._lib import EUCLIDEAN, MOD_CANBERRA
+
+__all__ = ["Mapping"]
+
+_COL_IDX, _COL_DIST, _COL_CELLS = "__knn_idx", "__knn_dist", "__knn_cells"
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError as e:  # pragma: no cover - depends on the interpreter
+        raise ImportError("nabo_amd.Mapping needs h5py for Nabo's HDF5 files (the array-level "
+                          "nabo_amd.knn / KnnIndex API does not)") from e
+    return h5py
+
+
+def _uid(n=30):
+    return "".join(random.choice(string.ascii_lowercase) for _ in range(n))
+
+
+def _read_group_matrix(fn, grp, cells, use_comps):
+    """Gather the per-cell float64 vectors `[:use_comps]` (nabo/_mapping.py:105,113) into one
+    dense C-contiguous [n_cells, use_comps] array -- once, instead of once per tile."""
+    h5py = _h5py()
+    with h5py.File(fn, mode="r") as h5:
+        g = h5[grp]
+        if cells is None:
+            cells = [x for x in g]
+        out = np.empty((len(cells), use_comps), dtype=np.float64)
+        for i, c in enumerate(cells):
+            v = g[c][:use_comps]
+            if v.shape[0] != use_comps:
+                raise ValueError("ERROR: cell %s has only %d components, use_comps=%d" % (c, v.shape[0], use_comps))
+            out[i] = v
+    return cells, out
+
+
+def snn_weight_table(k):
+    """round(snn / (2*(k-1) - snn), 2) for snn = 0..k (nabo/_mapping.py:185,194); entries whose
+    denominator is zero are NaN and raise if they are ever needed."""
+    factor = 2 * (k - 1)
+    tab = np.full(k + 1, np.nan)
+    for s in range(k + 1):
+        if factor - s != 0:
+            tab[s] = round(s / (factor - s), 2)
+    return tab
+
+
+def snn_edges(t_idx, r_idx, k, device=0):
+    """(t, j, weight) for every j in order_t[:k] sharing >= 1 neighbour with order_ref_j[:k]
+    (nabo/_mapping.py:186-198).  Counting runs on the GPU (nabo_snn_counts)."""
+    t_idx = np.asarray(t_idx)[:, :k]
+    cnt = _knn.snn_counts(t_idx, r_idx, k, device=device)
+    tab = snn_weight_table(k)
+    tt, ss = np.nonzero(cnt > 0)
+    w = tab[cnt[tt, ss]]
+    if np.isnan(w).any():
+        raise ZeroDivisionError("division by zero")        # what round(snn/(factor-snn)) does at :194
+    return tt.astype(np.int64), t_idx[tt, ss].astype(np.int64), w
+
+
+class _Components:
+    """Connected components of an undirected edge list (union-find)."""
+
+    def __init__(self, n):
+        self.p = np.arange(n)
+
+    def find(self, a):
+        p = self.p
+        while p[a] != a:
+            p[a] = p[p[a]]
+            a = p[a]
+        return a
+
+    def union(self, a, b):
+        ra, rb = self.find(a), self.find(b)
+        if ra != rb:
+            self.p[max(ra, rb)] = min(ra, rb)
+
+    def labels(self):
+        return np.array([self.find(i) for i in range(len(self.p))])
+
+
+class Mapping:
+    """
+    Cell mapping on the GPU.  Same constructor and methods as the reference class
+    (nabo/_mapping.py:280-621).
+
+    :param mapping_h5_fn: Output HDF5 file (results; existing data may be re-used)
+    :param ref_name: Label for reference samples
+    :param ref_pca_fn: HDF5 file with the reference PCA data (one dataset per cell)
+    :param ref_pca_grp_name: Group inside ref_pca_fn holding the data
+    :param overwrite: start from scratch, deleting everything saved in mapping_h5_fn
+    Extensions (keyword only, defaults = reference behaviour): device, layout.
+    """
+
+    def __init__(self, mapping_h5_fn, ref_name, ref_pca_fn, ref_pca_grp_name, overwrite=False, *,
+                 device=0, layout="per_cell"):
+        self._h5Fn = mapping_h5_fn
+        if ref_name.find("__") != -1:
+            raise ValueError("ERROR: Underscores are not allowed in the value for `ref_name` parameter")
+        self.refName = ref_name
+        self._refPcaFn = ref_pca_fn
+        self._refPcaGrp = ref_pca_grp_name
+        if self._h5Fn == self._refPcaFn:
+            raise ValueError("ERROR: Input HDF5 and output HDF5 file cannot be same")
+        if layout not in ("per_cell", "columnar"):
+            raise ValueError("ERROR: layout must be 'per_cell' or 'columnar'")
+        self._device = device
+        self._layout = layout
+        self._check_h5(self._refPcaFn, self._refPcaGrp)
+        self.refCells = []
+        self._nameStash = {}
+        self._check_preload(overwrite)
+        self._refDistGrp = self._nameStash[self.refName] + "_dist"
+        self._refSortedDistGrp = self._nameStash[self.refName] + "_sortedDist"
+        self._refGraphGrpName = self._nameStash[self.refName] + "_graph"
+        self._useComps = None
+        self._k = None
+        self._distFactor = None
+        self._chunkSize = None
+        self._refMatrix = None          # cached dense reference [:use_comps]
+
+    # ---- metadata (nabo/_mapping.py:322-406) ---------------------------------------------
+    @staticmethod
+    def _check_h5(fn, group):
+        h5py = _h5py()
+        if os.path.exists(fn) is False:
+            raise ValueError("File %s doesn't exist" % fn)
+        with h5py.File(fn, mode="r") as h5:
+            if group not in h5:
+                raise ValueError("Group %s does not exist in file %s" % (group, fn))
+        return True
+
+    def _load_ref_cells(self):
+        with _h5py().File(self._refPcaFn, mode="r") as h5:
+            return [x for x in h5[self._refPcaGrp]]          # HDF5 name order (:404)
+
+    def _create_metadata(self, h5):
+        for key in list(h5.keys()):
+            del h5[key]
+        grp = h5.create_group("name_stash")
+        rs = _uid(30)
+        self._nameStash[self.refName] = rs
+        grp.create_dataset("ref_name", data=[self.refName.encode("ascii"), rs.encode("ascii")])
+        self.refCells = self._load_ref_cells()
+        grp = h5.create_group("ref_cells")
+        grp.create_dataset("ref_cells", data=[x.encode("ascii") for x in self.refCells])
+        return True
+
+    def _check_preload(self, overwrite):
+        with _h5py().File(self._h5Fn, mode="a") as h5:
+            have = ("ref_cells" in h5 and "ref_cells" in h5["ref_cells"] and
+                    "name_stash" in h5 and "ref_name" in h5["name_stash"])
+            if overwrite is True or not have:
+                self._create_metadata(h5)
+                return
+            ref_name = h5["name_stash/ref_name"][0].decode("UTF-8")
+            if ref_name != self.refName:
+                raise ValueError("ERROR: A different ref_name was used before for this mapping file. "
+                                 "Please set overwrite=True if you want to overwrite all the saved data.")
+            if "target_names" in h5["name_stash"]:
+                for i in h5["name_stash/target_names"]:
+                    self._nameStash[i[0].decode("UTF-8")] = i[1].decode("UTF-8")
+            self._nameStash[self.refName] = h5["name_stash/ref_name"][1].decode("UTF-8")
+            saved_cells = [x.decode("UTF-8") for x in h5["ref_cells/ref_cells"][:]]
+            pca_cells = self._load_ref_cells()
+            if len(saved_cells) == len(pca_cells) == len(set(saved_cells).intersection(pca_cells)):
+                self.refCells = saved_cells
+            else:
+                raise ValueError("ERROR: Cell names in PCA file does not match those used before in this "
+                                 "mapping file. Please set overwrite=True if you want to overwrite all the "
+                                 "saved data.")
+
+    def _stash_target_name(self, target):
+        with _h5py().File(self._h5Fn, mode="a") as h5:
+            if "target_names" in h5["name_stash"]:
+                del h5["name_stash/target_names"]
+            self._nameStash[target] = _uid(30)
+            stash = [[n.encode("ascii"), u.encode("ascii")] for n, u in self._nameStash.items()
+                     if n != self.refName]
+            h5["name_stash"].create_dataset("target_names", data=stash)
+
+    # ---- parameters (nabo/_mapping.py:495-524) -------------------------------------------
+    def set_parameters(self, use_comps, k, dist_factor, chunk_size):
+        """use_comps: leading input dimensions to use; k: neighbours; dist_factor: window of the
+        modified Canberra distance (> 0); chunk_size: kept for API compatibility -- the GPU
+        path streams tiles from HBM and does not need a host-side chunk size."""
+        self._useComps = use_comps
+        self._k = k
+        try:
+            float(dist_factor)
+            assert dist_factor > 0
+        except (ValueError, AssertionError, TypeError):
+            raise ValueError('ERROR: "dist_factor" must be a non-zero float value')
+        self._distFactor = dist_factor
+        self._chunkSize = chunk_size
+        self._refMatrix = None
+        return None
+
+    # ---- distances + neighbour selection (nabo/_mapping.py:408-444 -> :48-148) -------------
+    def _ref_matrix(self):
+        if self._refMatrix is None or self._refMatrix.shape[1] != self._useComps:
+            _, self._refMatrix = _read_group_matrix(self._refPcaFn, self._refPcaGrp, self.refCells, self._useComps)
+        return self._refMatrix
+
+    def _store_knn(self, h5, dist_grp, sorted_dist_grp, cells, idx, dist):
+        for g in (dist_grp, sorted_dist_grp):
+            if g in h5:
+                del h5[g]
+        dg = h5.create_group(dist_grp)
+        sg = h5.create_group(sorted_dist_grp)
+        if self._layout == "columnar":
+            sg.create_dataset(_COL_IDX, data=idx)
+            sg.create_dataset(_COL_CELLS, data=[c.encode("ascii") for c in cells])
+            dg.create_dataset(_COL_DIST, data=dist)
+        else:
+            for i, c in enumerate(cells):
+                sg.create_dataset(c, data=idx[i])
+                dg.create_dataset(c, data=dist[i])
+
+    @staticmethod
+    def _load_knn(h5, sorted_dist_grp):
+        sg = h5[sorted_dist_grp]
+        if _COL_IDX in sg:
+            cells = [x.decode("UTF-8") for x in sg[_COL_CELLS][:]]
+            return cells, sg[_COL_IDX][:]
+        cells = [x for x in sg]
+        return cells, np.stack([sg[c][:] for c in cells]) if cells else np.empty((0, 0), dtype=np.int64)
+
+    def calc_dist(self, target_fn, target_grp, dist_grp, sorted_dist_grp, ignore_ref_cells):
+        """Euclidean (reference vs itself) or modified Canberra (target vs reference) distances,
+        then the first k entries of every order row, on the GPU."""
+        if self._useComps is None or self._chunkSize is None or self._distFactor is None:
+            raise ValueError('ERROR: Please set the parameters first using "set_parameters" method')
+        if ignore_ref_cells is None:
+            ignore_ref_cells = []
+        intra_ref = (target_fn == self._refPcaFn and target_grp == self._refPcaGrp)
+        ref = self._ref_matrix()
+        cells, X = _read_group_matrix(target_fn, target_grp, None, self._useComps)   # HDF5 name order (:79)
+        mask = None
+        if len(ignore_ref_cells) > 0:
+            ign = set(ignore_ref_cells)
+            mask = np.array([c in ign for c in self.refCells], dtype=np.uint8)
+        drop = 1 if intra_ref else 0
+        n_ref = ref.shape[0]
+        k_store = min(self._k if self._k is not None else 1, n_ref - drop)
+        if k_store < 1:
+            raise ValueError("ERROR: not enough reference cells")
+        idx, dist = _knn.knn(X, ref, k_store, metric=EUCLIDEAN if intra_ref else MOD_CANBERRA,
+                             dist_factor=float(self._distFactor), ref_mask=mask, drop_first=bool(drop),
+                             device=self._device)
+        with _h5py().File(self._h5Fn, mode="a") as h5:
+            self._store_knn(h5, dist_grp, sorted_dist_grp, cells, idx, dist)
+
+    # ---- SNN graph (nabo/_mapping.py:446-493 -> :151-273) ----------------------------------
+    def _fix_disconnected(self, n, edges_a, edges_b, weight):
+        """One repair round (nabo/_mapping.py:203-249): every component that has a strictly larger
+        one gets an edge from its member closest (Euclidean) to any cell of those larger components.
+        The reference walks full order rows; here it is a masked 1-NN query on the GPU.
+        Returns (new edges, number of components before the round)."""
+        uf = _Components(n)
+        for a, b in zip(edges_a, edges_b):
+            uf.union(int(a), int(b))
+        lab = uf.labels()
+        comps, sizes = np.unique(lab, return_counts=True)
+        if len(comps) == 1:
+            return [], 1
+        ref = self._ref_matrix()
+        new = []
+        for c, sz in zip(comps, sizes):
+            larger = comps[sizes > sz]
+            if len(larger) == 0:
+                continue
+            members = np.nonzero(lab == c)[0]
+            mask = (~np.isin(lab, larger)).astype(np.uint8)
+            idx, dist = _knn.knn(ref[members], ref, 1, metric=EUCLIDEAN, ref_mask=mask, drop_first=False,
+                                 device=self._device)
+            best = int(np.lexsort((idx[:, 0], members, dist[:, 0]))[0])
+            new.append((int(members[best]), int(idx[best, 0]), weight))
+        return new, len(comps)
+
+    def calc_snn(self, target_sorted_dist_grp, target_name, graph_grp, fix_graph_attempts=5, fix_weight=None):
+        """Shared-nearest-neighbour graph from the stored neighbour lists; written in the layout
+        Graph.load_from_h5 reads."""
+        if self._k is None:
+            raise ValueError("ERROR: Set parameters first")
+        k = self._k
+        with _h5py().File(self._h5Fn, mode="r") as h5:
+            if self._refSortedDistGrp not in h5:
+                raise KeyError("ERROR: Please make sure that the distances between reference cells has "
+                               "already been calculated")
+            if target_sorted_dist_grp not in h5:
+                raise KeyError("ERROR: Please make sure that the distances between reference and target "
+                               "cells has already been calculated")
+            t_cells, t_idx = self._load_knn(h5, target_sorted_dist_grp)
+            r_cells, r_idx = self._load_knn(h5, self._refSortedDistGrp)
+        if t_idx.shape[1] < k or r_idx.shape[1] < k:
+            raise ValueError("ERROR: stored neighbour lists are shorter than k=%d; recompute the distances" % k)
+        order = {c: i for i, c in enumerate(r_cells)}
+        if r_cells != list(self.refCells):
+            r_idx = r_idx[[order[c] for c in self.refCells]]
+        et, ej, ew = snn_edges(t_idx, r_idx, k, device=self._device)
+        is_ref = (target_name == self.refName)
+        extra = []
+        if is_ref:
+            n = len(self.refCells)
+            tpos = np.array([order[c] for c in t_cells]) if t_cells != list(self.refCells) else np.arange(n)
+            ea, eb = list(tpos[et]), list(ej)
+            if fix_weight is None:
+                fix_weight = 0.5 / ((2 * (k - 1)) - 0.5)
+            new, n_comp = self._fix_disconnected(n, ea, eb, fix_weight)
+            if n_comp > 1:
+                print("INFO: Reference graph is disconnected. Trying to fix..")
+                for _ in range(fix_graph_attempts):
+                    for a, b, w in new:
+                        ea.append(a)
+                        eb.append(b)
+                        extra.append((a, b, w))
+                    new, n_comp = self._fix_disconnected(n, ea, eb, fix_weight)
+                    if n_comp == 1:
+                        print("INFO: Reference graph is no longer disconnected.")
+                        break
+            if n_comp > 1:
+                print("WARNING: Output graph is disconnected.")
+        self._dump_graph(graph_grp, t_cells, target_name, is_ref, et, ej, ew, extra)
+
+    def _dump_graph(self, out_grp, t_cells, target_name, is_ref, et, ej, ew, extra):
+        """The a10 wire format (nabo/_mapping.py:252-273): per node one dataset of
+        (neighbour name, weight) rows coerced to byte strings."""
+        ref_nodes = [c + "_" + self.refName for c in self.refCells]
+        t_nodes = [c + "_" + target_name for c in t_cells]
+        adj = [dict() for _ in t_cells]
+        if is_ref:
+            pos = {c: i for i, c in enumerate(t_cells)}
+            rpos = [pos[c] for c in self.refCells]
+            for t, j, w in zip(et, ej, ew):
+                adj[t][ref_nodes[j]] = w
+                adj[rpos[j]][t_nodes[t]] = w
+            for a, b, w in extra:            # repair edges are given in reference-cell positions
+                adj[rpos[a]][ref_nodes[b]] = w
+                adj[rpos[b]][ref_nodes[a]] = w
+        else:
+            for t, j, w in zip(et, ej, ew):
+                adj[t][ref_nodes[j]] = w
+        with _h5py().File(self._h5Fn, mode="a") as h5:
+            if out_grp in h5:
+                del h5[out_grp]
+            out = h5.create_group(out_grp)
+            for node, nb in zip(t_nodes, adj):
+                if len(nb) == 0:
+                    out.create_dataset(node, data=np.empty((0,), dtype=np.float64))
+                    continue
+                rows = [(n2.encode("ascii"), repr(float(w)).encode("ascii")) for n2, w in nb.items()]
+                width = max(32, max(len(r[0]) for r in rows))
+                out.create_dataset(node, data=np.array(rows, dtype="S%d" % width))
+
+    # ---- entry points (nabo/_mapping.py:526-541, :557-621) ----------------------------------
+    def make_ref_graph(self, use_stored_distances=False):
+        if use_stored_distances is False:
+            self.calc_dist(self._refPcaFn, self._refPcaGrp, self._refDistGrp, self._refSortedDistGrp, [])
+        self.calc_snn(self._refSortedDistGrp, self.refName, self._refGraphGrpName)
+
+    def map_target(self, target_name, target_pca_fn, target_pca_grp_name, ignore_ref_cells=None,
+                   use_stored_distances=False, overwrite=False):
+        if target_pca_fn == self._refPcaFn and target_pca_grp_name == self._refPcaGrp:
+            raise ValueError("ERROR: Target PCA file name and group name can not be same as that of reference")
+        if target_pca_fn == self._h5Fn:
+            raise ValueError("ERROR: Input HDF5 and output HDF5 file cannot be same")
+        if target_name == self.refName:
+            raise ValueError("ERROR: Target name cannot be same as reference name. Please provide a "
+                             "different name.")
+        if target_name.find("__") != -1:
+            raise ValueError("ERROR: Underscores are not allowed in the value for `target_name` parameter")
+        if ignore_ref_cells is None:
+            ignore_ref_cells = []
+        if use_stored_distances is True:
+            if target_name not in self._nameStash:
+                print("WARNING: Target data not saved. use_stored_distances will have no effect")
+            else:
+                if overwrite is True:
+                    print("WARNING: overwrite has no effect as use_stored_distances is set to True")
+                self.calc_snn(self._nameStash[target_name] + "_sortedDist", target_name,
+                              self._nameStash[target_name] + "_graph")
+                return None
+        else:
+            if overwrite is False and target_name in self._nameStash:
+                raise ValueError("ERROR: Data with this target name exists. Please set overwrite=True if "
+                                 "you want to map this target again.")
+        self._stash_target_name(target_name)
+        self._check_h5(target_pca_fn, target_pca_grp_name)
+        uid = self._nameStash[target_name]
+        self.calc_dist(target_pca_fn, target_pca_grp_name, uid + "_dist", uid + "_sortedDist", ignore_ref_cells)
+        self.calc_snn(uid + "_sortedDist", target_name, uid + "_graph")
+        return None

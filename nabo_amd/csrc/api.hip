@@ -1,0 +1,534 @@
+// api.hip -- C ABI of libnabo_knn.so (include/nabo_knn.h).  Host orchestration only:
+// buffer management, kernel sequencing on the index's HIP stream, HIP-event timing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nabo_knn.h"
+
+namespace nabo {
+// kernels (pack.hip, l2_topk.hip, refine.hip, canberra.hip)
+hipError_t centre_launch(const double *Y, int64_t n, int g, double *centre, hipStream_t st);
+hipError_t pack_ref_launch(const double *Y, int64_t n, int g, const double *centre, int ksteps, int64_t ntiles_total,
+                           const uint8_t *mask, float *out, unsigned int *norm_max_bits, hipStream_t st);
+hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *centre, int ksteps,
+                             int64_t ntiles_total, float *out, double *xnorm, hipStream_t st);
+hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
+                          uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st);
+hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t n, int g, int metric, double f,
+                           double *D, hipStream_t st);
+hipError_t refine_launch(const double *X, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
+                         const float *cand_tau, int S, int L, const double *xnorm, double err_coef, double ymax_sqrt,
+                         int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
+                         int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
+                         unsigned int *fail_count, hipStream_t st);
+hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
+                             const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
+                             int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
+                             double *out_dist, hipStream_t st);
+hipError_t masked_tail_launch(const double *X, int64_t m, const double *Y, int g, int metric, double f,
+                              const uint32_t *masked_list, int n_masked_list, int n_valid, int k, int drop,
+                              int64_t base, int64_t *out_idx, double *out_dist, hipStream_t st);
+hipError_t transpose_ref_launch(const double *Y, int64_t n, int g, double *Yt, hipStream_t st);
+hipError_t canberra_topk_launch(int epl, const double *X, int64_t m, const double *Yt, int64_t n, int g, double f,
+                                const uint8_t *mask, int S, double *cand_d, uint32_t *cand_i, hipStream_t st);
+hipError_t merge_local_launch(const double *cand_d, const uint32_t *cand_i, int64_t m, int P, int k, int drop,
+                              int64_t base, int64_t *out_idx, double *out_dist, int *n_found, hipStream_t st);
+hipError_t merge_parts_launch(const double *parts_d, const int64_t *parts_i, int n_parts, int64_t m, int kp, int k,
+                              int drop, int64_t *out_idx, double *out_dist, hipStream_t st);
+hipError_t snn_counts_launch(const int64_t *t_idx, int64_t m, const int64_t *r_idx, int64_t n, int k, int32_t *out,
+                             hipStream_t st);
+}  // namespace nabo
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            return fail(e__ == hipErrorOutOfMemory ? NABO_E_NOMEM : NABO_E_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(e__));                                        \
+    } while (0)
+
+int use_device(int device)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        return fail(NABO_E_NODEVICE, "no HIP device is available (libnabo_knn has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(NABO_E_NODEVICE, "device %d out of range (have %d)", device, cnt);
+    HIP_TRY(hipSetDevice(device));
+    return NABO_OK;
+}
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return NABO_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(NABO_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        }
+        cap = want;
+        return NABO_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+int pick_ksteps(int g)
+{
+    const int need = (g + 1) / 2;
+    const int inst[] = {8, 16, 25, 32, 50, 64};
+    for (int v : inst)
+        if (need <= v) return v;
+    return -1;
+}
+
+int env_int(const char *name, int dflt)
+{
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+}  // namespace
+
+struct nabo_index {
+    int device = 0;
+    int64_t n = 0;
+    int g = 0;
+    int metric = 0;
+    double f = 0.25;
+    int64_t base = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {};
+    bool have_ref = false;
+
+    const double *dY = nullptr;      // [n,g] float64 on device (borrowed or == ybuf)
+    DevBuf ybuf, maskbuf, mlistbuf;
+    const uint8_t *dmask = nullptr;
+    int64_t n_masked = 0;
+    int n_masked_list = 0;
+
+    // Euclidean path
+    int ksteps = 0;
+    DevBuf centre, ypk, normmax;
+    int64_t ref_tiles = 0, ref_tiles_alloc = 0;
+    double ymax_sqrt = 0.0;
+    // Canberra path
+    DevBuf yt;
+
+    // query workspace
+    DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_d, fails, failcnt, oidx, odist, nfound;
+
+    double ms[5] = {0, 0, 0, 0, 0};
+    int64_t counters[4] = {0, 0, 0, 0};
+};
+
+extern "C" {
+
+const char *nabo_version(void) { return "nabo_knn 0.1 (gfx950)"; }
+const char *nabo_last_error(void) { return g_err; }
+
+int nabo_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt < 0 ? 0 : cnt;
+}
+
+int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g, int32_t metric,
+                      double dist_factor, int64_t ref_index_base)
+{
+    if (!out) return fail(NABO_E_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n_ref < 1 || n_ref >= 0xFFFFFFF0ll) return fail(NABO_E_INVALID, "n_ref=%lld out of range", (long long)n_ref);
+    if (g < 1) return fail(NABO_E_INVALID, "g=%d must be >= 1", g);
+    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_MOD_CANBERRA)
+        return fail(NABO_E_INVALID, "unknown metric %d", metric);
+    if (metric == NABO_METRIC_MOD_CANBERRA && !(dist_factor > 0))
+        return fail(NABO_E_INVALID, "dist_factor must be > 0");          // nabo/_mapping.py:516-521
+    if (metric == NABO_METRIC_EUCLIDEAN && g > NABO_MAX_COMPS)
+        return fail(NABO_E_UNSUPPORTED, "g=%d exceeds NABO_MAX_COMPS=%d", g, NABO_MAX_COMPS);
+    if (ref_index_base < 0) return fail(NABO_E_INVALID, "ref_index_base must be >= 0");
+    int rc = use_device(device);
+    if (rc) return rc;
+    nabo_index *ix = new (std::nothrow) nabo_index();
+    if (!ix) return fail(NABO_E_NOMEM, "host allocation failed");
+    ix->device = device;
+    ix->n = n_ref;
+    ix->g = g;
+    ix->metric = metric;
+    ix->f = dist_factor;
+    ix->base = ref_index_base;
+    if (metric == NABO_METRIC_EUCLIDEAN) ix->ksteps = pick_ksteps(g);
+    hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&ix->ev[i]);
+    if (e != hipSuccess) {
+        nabo_index_destroy(ix);
+        return fail(NABO_E_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    return NABO_OK;
+}
+
+int nabo_index_destroy(nabo_index *ix)
+{
+    if (!ix) return NABO_OK;
+    (void)hipSetDevice(ix->device);
+    if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+    DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->normmax, &ix->yt,
+                      &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_d, &ix->fails,
+                      &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
+    for (DevBuf *b : bufs) b->release();
+    for (int i = 0; i < 6; ++i)
+        if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+    return NABO_OK;
+}
+
+int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, const uint8_t *ref_mask)
+{
+    if (!ix || !Y) return fail(NABO_E_INVALID, "NULL argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    hipStream_t st = ix->stream;
+    const size_t ybytes = (size_t)ix->n * ix->g * sizeof(double);
+    if (y_on_device) {
+        ix->dY = Y;
+    } else {
+        if ((rc = ix->ybuf.reserve(ybytes))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->ybuf.p, Y, ybytes, hipMemcpyHostToDevice, st));
+        ix->dY = ix->ybuf.as<double>();
+    }
+    // mask + ascending list of the first masked indices (order-row tail, nabo/_mapping.py:135-144)
+    ix->dmask = nullptr;
+    ix->n_masked = 0;
+    ix->n_masked_list = 0;
+    if (ref_mask) {
+        std::vector<uint32_t> lst;
+        for (int64_t j = 0; j < ix->n; ++j)
+            if (ref_mask[j]) {
+                ++ix->n_masked;
+                if ((int)lst.size() < NABO_MAX_K) lst.push_back((uint32_t)j);
+            }
+        if (ix->n_masked > 0) {
+            if ((rc = ix->maskbuf.reserve((size_t)ix->n))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->maskbuf.p, ref_mask, (size_t)ix->n, hipMemcpyHostToDevice, st));
+            ix->dmask = ix->maskbuf.as<uint8_t>();
+            if ((rc = ix->mlistbuf.reserve(lst.size() * sizeof(uint32_t)))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->mlistbuf.p, lst.data(), lst.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));      // lst goes out of scope
+            ix->n_masked_list = (int)lst.size();
+        }
+    }
+    if (ix->metric == NABO_METRIC_EUCLIDEAN) {
+        const int Q = (ix->ksteps + 3) / 4;
+        const size_t rtf = (size_t)Q * 256 + 32;
+        ix->ref_tiles = (ix->n + 31) / 32;
+        ix->ref_tiles_alloc = ix->ref_tiles + 16;      // room for split padding (+inf-norm tiles)
+        if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
+        if ((rc = ix->ypk.reserve((size_t)ix->ref_tiles_alloc * rtf * sizeof(float)))) return rc;
+        if ((rc = ix->normmax.reserve(sizeof(unsigned int)))) return rc;
+        HIP_TRY(hipMemsetAsync(ix->normmax.p, 0, sizeof(unsigned int), st));
+        HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
+        HIP_TRY(nabo::pack_ref_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->ksteps, ix->ref_tiles_alloc,
+                                      ix->dmask, ix->ypk.as<float>(), ix->normmax.as<unsigned int>(), st));
+        unsigned int bits = 0;
+        HIP_TRY(hipMemcpyAsync(&bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float fmax;
+        memcpy(&fmax, &bits, sizeof(fmax));
+        ix->ymax_sqrt = std::sqrt((double)fmax) * (1.0 + 1e-6);
+    } else {
+        const int64_t chunks = (ix->n + 63) / 64;
+        if ((rc = ix->yt.reserve((size_t)chunks * 64 * ix->g * sizeof(double)))) return rc;
+        HIP_TRY(nabo::transpose_ref_launch(ix->dY, ix->n, ix->g, ix->yt.as<double>(), st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    ix->have_ref = true;
+    return NABO_OK;
+}
+
+int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k,
+                     int32_t drop_first, int64_t *out_idx, double *out_dist, int32_t out_on_device)
+{
+    if (!ix || !X || !out_idx || !out_dist) return fail(NABO_E_INVALID, "NULL argument");
+    if (!ix->have_ref) return fail(NABO_E_INVALID, "nabo_index_set_ref has not been called");
+    if (m < 1) return fail(NABO_E_INVALID, "m=%lld must be >= 1", (long long)m);
+    const int drop = drop_first ? 1 : 0;
+    const int kk = k + drop;
+    if (k < 1) return fail(NABO_E_INVALID, "k=%d must be >= 1", k);
+    if (kk > ix->n) return fail(NABO_E_INVALID, "k + drop_first = %d exceeds the %lld references", kk, (long long)ix->n);
+    if (kk > NABO_MAX_K) return fail(NABO_E_UNSUPPORTED, "k + drop_first = %d exceeds NABO_MAX_K=%d", kk, NABO_MAX_K);
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    hipStream_t st = ix->stream;
+    const int g = ix->g;
+    const int64_t n_valid = ix->n - ix->n_masked;
+
+    // operands / results on device
+    const double *dX = X;
+    if (!x_on_device) {
+        const size_t xb = (size_t)m * g * sizeof(double);
+        if ((rc = ix->xbuf.reserve(xb))) return rc;
+        HIP_TRY(hipMemcpyAsync(ix->xbuf.p, X, xb, hipMemcpyHostToDevice, st));
+        dX = ix->xbuf.as<double>();
+    }
+    int64_t *d_oidx = out_idx;
+    double *d_odist = out_dist;
+    const size_t ob = (size_t)m * k * 8;
+    if (!out_on_device) {
+        if ((rc = ix->oidx.reserve(ob))) return rc;
+        if ((rc = ix->odist.reserve(ob))) return rc;
+        d_oidx = ix->oidx.as<int64_t>();
+        d_odist = ix->odist.as<double>();
+    }
+    const int epl = kk <= 24 ? 1 : 2;
+    const int L = 32 * epl;
+    unsigned int n_fail = 0;
+    int S = 1;
+    int64_t n_wg = 0;
+    HIP_TRY(hipEventRecord(ix->ev[0], st));
+
+    if (ix->metric == NABO_METRIC_EUCLIDEAN) {
+        const int R = epl == 1 ? 2 : 1;
+        const int rows_per_wg = 4 * R * 32;
+        const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
+        const int64_t rows_pad = gx * rows_per_wg;
+        const int Q = (ix->ksteps + 3) / 4;
+        // reference splits: enough workgroups to fill 256 CUs when there are few target rows
+        S = env_int("NABO_SPLITS", 0);
+        if (S <= 0) {
+            S = 1;
+            if (gx < 512) {
+                S = (int)((1024 + gx - 1) / gx);
+                const int64_t max_by_tiles = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
+                if (S > max_by_tiles) S = (int)max_by_tiles;
+                if (S > 8) S = 8;
+            }
+        }
+        if (S > 8) S = 8;
+        if (S < 1) S = 1;
+        if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
+        const int64_t tps = (ix->ref_tiles + S - 1) / S;
+        if (tps * S > ix->ref_tiles_alloc) return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
+        if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * Q * 256 * sizeof(float)))) return rc;
+        if ((rc = ix->xnorm.reserve((size_t)m * sizeof(double)))) return rc;
+        if ((rc = ix->cand_idx.reserve((size_t)rows_pad * S * L * sizeof(uint32_t)))) return rc;
+        if ((rc = ix->cand_tau.reserve((size_t)rows_pad * S * sizeof(float)))) return rc;
+        if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
+        if ((rc = ix->failcnt.reserve(sizeof(unsigned int)))) return rc;
+        HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
+        HIP_TRY(nabo::pack_query_launch(dX, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
+                                        ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
+        HIP_TRY(hipEventRecord(ix->ev[1], st));
+        HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S, (int)gx,
+                                     ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(), st));
+        HIP_TRY(hipEventRecord(ix->ev[2], st));
+        const double err_coef = 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
+        HIP_TRY(nabo::refine_launch(dX, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
+                                    ix->xnorm.as<double>(), err_coef, ix->ymax_sqrt, k, drop, ix->base, n_valid,
+                                    ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
+                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st));
+        HIP_TRY(hipEventRecord(ix->ev[3], st));
+        HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
+                                        n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
+                                        d_oidx, d_odist, st));
+        HIP_TRY(hipEventRecord(ix->ev[4], st));
+        n_wg = gx * S;
+    } else {
+        const int64_t n_chunks = (ix->n + 63) / 64;
+        const int64_t gx = (m + 63) / 64;
+        S = env_int("NABO_SPLITS", 0);
+        if (S <= 0) {
+            S = 1;
+            if (gx < 512) {
+                S = (int)((1024 + gx - 1) / gx);
+                if (S > n_chunks) S = (int)n_chunks;
+                if (S > 16) S = 16;
+            }
+        }
+        if (S > 16) S = 16;
+        if (S < 1) S = 1;
+        if ((rc = ix->cand_d.reserve((size_t)m * S * L * sizeof(double)))) return rc;
+        if ((rc = ix->cand_idx.reserve((size_t)m * S * L * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipEventRecord(ix->ev[1], st));
+        HIP_TRY(nabo::canberra_topk_launch(epl, dX, m, ix->yt.as<double>(), ix->n, g, ix->f, ix->dmask, S,
+                                           ix->cand_d.as<double>(), ix->cand_idx.as<uint32_t>(), st));
+        HIP_TRY(hipEventRecord(ix->ev[2], st));
+        HIP_TRY(nabo::merge_local_launch(ix->cand_d.as<double>(), ix->cand_idx.as<uint32_t>(), m, S * L, k, drop,
+                                         ix->base, d_oidx, d_odist, nullptr, st));
+        HIP_TRY(hipEventRecord(ix->ev[3], st));
+        if (n_valid < kk)
+            HIP_TRY(nabo::masked_tail_launch(dX, m, ix->dY, g, ix->metric, ix->f, ix->mlistbuf.as<uint32_t>(),
+                                             ix->n_masked_list, (int)n_valid, k, drop, ix->base, d_oidx, d_odist, st));
+        HIP_TRY(hipEventRecord(ix->ev[4], st));
+        n_wg = gx * S;
+    }
+    if (!out_on_device) {
+        HIP_TRY(hipMemcpyAsync(out_idx, d_oidx, ob, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_dist, d_odist, ob, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipEventRecord(ix->ev[5], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float t = 0;
+    for (int i = 0; i < 4; ++i) {
+        HIP_TRY(hipEventElapsedTime(&t, ix->ev[i], ix->ev[i + 1]));
+        ix->ms[i] = t;
+    }
+    HIP_TRY(hipEventElapsedTime(&t, ix->ev[0], ix->ev[5]));
+    ix->ms[4] = t;
+    ix->counters[0] = n_fail;
+    ix->counters[1] = S;
+    ix->counters[2] = L;
+    ix->counters[3] = n_wg;
+    return NABO_OK;
+}
+
+int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4])
+{
+    if (!ix) return fail(NABO_E_INVALID, "NULL index");
+    if (ms) memcpy(ms, ix->ms, sizeof(ix->ms));
+    if (counters) memcpy(counters, ix->counters, sizeof(ix->counters));
+    return NABO_OK;
+}
+
+int nabo_knn(const double *X, int64_t m, const double *Y, int64_t n, int32_t g, int32_t k, int32_t metric,
+             double dist_factor, const uint8_t *ref_mask, int32_t drop_first, int64_t *out_idx, double *out_dist,
+             int32_t device)
+{
+    if (!X || !Y || !out_idx || !out_dist) return fail(NABO_E_INVALID, "NULL argument");
+    nabo_index *ix = nullptr;
+    int rc = nabo_index_create(&ix, device, n, g, metric, dist_factor, 0);
+    if (rc) return rc;
+    rc = nabo_index_set_ref(ix, Y, 0, ref_mask);
+    if (!rc) rc = nabo_index_query(ix, X, 0, m, k, drop_first, out_idx, out_dist, 0);
+    nabo_index_destroy(ix);
+    return rc;
+}
+
+int nabo_pairwise(const double *X, int64_t m, const double *Y, int64_t n, int32_t g, int32_t metric,
+                  double dist_factor, double *D, int32_t device)
+{
+    if (!X || !Y || !D) return fail(NABO_E_INVALID, "NULL argument");
+    if (m < 1 || n < 1 || g < 1) return fail(NABO_E_INVALID, "empty operand");
+    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_MOD_CANBERRA)
+        return fail(NABO_E_INVALID, "unknown metric %d", metric);
+    if (m > 65535) return fail(NABO_E_UNSUPPORTED, "nabo_pairwise is the tile-sized seam: m <= 65535");
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf dx, dy, dd;
+    const size_t xb = (size_t)m * g * 8, yb = (size_t)n * g * 8, db = (size_t)m * n * 8;
+    if ((rc = dx.reserve(xb)) || (rc = dy.reserve(yb)) || (rc = dd.reserve(db))) {
+        dx.release(); dy.release(); dd.release();
+        return rc;
+    }
+    hipError_t e = hipMemcpy(dx.p, X, xb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dy.p, Y, yb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = nabo::pairwise_launch(dx.as<double>(), m, dy.as<double>(), n, g, metric, dist_factor,
+                                                   dd.as<double>(), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(D, dd.p, db, hipMemcpyDeviceToHost);
+    dx.release(); dy.release(); dd.release();
+    if (e != hipSuccess) return fail(NABO_E_HIP, "nabo_pairwise: %s", hipGetErrorString(e));
+    return NABO_OK;
+}
+
+int nabo_merge_topk(int32_t device, const int64_t *parts_idx, const double *parts_dist, int32_t n_parts, int64_t m,
+                    int32_t kp, int32_t k, int32_t drop_first, int64_t *out_idx, double *out_dist)
+{
+    if (!parts_idx || !parts_dist || !out_idx || !out_dist) return fail(NABO_E_INVALID, "NULL argument");
+    const int drop = drop_first ? 1 : 0;
+    if (n_parts < 1 || m < 1 || kp < 1 || k < 1) return fail(NABO_E_INVALID, "bad shape");
+    if (k + drop > n_parts * kp) return fail(NABO_E_INVALID, "k + drop_first exceeds n_parts * kp");
+    if ((int64_t)n_parts * kp > 1024) return fail(NABO_E_UNSUPPORTED, "n_parts * kp > 1024");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(nabo::merge_parts_launch(parts_dist, parts_idx, n_parts, m, kp, k, drop, out_idx, out_dist, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NABO_OK;
+}
+
+int nabo_snn_counts(int32_t device, const int64_t *t_idx, int64_t m, const int64_t *r_idx, int64_t n, int32_t k,
+                    int32_t *out_snn)
+{
+    if (!t_idx || !r_idx || !out_snn) return fail(NABO_E_INVALID, "NULL argument");
+    if (m < 1 || n < 1 || k < 1) return fail(NABO_E_INVALID, "bad shape");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(nabo::snn_counts_launch(t_idx, m, r_idx, n, k, out_snn, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return NABO_OK;
+}
+
+int nabo_dev_malloc(int32_t device, void **ptr, size_t bytes)
+{
+    if (!ptr) return fail(NABO_E_INVALID, "NULL argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(ptr, bytes ? bytes : 1));
+    return NABO_OK;
+}
+
+int nabo_dev_free(int32_t device, void *ptr)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return NABO_OK;
+}
+
+int nabo_memcpy_h2d(int32_t device, void *dst, const void *src, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return NABO_OK;
+}
+
+int nabo_memcpy_d2h(int32_t device, void *dst, const void *src, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return NABO_OK;
+}
+
+int nabo_dev_synchronize(int32_t device)
+{
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return NABO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+// knn_common.h -- shared definitions for the gfx950 k-NN kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nabo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+constexpr int TILE = 32;                 // cells per MFMA tile (32x32x2 f32)
+
+// ---------------------------------------------------------------------------------------
+// Packed operand tiles for v_mfma_f32_32x32x2_f32.
+// One tile = 32 cells.  K-step s consumes components k = 2s, 2s+1; lane l supplies
+// cell (l & 31), component 2s + (l >> 5)  (A and B operand maps are the same shape).
+// Four K-steps are packed per lane so a fragment group is ONE 16-byte load per lane:
+//   frag[q][l][e] = v[cell = l & 31][k = 2*(4q + e) + (l >> 5)],   q < Q = ceil(KSTEPS/4)
+// Reference tiles carry, behind the fragments, the accumulator-initialisation block
+//   norm[h][r] = ||y||^2 of cell (r&3) + 8*(r>>2) + 4*h      (the C/D row map of the MFMA)
+// so that lane (l>>5 == h) loads its 16 C-in values as one 64-byte read.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ constexpr int q_groups(int ksteps) { return (ksteps + 3) / 4; }
+__host__ __device__ constexpr int qtile_floats(int ksteps) { return q_groups(ksteps) * 256; }
+__host__ __device__ constexpr int rtile_floats(int ksteps) { return q_groups(ksteps) * 256 + 32; }
+
+// C/D row of accumulator register r in lane-half h (cdna_hip_programming.md section 3)
+__host__ __device__ constexpr int cd_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Canonical order on (key, idx): key ascending, then idx ascending.
+template <typename K>
+__device__ __forceinline__ bool kv_less(K ka, uint32_t va, K kb, uint32_t vb)
+{
+    return (ka < kb) || (ka == kb && va < vb);
+}
+
+__device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ uint32_t shfl_xor_t(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+__device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// Wave-wide bitonic sort of N = 64*EPL (key, val) pairs, ascending in the canonical order.
+// Element index e = r*64 + lane (r = register slot).  After the call element e holds rank e.
+template <int EPL, typename K>
+__device__ __forceinline__ void wave_bitonic_sort(K (&key)[EPL], uint32_t (&val)[EPL])
+{
+    const int lane = lane_id();
+    constexpr int N = 64 * EPL;
+#pragma unroll
+    for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int dr = j >> 6;
+#pragma unroll
+                for (int r = 0; r < EPL; ++r) {
+                    const int rp = r ^ dr;
+                    if (rp > r) {
+                        const bool asc = (((r * 64) & k) == 0) || (k == N);
+                        const bool lt = kv_less<K>(key[rp], val[rp], key[r], val[r]);  // partner < self
+                        if (lt == asc) {
+                            K tk = key[r]; key[r] = key[rp]; key[rp] = tk;
+                            uint32_t tv = val[r]; val[r] = val[rp]; val[rp] = tv;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < EPL; ++r) {
+                    const int e = r * 64 + lane;
+                    const bool asc = ((e & k) == 0) || (k == N);
+                    const bool lower = (lane & j) == 0;
+                    const K pk = shfl_xor_t(key[r], j);
+                    const uint32_t pv = shfl_xor_t(val[r], j);
+                    const bool plt = kv_less<K>(pk, pv, key[r], val[r]);   // partner < self
+                    const bool keep_min = (lower == asc);
+                    const bool take = keep_min ? plt : !plt && !(pk == key[r] && pv == val[r]);
+                    if (take) { key[r] = pk; val[r] = pv; }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace nabo

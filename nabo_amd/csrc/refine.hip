@@ -1,0 +1,291 @@
+// refine.hip -- float64 re-evaluation, certification and exact fallback (gfx950).
+//
+// This is where results become the reference's: every candidate distance is recomputed
+// exactly as nabo/_mapping.py:20-26 does it -- float64, components in ascending order,
+// rounded multiply then rounded add (no FMA: __dmul_rn/__dadd_rn), correctly rounded sqrt --
+// and rows are ordered by (distance, index), the canonical form of the np.argsort at
+// nabo/_mapping.py:139-145 (masked refs last, positional `[1:]` drop for intra_ref).
+//
+// Certification (per row): the fp32 filter guarantees every NON-candidate j has score
+// a_j >= tau.  With  |a_j + ||x~||^2 - d_j^2| <= E  (rounding-error bound of the fp32 fma
+// chain + fp32 input rounding), a row is certified when
+//       tau_min + ||x~||^2 - E  >  d_(k')^2          (k' = k + drop_first, exact value)
+// i.e. nothing outside the candidate set can enter or tie with the first k'.  Rows that fail
+// (duplicates, pathological gaps) are re-solved by exact_rows_kernel, which brute-forces the
+// whole reference set in float64 on the GPU.  There is no CPU path.
+#include "knn_common.h"
+
+namespace nabo {
+
+// Exact reference distance (nabo/_mapping.py:20-26).
+__device__ __forceinline__ double euclid_exact(const double *__restrict__ x, const double *__restrict__ y, int g)
+{
+    double td = 0.0;
+    for (int k = 0; k < g; ++k) {
+        const double t = __dsub_rn(x[k], y[k]);
+        td = __dadd_rn(td, __dmul_rn(t, t));
+    }
+    return __dsqrt_rn(td);
+}
+
+// Exact modified Canberra (nabo/_mapping.py:33-45); x = target, y = reference.
+__device__ __forceinline__ double canberra_exact(const double *__restrict__ x, const double *__restrict__ y, int g,
+                                                 double f)
+{
+    double dist = 0.0;
+    for (int k = 0; k < g; ++k) {
+        const double xv = x[k], yv = y[k];
+        const double absx = fabs(xv);
+        const double num = fabs(__dsub_rn(xv, yv));
+        if (num < __dmul_rn(f, absx)) {
+            const double den = __dadd_rn(__dadd_rn(absx, fabs(yv)), 0.01);
+            dist = __dadd_rn(dist, __ddiv_rn(num, den));
+        } else {
+            dist = __dadd_rn(dist, 1.0);
+        }
+    }
+    return dist;
+}
+
+// ---- fine seam: dense D[m,n] (a1 / a2 literal) -------------------------------------------
+__global__ void pairwise_kernel(const double *__restrict__ X, int64_t m, const double *__restrict__ Y, int64_t n,
+                                int g, int metric, double f, double *__restrict__ D)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n || i >= m) return;
+    const double *x = X + i * g, *y = Y + j * g;
+    D[i * n + j] = metric == 0 ? euclid_exact(x, y, g) : canberra_exact(x, y, g, f);
+}
+
+// Rows with fewer valid (unmasked) references than k': the order row continues with the
+// masked references (NaN-filled by numpy.ma -> sorted last), by ascending index, carrying
+// their true distances.  masked_list holds the first masked indices in ascending order.
+__device__ void emit_masked_tail(const double *__restrict__ x, const double *__restrict__ Y, int g, int metric,
+                                 double f, const uint32_t *__restrict__ masked_list, int n_masked_list,
+                                 int n_valid, int k, int drop, int64_t base, int64_t *__restrict__ oi,
+                                 double *__restrict__ od)
+{
+    // positions p (in the full order row) n_valid .. k+drop-1 come from the masked list
+    for (int p = n_valid + (int)threadIdx.x % 64; p < k + drop; p += 64) {
+        const int q = p - n_valid;
+        const int o = p - drop;
+        if (o < 0) continue;
+        if (q < n_masked_list) {
+            const uint32_t j = masked_list[q];
+            oi[o] = base + j;
+            od[o] = metric == 0 ? euclid_exact(x, Y + (int64_t)j * g, g) : canberra_exact(x, Y + (int64_t)j * g, g, f);
+        } else {
+            oi[o] = -1;
+            od[o] = __builtin_nan("");
+        }
+    }
+}
+
+// One wave per target row; NCL = ceil(S*L/64) candidates per lane.
+template <int NCL>
+__global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t m,
+                                                     const double *__restrict__ Y, int g,
+                                                     const uint32_t *__restrict__ cand_idx,
+                                                     const float *__restrict__ cand_tau, int S, int L,
+                                                     const double *__restrict__ xnorm, double err_coef,
+                                                     double ymax_sqrt, int k, int drop, int64_t base,
+                                                     int64_t n_valid_total,
+                                                     const uint32_t *__restrict__ masked_list, int n_masked_list,
+                                                     int64_t *__restrict__ out_idx, double *__restrict__ out_dist,
+                                                     uint32_t *__restrict__ fail_rows,
+                                                     unsigned int *__restrict__ fail_count)
+{
+    const int lane = lane_id();
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const double *x = X + row * g;
+    const int ncand = S * L;
+    double key[NCL];
+    uint32_t val[NCL];
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) {
+        const int e = r * 64 + lane;
+        key[r] = __builtin_inf();
+        val[r] = 0xFFFFFFFFu;
+        if (e < ncand) {
+            const uint32_t j = cand_idx[row * ncand + e];
+            if (j != 0xFFFFFFFFu) {
+                val[r] = j;
+                key[r] = euclid_exact(x, Y + (int64_t)j * g, g);
+            }
+        }
+    }
+    wave_bitonic_sort<NCL, double>(key, val);
+    // number of real candidates
+    int nreal = 0;
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) nreal += __popcll(__builtin_amdgcn_ballot_w64(val[r] != 0xFFFFFFFFu));
+    const int kk = k + drop;
+    // threshold below which no reference was discarded by the filter (min over splits)
+    float tmin = __builtin_inff();
+    for (int s = lane; s < S; s += 64) tmin = fminf(tmin, cand_tau[row * S + s]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+
+    bool certified = true;
+    if (nreal >= kk) {
+        // exact k'-th distance
+        const int e = kk - 1;
+        double dk = 0.0;
+#pragma unroll
+        for (int r = 0; r < NCL; ++r)
+            if ((e >> 6) == r) dk = __shfl(key[r], e & 63, 64);
+        if (tmin != __builtin_inff()) {
+            const double sx = sqrt(xnorm[row]);
+            const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
+            const double bound = ((double)tmin + xnorm[row] - E) * (1.0 - 1e-12);
+            certified = bound > dk * dk * (1.0 + 1e-12);
+        }
+    } else {
+        // fewer candidates than k': fine only if the filter never discarded anything
+        certified = (tmin == __builtin_inff()) || ((int64_t)nreal >= n_valid_total);
+    }
+    if (!certified) {
+        if (lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = (uint32_t)row;
+        return;
+    }
+    int64_t *oi = out_idx + row * k;
+    double *od = out_dist + row * k;
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) {
+        const int e = r * 64 + lane;
+        const int o = e - drop;
+        if (o >= 0 && o < k && e < nreal) {
+            oi[o] = base + val[r];
+            od[o] = key[r];
+        }
+    }
+    if (nreal < kk) emit_masked_tail(x, Y, g, 0, 0.0, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
+}
+
+// Exact brute force for flagged rows: one 256-thread block per row, k' selection passes over
+// all references (each pass picks the smallest (d, j) strictly after the previous pick).
+__global__ __launch_bounds__(256) void exact_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
+                                                         int64_t n, int g, int metric, double f,
+                                                         const uint8_t *__restrict__ mask,
+                                                         const uint32_t *__restrict__ rows,
+                                                         int k, int drop, int64_t base,
+                                                         const uint32_t *__restrict__ masked_list, int n_masked_list,
+                                                         int64_t *__restrict__ out_idx, double *__restrict__ out_dist)
+{
+    __shared__ double s_d[256];
+    __shared__ uint32_t s_j[256];
+    __shared__ double prev_d;
+    __shared__ uint32_t prev_j;
+    __shared__ int have_prev;
+    const int64_t row = rows[blockIdx.x];
+    const double *x = X + row * g;
+    const int kk = k + drop;
+    if (threadIdx.x == 0) { have_prev = 0; prev_d = 0.0; prev_j = 0; }
+    __syncthreads();
+    int found = 0;
+    for (int p = 0; p < kk; ++p) {
+        double bd = __builtin_inf();
+        uint32_t bj = 0xFFFFFFFFu;
+        const bool hp = have_prev != 0;
+        const double pd = prev_d;
+        const uint32_t pj = prev_j;
+        for (int64_t j = threadIdx.x; j < n; j += 256) {
+            if (mask && mask[j]) continue;
+            const double d = metric == 0 ? euclid_exact(x, Y + j * g, g) : canberra_exact(x, Y + j * g, g, f);
+            if (hp && !kv_less<double>(pd, pj, d, (uint32_t)j)) continue;   // not after previous pick
+            if (kv_less<double>(d, (uint32_t)j, bd, bj)) { bd = d; bj = (uint32_t)j; }
+        }
+        s_d[threadIdx.x] = bd;
+        s_j[threadIdx.x] = bj;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) {
+                if (kv_less<double>(s_d[threadIdx.x + w], s_j[threadIdx.x + w], s_d[threadIdx.x], s_j[threadIdx.x])) {
+                    s_d[threadIdx.x] = s_d[threadIdx.x + w];
+                    s_j[threadIdx.x] = s_j[threadIdx.x + w];
+                }
+            }
+            __syncthreads();
+        }
+        const uint32_t wj = s_j[0];
+        const double wd = s_d[0];
+        __syncthreads();
+        if (wj == 0xFFFFFFFFu) break;       // ran out of valid references
+        if (threadIdx.x == 0) {
+            prev_d = wd; prev_j = wj; have_prev = 1;
+            const int o = p - drop;
+            if (o >= 0) { out_idx[row * k + o] = base + wj; out_dist[row * k + o] = wd; }
+        }
+        ++found;
+        __syncthreads();
+    }
+    if (found < kk && threadIdx.x < 64)
+        emit_masked_tail(x, Y, g, metric, f, masked_list, n_masked_list, found, k, drop, base, out_idx + row * k,
+                         out_dist + row * k);
+}
+
+// Order-row tail for every row when the index holds fewer valid references than k'.
+__global__ __launch_bounds__(256) void masked_tail_kernel(const double *__restrict__ X, int64_t m,
+                                                          const double *__restrict__ Y, int g, int metric, double f,
+                                                          const uint32_t *__restrict__ masked_list, int n_masked_list,
+                                                          int n_valid, int k, int drop, int64_t base,
+                                                          int64_t *__restrict__ out_idx, double *__restrict__ out_dist)
+{
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    emit_masked_tail(X + row * g, Y, g, metric, f, masked_list, n_masked_list, n_valid, k, drop, base,
+                     out_idx + row * k, out_dist + row * k);
+}
+
+hipError_t masked_tail_launch(const double *X, int64_t m, const double *Y, int g, int metric, double f,
+                              const uint32_t *masked_list, int n_masked_list, int n_valid, int k, int drop,
+                              int64_t base, int64_t *out_idx, double *out_dist, hipStream_t st)
+{
+    hipLaunchKernelGGL(masked_tail_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, st, X, m, Y, g, metric, f,
+                       masked_list, n_masked_list, n_valid, k, drop, base, out_idx, out_dist);
+    return hipGetLastError();
+}
+
+hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t n, int g, int metric, double f,
+                           double *D, hipStream_t st)
+{
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)m);
+    hipLaunchKernelGGL(pairwise_kernel, grid, dim3(256), 0, st, X, m, Y, n, g, metric, f, D);
+    return hipGetLastError();
+}
+
+hipError_t refine_launch(const double *X, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
+                         const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
+                         double ymax_sqrt, int k, int drop, int64_t base, int64_t n_valid_total,
+                         const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
+                         uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st)
+{
+    const int ncl = (S * L + 63) / 64;
+    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+#define NABO_RF(N)                                                                                               \
+    hipLaunchKernelGGL((refine_kernel<N>), grid, block, 0, st, X, m, Y, g, cand_idx, cand_tau, S, L, xnorm,       \
+                       err_coef, ymax_sqrt, k, drop, base, n_valid_total, masked_list, n_masked_list, out_idx,    \
+                       out_dist, fail_rows, fail_count)
+    if (ncl <= 1) NABO_RF(1);
+    else if (ncl <= 2) NABO_RF(2);
+    else if (ncl <= 4) NABO_RF(4);
+    else if (ncl <= 8) NABO_RF(8);
+    else return hipErrorInvalidValue;
+#undef NABO_RF
+    return hipGetLastError();
+}
+
+hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
+                             const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
+                             int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
+                             double *out_dist, hipStream_t st)
+{
+    if (nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(exact_rows_kernel, dim3(nrows), dim3(256), 0, st, X, Y, n, g, metric, f, mask, rows, k, drop,
+                       base, masked_list, n_masked_list, out_idx, out_dist);
+    return hipGetLastError();
+}
+
+}  // namespace nabo

@@ -1,0 +1,57 @@
+"""The C-ABI shared library: loads without a GPU, exports every symbol the header declares,
+validates arguments, and refuses to compute without a device (no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nabo_amd
+from nabo_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(REPO, "include", "nabo_knn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nabo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_loads_and_exports_header_symbols():
+    L = _lib.lib()
+    names = _header_functions()
+    assert len(names) >= 15
+    assert sorted(names) == sorted(_lib.SYMBOLS)
+    for n in names:
+        assert hasattr(L, n), "libnabo_knn.so does not export %s" % n
+    assert b"gfx950" in L.nabo_version()
+
+
+def test_argument_validation_maps_to_value_error():
+    x = np.zeros((4, 3))
+    with pytest.raises(ValueError):
+        nabo_amd.knn(x, np.zeros((5, 2)), 2)            # component mismatch
+    with pytest.raises(ValueError):
+        nabo_amd.knn(x, np.zeros((5, 3)), 2, ref_mask=np.zeros(4, np.uint8))   # mask length
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    if nabo_amd.device_count() > 0:
+        pytest.skip("a GPU is visible here; the no-device path is covered on the CPU box")
+    x = np.random.default_rng(0).standard_normal((8, 4))
+    with pytest.raises(nabo_amd.NaboError) as e:
+        nabo_amd.knn(x, x, 2)
+    assert "no HIP device" in str(e.value)
+    with pytest.raises(nabo_amd.NaboError):
+        nabo_amd.pairwise(x, x)
+
+
+def test_product_never_imports_the_oracle():
+    """Nothing under nabo_amd/ may import, load or link oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(REPO, "nabo_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "libnabo_oracle" not in txt, f

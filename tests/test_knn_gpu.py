@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference-generated
+golden vectors.  Indices must be bit-exact, distances are compared bit-for-bit as well
+(the contract allows 1e-4 relative; the implementation recomputes them in the reference's own
+float64 arithmetic, so equality is asserted and the tolerance is only the documented bound)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from nabo_amd._synth import pca_like
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4        # north_star tolerance for distances; we assert exact equality below
+
+
+def _check(gi, gd, oi, od):
+    assert np.array_equal(gi, oi), "indices differ in %d rows" % int((gi != oi).any(axis=1).sum())
+    assert np.array_equal(gd, od), "max rel dist err %g" % float(np.max(np.abs(gd - od) / np.maximum(od, 1e-300)))
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+@pytest.mark.parametrize("d", [7, 30, 50])
+def test_pairwise_bit_exact_vs_golden(gpu_lib, golden, metric, d):
+    g = golden("kernels")
+    x, y = g["x_%d" % d], g["y_%d" % d]
+    if metric == 0:
+        assert np.array_equal(gpu_lib.pairwise(x, y, 0), g["euclid_%d" % d])
+    else:
+        for f in (0.1, 0.25, 1.0):
+            assert np.array_equal(gpu_lib.pairwise(x, y, 1, f), g["canberra_%d_%s" % (d, str(f).replace(".", "p"))])
+
+
+def test_device_sqrt_and_divide_are_correctly_rounded(gpu_lib):
+    """The refine kernel relies on IEEE sqrt/div on the device; check them on 1e5 random pairs."""
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((300, 1)) * np.exp(rng.uniform(-20, 20, (300, 1)))
+    y = rng.standard_normal((400, 1)) * np.exp(rng.uniform(-20, 20, (400, 1)))
+    assert np.array_equal(gpu_lib.pairwise(x, y, 0), np.abs(x - y.T))        # sqrt(t*t) == |t|
+    assert np.array_equal(gpu_lib.pairwise(x, y, 1, 1e9), oracle.pairwise(x, y, 1, 1e9))   # always divides
+    x2 = rng.standard_normal((300, 2)) * np.exp(rng.uniform(-5, 5, (300, 1)))
+    y2 = rng.standard_normal((400, 2)) * np.exp(rng.uniform(-5, 5, (400, 1)))
+    assert np.array_equal(gpu_lib.pairwise(x2, y2, 0), oracle.pairwise(x2, y2, 0))
+
+
+SHAPES = [
+    # m, n, g, k, drop
+    (1, 40, 5, 3, False),
+    (33, 64, 16, 8, False),
+    (100, 1000, 30, 11, True),
+    (257, 4097, 50, 15, False),
+    (1000, 1000, 15, 11, True),
+    (64, 20000, 50, 15, False),
+    (3000, 3000, 100, 23, True),
+    (130, 5000, 64, 30, False),      # L=64 lists
+    (200, 3000, 128, 50, True),      # max components, k=50 (BASELINE config 5 neighbour count)
+]
+
+
+@pytest.mark.parametrize("m,n,g,k,drop", SHAPES)
+def test_euclidean_knn_vs_oracle(gpu_lib, m, n, g, k, drop):
+    Y = pca_like(n, g, seed=1000 + n + g)
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
+    gi, gd = gpu_lib.knn(X, Y, k, metric=0, drop_first=drop)
+    oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
+    _check(gi, gd, oi, od)
+
+
+@pytest.mark.parametrize("m,n,g,k,drop", [(50, 300, 10, 5, False), (500, 3000, 30, 11, False),
+                                          (300, 2000, 50, 30, True), (40, 70, 7, 50, False)])
+def test_canberra_knn_vs_oracle(gpu_lib, m, n, g, k, drop):
+    Y = pca_like(n, g, seed=1000 + n + g)
+    X = pca_like(m, g, seed=2000 + m + g)
+    for f in (0.25, 1.0):
+        gi, gd = gpu_lib.knn(X, Y, k, metric=1, dist_factor=f, drop_first=drop)
+        oi, od = oracle.knn(X, Y, k, 1, f, drop_first=drop, nthreads=8)
+        _check(gi, gd, oi, od)
+
+
+def test_canberra_exact_ties_follow_canonical_order(gpu_lib):
+    """Far-apart pairs all score exactly g: the top-k is tie-filled and must come out in
+    ascending index order (the canonical (dist, idx) rule)."""
+    rng = np.random.default_rng(9)
+    Y = rng.standard_normal((900, 12)) * 100.0
+    X = rng.standard_normal((70, 12)) * 0.01
+    gi, gd = gpu_lib.knn(X, Y, 20, metric=1, dist_factor=0.25)
+    oi, od = oracle.knn(X, Y, 20, 1, 0.25)
+    assert (od == 12.0).mean() > 0.5            # the case really is tie-dominated
+    _check(gi, gd, oi, od)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_ignore_mask_and_masked_tail(gpu_lib, metric):
+    Y = pca_like(500, 20, seed=77)
+    X = pca_like(90, 20, seed=78)
+    mask = np.zeros(500, np.uint8)
+    mask[np.random.default_rng(1).choice(500, 60, replace=False)] = 1
+    gi, gd = gpu_lib.knn(X, Y, 15, metric=metric, ref_mask=mask)
+    oi, od = oracle.knn(X, Y, 15, metric, ref_mask=mask)
+    _check(gi, gd, oi, od)
+    assert not mask[gi].any()
+    # fewer un-ignored refs than k: ignored refs follow in ascending index order with true distances
+    Ys = Y[:30]
+    mk = np.zeros(30, np.uint8)
+    mk[[1, 5, 6, 20, 29]] = 1
+    gi, gd = gpu_lib.knn(X, Ys, 28, metric=metric, ref_mask=mk)
+    oi, od = oracle.knn(X, Ys, 28, metric, ref_mask=mk)
+    _check(gi, gd, oi, od)
+    assert np.array_equal(gi[:, 25:], np.tile([1, 5, 6], (90, 1)))
+
+
+def test_duplicates_force_the_exact_fallback(gpu_lib):
+    """40 identical reference cells: the fp32 filter cannot separate them, the guard must flag the
+    rows and the float64 fallback must still return the canonical answer."""
+    Y = pca_like(3000, 30, seed=5)
+    Y[100:140] = Y[100]
+    X = np.vstack([Y[100:103], pca_like(50, 30, seed=6)])
+    ix = gpu_lib.KnnIndex(3000, 30, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, 15)
+    st = ix.last_stats()
+    oi, od = oracle.knn(X, Y, 15, 0)
+    _check(gi, gd, oi, od)
+    assert st["fallback_rows"] >= 3
+    assert np.array_equal(gi[0], np.arange(100, 115))
+    ix.close()
+
+
+def test_golden_mapping_small_through_the_abi(gpu_lib, golden):
+    g = golden("mapping_small")
+    uc, k, _ = g["params"]
+    names = list(g["ref_names"])
+    ref = g["ref"][[names.index(c) for c in g["ref_cells"]]][:, :uc]
+    gi, gd = gpu_lib.knn(ref, ref, 32, metric=0, drop_first=True)
+    assert np.array_equal(gi, g["ref_idx"]) and np.array_equal(gd, g["ref_dist"])
+    for t in ("ME", "IG"):
+        tn = list(g["t_%s_names" % t])
+        X = g["t_%s_data" % t][[tn.index(c) for c in g["t_%s_cells" % t]]][:, :uc]
+        mask = np.isin(g["ref_cells"], g["t_%s_ignore" % t]).astype(np.uint8)
+        gi, gd = gpu_lib.knn(X, ref, 32, metric=1, dist_factor=float(g["dist_factor"]), ref_mask=mask)
+        assert np.array_equal(gi, g["t_%s_idx" % t]) and np.array_equal(gd, g["t_%s_dist" % t])
+
+
+def test_golden_c1_full_size(gpu_lib, golden):
+    """BASELINE.json configs[0] against the reference's own output."""
+    g = golden("c1_3k")
+    ref, tgt = pca_like(3000, 30, 1001), pca_like(3000, 30, 2001)
+    gi, gd = gpu_lib.knn(ref, ref, 16, metric=0, drop_first=True)
+    assert np.array_equal(gi, g["ref_idx"]) and np.array_equal(gd[:, :12], g["ref_dist"])
+    gi, gd = gpu_lib.knn(tgt, ref, 16, metric=1, dist_factor=0.25)
+    assert np.array_equal(gi, g["t_ME_idx"]) and np.array_equal(gd[:, :12], g["t_ME_dist"])
+
+
+def test_reference_splits_do_not_change_results(gpu_lib):
+    Y = pca_like(20000, 50, seed=31)
+    X = pca_like(300, 50, seed=32)
+    base = None
+    for s in ("1", "2", "5", "8"):
+        os.environ["NABO_SPLITS"] = s
+        try:
+            r = gpu_lib.knn(X, Y, 15, metric=0)
+        finally:
+            del os.environ["NABO_SPLITS"]
+        if base is None:
+            base = r
+        assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1])
+    oi, od = oracle.knn(X, Y, 15, 0, nthreads=8)
+    _check(base[0], base[1], oi, od)
+
+
+def test_resident_index_shard_base_and_merge(gpu_lib):
+    """Reference rows sharded 3 ways on ONE device, merged with nabo_merge_topk == unsharded."""
+    from nabo_amd import _knn
+    from nabo_amd._dist import shard_bounds
+    Y = pca_like(10001, 30, seed=41)
+    X = pca_like(777, 30, seed=42)
+    k, kk = 11, 12
+    pi, pd = [], []
+    for r in range(3):
+        lo, hi = shard_bounds(10001, 3, r)
+        ix = gpu_lib.KnnIndex(hi - lo, 30, metric=0, ref_index_base=lo).set_ref(Y[lo:hi])
+        i, d = ix.query(X, kk)
+        ix.close()
+        assert i.min() >= lo and i.max() < hi
+        pi.append(i)
+        pd.append(d)
+    pi, pd = np.stack(pi), np.stack(pd)
+    dpi = _knn.DeviceBuffer(pi.nbytes).upload(pi)
+    dpd = _knn.DeviceBuffer(pd.nbytes).upload(pd)
+    doi, dod = _knn.DeviceBuffer(777 * k * 8), _knn.DeviceBuffer(777 * k * 8)
+    _knn.merge_topk_device(dpi.ptr, dpd.ptr, 3, 777, kk, k, True, doi.ptr, dod.ptr)
+    gi, gd = doi.download((777, k), np.int64), dod.download((777, k), np.float64)
+    oi, od = oracle.knn(X, Y, k, 0, drop_first=True, nthreads=8)
+    _check(gi, gd, oi, od)
+
+
+def test_snn_counts_kernel_vs_oracle(gpu_lib):
+    Y = pca_like(2000, 20, seed=51)
+    idx, _ = oracle.knn(Y, Y, 11, 0, drop_first=True, nthreads=8)
+    cnt = gpu_lib.snn_counts(idx, idx, 11)
+    t, j, w = oracle.snn_edges(idx, idx, 11)
+    tt, ss = np.nonzero(cnt > 0)
+    assert np.array_equal(tt, t) and np.array_equal(idx[tt, ss], j)
+    assert np.array_equal(np.array([oracle.snn_weight(int(c), 11) for c in cnt[tt, ss]]), w)
+
+
+def test_config2_100k_sampled_rows(gpu_lib):
+    """BASELINE config[1] (100k x 100k, d=50, k=15): full GPU run; the oracle re-solves a sample of
+    rows exactly, and size-independent properties are checked on all rows."""
+    n = 100000
+    Y = pca_like(n, 50, seed=1002)
+    X = pca_like(n, 50, seed=2002)
+    ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, 15)
+    st = ix.last_stats()
+    ix.close()
+    assert (np.diff(gd, axis=1) >= 0).all()                       # sorted
+    assert gi.min() >= 0 and gi.max() < n
+    assert all(len(set(r)) == 15 for r in gi[::997])              # no repeated neighbour
+    rows = np.random.default_rng(3).choice(n, 256, replace=False)
+    oi, od = oracle.knn(X[rows], Y, 15, 0, nthreads=8)
+    _check(gi[rows], gd[rows], oi, od)
+    # distances returned are the reference formula evaluated at the returned indices
+    chk = oracle.pairwise(X[rows[:8]], Y[gi[rows[0]]], 0)[0]
+    assert np.array_equal(chk, gd[rows[0]])
+    assert st["fallback_rows"] < n // 100
