@@ -1,0 +1,203 @@
+"""Runs nabo_amd.Mapping end to end on HDF5 inputs built from the golden fixtures and compares
+everything the reference wrote for the same inputs.  Executed by test_mapping.py, in-process
+when h5py is importable, otherwise under an interpreter that has it.
+
+    python tests/_mapping_case.py validate     # API / validation rules only (no GPU needed)
+    python tests/_mapping_case.py small|dup|c1 # full runs (GPU)
+"""
+import io
+import json
+import os
+import sys
+import tempfile
+from contextlib import redirect_stdout
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import h5py  # noqa: E402
+
+import nabo_amd  # noqa: E402
+from nabo_amd._synth import pca_like  # noqa: E402
+
+GOLD = os.path.join(REPO, "tests", "golden")
+
+
+def write_pca(fn, grp, names, data):
+    with h5py.File(fn, "w") as h5:
+        g = h5.create_group(grp)
+        for n, v in zip(names, data):
+            g.create_dataset(str(n), data=v)
+
+
+def read_graph_like_reference(fn, name, kind):
+    """What Graph.load_from_h5 does with the file (nabo/_graph.py:62-107), as plain sets."""
+    with h5py.File(fn, "r") as h5:
+        if kind == "reference":
+            assert h5["name_stash/ref_name"][0].decode("UTF-8") == name
+            uid = h5["name_stash/ref_name"][1].decode("UTF-8")
+        else:
+            uid = None
+            for i in h5["name_stash/target_names"][:]:
+                if i[0].decode("UTF-8") == name:
+                    uid = i[1].decode("UTF-8")
+            assert uid is not None
+        grp = h5[uid + "_graph"]
+        nodes, edges = [], set()
+        for node in grp:
+            nodes.append(node)
+            for j in grp[node]:
+                edges.add((node, j[0].decode("UTF-8"), float(j[1].decode("UTF-8"))))
+        return nodes, edges, uid
+
+
+def golden_edges(g, prefix):
+    return {(str(s), str(d), float(w)) for s, d, w in zip(g[prefix + "_src"], g[prefix + "_dst"], g[prefix + "_w"])}
+
+
+def mapping_score(ref_nodes, t_nodes, t_edges, score_multiplier=1000):
+    """get_mapping_score defaults (nabo/_graph.py:632-653): weighted degree of target edges."""
+    sc = {n: 0.0 for n in ref_nodes}
+    for a, b, w in t_edges:
+        if w > 0:
+            sc[b] += w
+    return {k: score_multiplier * v / len(t_nodes) for k, v in sc.items()}
+
+
+def run_case(tag):
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    uc, k, chunk = [int(v) for v in g["params"]]
+    f = float(g["dist_factor"])
+    if tag == "c1_3k":
+        ref = pca_like(3000, 30, 1001)
+        rn = ["R%04d" % i for i in range(3000)]
+        targets = [("ME", ["T%04d" % i for i in range(3000)], pca_like(3000, 30, 2001), None)]
+    else:
+        ref, rn = g["ref"], list(g["ref_names"])
+        targets = []
+        for key in g.files:
+            if key.startswith("t_") and key.endswith("_data"):
+                t = key[2:-5]
+                ign = [str(x) for x in g["t_%s_ignore" % t]]
+                targets.append((t, list(g["t_%s_names" % t]), g[key], ign if ign else None))
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        ref_fn = os.path.join(td, "ref.h5")
+        write_pca(ref_fn, "data", rn, ref)
+        map_fn = os.path.join(td, "mapping.h5")
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = nabo_amd.Mapping(map_fn, "WT", ref_fn, "data", overwrite=True)
+            m.set_parameters(uc, k, f, chunk)
+            m.make_ref_graph()
+        out["ref_cells_equal"] = list(m.refCells) == [str(c) for c in g["ref_cells"]]
+        for (tn, names, data, ign) in targets:
+            tfn = os.path.join(td, "t_%s.h5" % tn)
+            write_pca(tfn, "data", names, data)
+            with redirect_stdout(buf):
+                m.map_target(tn, tfn, "data", ignore_ref_cells=ign)
+        out["log"] = buf.getvalue()
+        # stored neighbour lists == first k entries of the reference's order rows
+        with h5py.File(map_fn, "r") as h5:
+            uid = h5["name_stash/ref_name"][1].decode()
+            idx = np.stack([h5[uid + "_sortedDist"][c][:] for c in m.refCells])
+            dist = np.stack([h5[uid + "_dist"][c][:] for c in m.refCells])
+        ties = g["ref_ties"]
+        out["ref_idx_equal"] = bool(np.array_equal(idx[~ties], g["ref_idx"][~ties][:, :k]))
+        out["ref_dist_equal"] = bool(np.array_equal(dist, g["ref_dist"][:, :k]))
+        nodes, edges, _ = read_graph_like_reference(map_fn, "WT", "reference")
+        ge = golden_edges(g, "ref_graph")
+        out["ref_graph_nodes_equal"] = sorted(nodes) == sorted(str(x) for x in g["ref_graph_nodes"])
+        out["ref_graph_edges_equal"] = edges == ge
+        out["ref_graph_missing"] = sorted(ge - edges)[:5]
+        out["ref_graph_extra"] = sorted(edges - ge)[:5]
+        fixw = 0.5 / ((2 * (k - 1)) - 0.5)
+        out["n_repair_edges"] = len({e for e in ge if e[2] == fixw}) // 2
+        for (tn, names, data, ign) in targets:
+            tnodes, tedges, tuid = read_graph_like_reference(map_fn, tn, "target")
+            gte = golden_edges(g, "t_%s_graph" % tn)
+            tt = g["t_%s_ties" % tn]
+            out["t_%s_graph_nodes_equal" % tn] = sorted(tnodes) == sorted(str(x) for x in g["t_%s_graph_nodes" % tn])
+            if not tt.any():
+                out["t_%s_graph_edges_equal" % tn] = tedges == gte
+            else:       # rows with exact ties inside the first k+1: reference order is unstable there
+                tied = {str(c) + "_" + tn for c, t in zip(g["t_%s_cells" % tn], tt) if t}
+                out["t_%s_graph_edges_equal" % tn] = ({e for e in tedges if e[0] not in tied} ==
+                                                      {e for e in gte if e[0] not in tied})
+            if "score_%s_nodes" % tn in g.files and not tt.any():
+                sc = mapping_score(nodes, tnodes, tedges)
+                gs = dict(zip([str(x) for x in g["score_%s_nodes" % tn]], g["score_%s_vals" % tn]))
+                out["t_%s_score_maxerr" % tn] = float(max(abs(sc[n] - gs[n]) for n in gs))
+        # use_stored_distances: rebuild the graphs from the stored lists only
+        with redirect_stdout(buf):
+            m2 = nabo_amd.Mapping(map_fn, "WT", ref_fn, "data")
+            m2.set_parameters(uc, k, f, chunk)
+            m2.make_ref_graph(use_stored_distances=True)
+        _, edges2, _ = read_graph_like_reference(map_fn, "WT", "reference")
+        out["stored_distances_same_graph"] = edges2 == edges
+        # columnar layout gives the same graph
+        map2 = os.path.join(td, "mapping_col.h5")
+        with redirect_stdout(buf):
+            m3 = nabo_amd.Mapping(map2, "WT", ref_fn, "data", overwrite=True, layout="columnar")
+            m3.set_parameters(uc, k, f, chunk)
+            m3.make_ref_graph()
+        _, edges3, _ = read_graph_like_reference(map2, "WT", "reference")
+        out["columnar_same_graph"] = edges3 == edges
+    return out
+
+
+def run_validate():
+    """Validation rules and exception types of the reference API (no distance computation)."""
+    out = {}
+
+    def raises(exc, fn, *a, **kw):
+        try:
+            fn(*a, **kw)
+        except exc:
+            return True
+        except Exception as e:      # wrong type
+            return "wrong exception %r" % (e,)
+        return False
+
+    with tempfile.TemporaryDirectory() as td:
+        ref_fn = os.path.join(td, "ref.h5")
+        names = ["c%d" % i for i in range(12)]
+        write_pca(ref_fn, "data", names, pca_like(12, 6, 1))
+        map_fn = os.path.join(td, "m.h5")
+        M = nabo_amd.Mapping
+        out["ref_name_double_underscore"] = raises(ValueError, M, map_fn, "a__b", ref_fn, "data")
+        out["same_in_out_file"] = raises(ValueError, M, ref_fn, "WT", ref_fn, "data")
+        out["missing_file"] = raises(ValueError, M, map_fn, "WT", os.path.join(td, "nope.h5"), "data")
+        out["missing_group"] = raises(ValueError, M, map_fn, "WT", ref_fn, "nogroup")
+        m = M(map_fn, "WT", ref_fn, "data", overwrite=True)
+        out["ref_cells_name_order"] = m.refCells == sorted(names)
+        out["calc_dist_needs_parameters"] = raises(ValueError, m.calc_dist, ref_fn, "data", "a", "b", [])
+        out["calc_snn_needs_parameters"] = raises(ValueError, m.calc_snn, "a", "WT", "g")
+        out["dist_factor_zero"] = raises(ValueError, m.set_parameters, 5, 3, 0, 10)
+        out["dist_factor_str"] = raises(ValueError, m.set_parameters, 5, 3, "x", 10)
+        m.set_parameters(5, 3, 0.25, 10)
+        out["target_same_as_ref"] = raises(ValueError, m.map_target, "T", ref_fn, "data")
+        out["target_is_mapping_file"] = raises(ValueError, m.map_target, "T", map_fn, "data")
+        out["target_named_like_ref"] = raises(ValueError, m.map_target, "WT", os.path.join(td, "t.h5"), "data")
+        out["target_double_underscore"] = raises(ValueError, m.map_target, "T__1", os.path.join(td, "t.h5"), "data")
+        out["calc_snn_missing_group"] = raises(KeyError, m.calc_snn, "nogrp_sortedDist", "T", "g")
+        # metadata persists and is validated on reopen (nabo/_mapping.py:357-392)
+        with h5py.File(map_fn, "r") as h5:
+            out["name_stash_layout"] = (h5["name_stash/ref_name"][0] == b"WT" and
+                                        len(h5["name_stash/ref_name"][1]) == 30 and
+                                        [x.decode() for x in h5["ref_cells/ref_cells"][:]] == sorted(names))
+        out["different_ref_name_on_reopen"] = raises(ValueError, M, map_fn, "OTHER", ref_fn, "data")
+        ref2 = os.path.join(td, "ref2.h5")
+        write_pca(ref2, "data", names[:-1] + ["zz"], pca_like(12, 6, 1))
+        out["different_cells_on_reopen"] = raises(ValueError, M, map_fn, "WT", ref2, "data")
+        m2 = M(map_fn, "WT", ref_fn, "data")
+        out["reopen_keeps_uid"] = m2._refGraphGrpName == m._refGraphGrpName
+    return out
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    res = run_validate() if mode == "validate" else run_case({"small": "mapping_small", "dup": "dup",
+                                                                "c1": "c1_3k"}[mode])
+    print("RESULT " + json.dumps(res))

@@ -1,0 +1,88 @@
+"""World-size-2 (and 3) runs of the reference-row-sharded k-NN over the gloo backend on CPU.
+The two compute steps are injected (oracle for the per-shard k-NN, merge_numpy for the merge), so
+what is exercised is exactly the product's N>1 plumbing in nabo_amd/_dist.py: shard bounds, global
+index bases, the all_to_all exchange layout, ragged target counts, the positional drop after the
+merge, and the final all_gather -- and that N shards == 1 shard bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir):
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from nabo_amd._dist import ShardedKnn, merge_numpy, shard_bounds
+    from nabo_amd._synth import pca_like
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    Y = pca_like(n, g, seed=11)
+    X = pca_like(m, g, seed=12)
+    lo, hi = shard_bounds(n, world, rank)
+
+    def local_knn(Xt, kk):
+        i, d = oracle.knn(Xt.numpy(), Y[lo:hi], kk, metric)
+        return torch.from_numpy(i + lo), torch.from_numpy(d)
+
+    def merge(pi, pd, kq, dropq):
+        i, d = merge_numpy(pi.numpy(), pd.numpy(), kq, dropq)
+        return torch.from_numpy(i), torch.from_numpy(d)
+
+    sk = ShardedKnn(dist, local_knn, merge, torch.device("cpu"))
+    oi, od = sk.query(torch.from_numpy(X), m, k, drop)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), idx=oi.numpy(), dist=od.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m,n,drop,metric", [(2, 101, 600, False, 0), (2, 64, 501, True, 0), (3, 50, 400, False, 1)])
+def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric):
+    import torch.multiprocessing as mp
+    import oracle
+    from nabo_amd._synth import pca_like
+    g, k = 12, 7
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, m, n, g, k, drop, metric, str(tmp_path)), nprocs=world, join=True)
+    Y = pca_like(n, g, seed=11)
+    X = pca_like(m, g, seed=12)
+    oi, od = oracle.knn(X, Y, k, metric, drop_first=drop)
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
+        assert np.array_equal(z["idx"], oi) and np.array_equal(z["dist"], od)
+
+
+def test_shard_bounds_cover_everything():
+    from nabo_amd._dist import shard_bounds
+    for n in (1, 7, 1000, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, w, r) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_merge_numpy_matches_oracle_order():
+    from nabo_amd._dist import merge_numpy
+    rng = np.random.default_rng(0)
+    pi = np.stack([np.arange(0, 6)[None].repeat(4, 0), np.arange(6, 12)[None].repeat(4, 0)])
+    pd = np.sort(rng.integers(0, 4, size=(2, 4, 6)).astype(np.float64), axis=2)      # many exact ties
+    i, d = merge_numpy(pi, pd, 5, True)
+    for r in range(4):
+        allp = sorted(zip(np.concatenate([pd[0, r], pd[1, r]]), np.concatenate([pi[0, r], pi[1, r]])))
+        assert [x[1] for x in allp[1:6]] == list(i[r]) and [x[0] for x in allp[1:6]] == list(d[r])
