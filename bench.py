@@ -136,7 +136,7 @@ def main():
         dt = float(tmax.item())
 
     # light self-check outside the timed region (rank 0): sorted rows, valid indices
-    if world == 1:
+    if world == 1 and not os.environ.get("NABO_DEBUG_ABLATE"):
         gi = dI.download((m, k), np.int64)
         gd = dD.download((m, k), np.float64)
         assert gi.min() >= 0 and gi.max() < n and (np.diff(gd[:: max(1, m // 4096)], axis=1) >= 0).all()

@@ -353,6 +353,16 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S, (int)gx,
                                      ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(), st));
         HIP_TRY(hipEventRecord(ix->ev[2], st));
+        if (env_int("NABO_DEBUG_ABLATE", 0) != 0) {     // kernel-timing experiments only: results are garbage
+            HIP_TRY(hipEventRecord(ix->ev[3], st));
+            HIP_TRY(hipEventRecord(ix->ev[4], st));
+            HIP_TRY(hipEventRecord(ix->ev[5], st));
+            HIP_TRY(hipStreamSynchronize(st));
+            float tt = 0;
+            HIP_TRY(hipEventElapsedTime(&tt, ix->ev[1], ix->ev[2]));
+            ix->ms[1] = tt;
+            return NABO_OK;
+        }
         const double err_coef = 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
         HIP_TRY(nabo::refine_launch(dX, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ix->ymax_sqrt, k, drop, ix->base, n_valid,

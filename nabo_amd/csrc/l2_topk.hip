@@ -19,10 +19,15 @@
 //     pre-packed fragment layout (knn_common.h); the next tile is loaded in place while the
 //     last chain of the current tile is still issuing (rolling prefetch);
 //   * accumulator layout: lane (l&31) = target, register r / lane-half = reference, so a
-//     row's threshold is ONE VGPR and the filter is 16 v_cmp per 32x32 tile, issued in
-//     the shadow of the next chain's MFMAs.
+//     row's threshold is ONE VGPR and the filter of a chain is 8 v_min3 + 1 v_cmp, scheduled
+//     into the shadow of the next chain's MFMAs; only a hit takes the (out-of-line) append path;
+//   * candidate lists are L kept + PEND pending entries per row; two 4-wave workgroups fit a CU
+//     (2 x 80 KB LDS, <= 256 VGPRs), so each SIMD holds two waves and one wave's append /
+//     compaction / L2 waits are covered by the other wave's MFMAs.
 // Algorithmic work: 2*m*n*d flop on the MFMA pipe; HBM traffic is only the packed operands
 // (4*KSTEPS*2 bytes per cell) and L indices per row -- the kernel is MFMA-bound.
+#include <cstdlib>
+
 #include "knn_common.h"
 
 namespace nabo {
@@ -71,12 +76,19 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
     return acc;
 }
 
+// Candidate-list geometry: L = 32*EPL kept entries + PEND pending slots per row.
+template <int EPL, int PEND>
+struct ListCfg {
+    static constexpr int L = 32 * EPL;
+    static constexpr int CAP = L + PEND;
+    static_assert(CAP <= 64 * EPL, "a row must fit one wave-wide sort");
+};
+
 // Sort one row's buffer, keep the L smallest, return the new threshold (key of rank L-1).
-template <int EPL>
-__device__ __forceinline__ float compact_row(uint2 *rowbuf, int row, uint32_t count,
-                                             float (&key)[EPL], uint32_t (&val)[EPL])
+template <int EPL, int PEND>
+__device__ __forceinline__ float compact_row(uint2 *rowbuf, uint32_t count, float (&key)[EPL], uint32_t (&val)[EPL])
 {
-    constexpr int CAP = 64 * EPL, L = 32 * EPL;
+    constexpr int L = ListCfg<EPL, PEND>::L;
     const int lane = lane_id();
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
@@ -84,7 +96,7 @@ __device__ __forceinline__ float compact_row(uint2 *rowbuf, int row, uint32_t co
         key[r] = __builtin_inff();
         val[r] = 0xFFFFFFFFu;
         if ((uint32_t)e < count) {
-            uint2 v = rowbuf[(e + row) & (CAP - 1)];
+            uint2 v = rowbuf[e];
             key[r] = __uint_as_float(v.x);
             val[r] = v.y;
         }
@@ -93,7 +105,7 @@ __device__ __forceinline__ float compact_row(uint2 *rowbuf, int row, uint32_t co
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
         const int e = r * 64 + lane;
-        if (e < L) rowbuf[(e + row) & (CAP - 1)] = make_uint2(__float_as_uint(key[r]), val[r]);
+        if (e < L) rowbuf[e] = make_uint2(__float_as_uint(key[r]), val[r]);
     }
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[(L - 1) >> 6]), (L - 1) & 63));
 }
@@ -101,11 +113,13 @@ __device__ __forceinline__ float compact_row(uint2 *rowbuf, int row, uint32_t co
 // Append every accumulator element below its row's threshold to that row's list.
 // lane l: target row (l & 31) of this row-block; register r / half (l >> 5): reference
 // jbase + cd_row(r, l >> 5).  Lanes l and l+32 share a row and keep identical tau / cnt.
-template <int EPL>
+// A row whose list is full is compacted (sort, keep L, tighten tau) and its deferred hits are
+// re-examined against the new threshold.
+template <int EPL, int PEND>
 __device__ __forceinline__ void append_hits(const f32x16 &acc, float &tau, uint32_t &cnt,
                                             uint2 *blockbuf /* this wave+rb: [32][CAP] */, uint32_t jbase)
 {
-    constexpr int CAP = 64 * EPL, L = 32 * EPL;
+    constexpr int CAP = ListCfg<EPL, PEND>::CAP, L = ListCfg<EPL, PEND>::L;
     const int lane = lane_id();
     const int tl = lane & 31;
     const int hh = lane >> 5;
@@ -122,9 +136,7 @@ __device__ __forceinline__ void append_hits(const f32x16 &acc, float &tau, uint3
                 const uint32_t h1 = ((uint32_t)(mask >> 32) >> tl) & 1u;
                 const uint32_t pos = cnt + (hh ? h0 : 0u);
                 const bool ok = hit && pos < (uint32_t)CAP;
-                if (ok)
-                    rowbuf[(pos + tl) & (CAP - 1)] =
-                        make_uint2(__float_as_uint(acc[r]), jbase + (uint32_t)(cd_row(r, 0) + 4 * hh));
+                if (ok) rowbuf[pos] = make_uint2(__float_as_uint(acc[r]), jbase + (uint32_t)(cd_row(r, 0) + 4 * hh));
                 if (hit && !ok) defer |= (1u << r);
                 cnt = min(cnt + h0 + h1, (uint32_t)CAP);
             }
@@ -138,38 +150,38 @@ __device__ __forceinline__ void append_hits(const f32x16 &acc, float &tau, uint3
             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, row);
             float key[EPL];
             uint32_t val[EPL];
-            const float nt = compact_row<EPL>(blockbuf + row * CAP, row, c, key, val);
+            const float nt = compact_row<EPL, PEND>(blockbuf + row * CAP, c, key, val);
             if (tl == row) { tau = nt; cnt = min(c, (uint32_t)L); }
         }
         pend = defer;
     }
 }
 
-template <int EPL>
+template <int EPL, int PEND>
 __device__ __forceinline__ void filter_and_append(const f32x16 &acc, float &tau, uint32_t &cnt,
                                                   uint2 *blockbuf, uint32_t jbase)
 {
     bool any = false;
 #pragma unroll
     for (int r = 0; r < 16; ++r) any |= (acc[r] < tau);
-    if (__builtin_amdgcn_ballot_w64(any) != 0) append_hits<EPL>(acc, tau, cnt, blockbuf, jbase);
+    if (__builtin_amdgcn_ballot_w64(any) != 0) append_hits<EPL, PEND>(acc, tau, cnt, blockbuf, jbase);
 }
 
 // Final flush of one row-block: sort every row, emit L candidate indices (+ tau).
-template <int EPL>
+template <int EPL, int PEND>
 __device__ __forceinline__ void flush_block(float &tau, uint32_t &cnt, uint2 *blockbuf,
                                             int64_t grow0, int split, int S,
                                             uint32_t *__restrict__ cand_idx, float *__restrict__ cand_key,
                                             float *__restrict__ cand_tau)
 {
-    constexpr int CAP = 64 * EPL, L = 32 * EPL;
+    constexpr int CAP = ListCfg<EPL, PEND>::CAP, L = ListCfg<EPL, PEND>::L;
     const int lane = lane_id();
     const int tl = lane & 31;
     for (int row = 0; row < 32; ++row) {
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, row);
         float key[EPL];
         uint32_t val[EPL];
-        float nt = compact_row<EPL>(blockbuf + row * CAP, row, c, key, val);
+        float nt = compact_row<EPL, PEND>(blockbuf + row * CAP, c, key, val);
         float t_row = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tau), row));
         if (c > (uint32_t)L) t_row = nt;           // entries were dropped: threshold = rank L-1 key
         const int64_t o = ((grow0 + row) * S + split) * (int64_t)L;
@@ -190,15 +202,18 @@ __device__ __forceinline__ void flush_block(float &tau, uint32_t &cnt, uint2 *bl
 // Xpk: [gridDim.x*4*R][qtile] packed target tiles (scaled by -2; padded tiles are zero).
 // Ypk: [S*tiles_per_split][rtile] packed reference tiles (padding: zero fragments, +inf norm).
 // cand_idx/cand_key: [rows_pad][S][L], cand_tau: [rows_pad][S], rows_pad = gridDim.x*4*R*32.
-template <int KSTEPS, int R, int EPL>
-__global__ __launch_bounds__(256, 1) void l2_topk_kernel(const float *__restrict__ Xpk,
+// Two waves per SIMD need <= 256 VGPRs; that holds while the resident target fragments
+// (R*KSTEPS registers) stay <= 64 -- larger shapes run one wave per SIMD without spilling.
+template <int KSTEPS, int R, int EPL, int PEND>
+__global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kernel(const float *__restrict__ Xpk,
                                                          const float *__restrict__ Ypk,
                                                          int tiles_per_split,
                                                          uint32_t *__restrict__ cand_idx,
                                                          float *__restrict__ cand_key,
-                                                         float *__restrict__ cand_tau)
+                                                         float *__restrict__ cand_tau,
+                                                         int dbg /* ablation switches, 0 in production */)
 {
-    constexpr int CAP = 64 * EPL;
+    constexpr int CAP = ListCfg<EPL, PEND>::CAP;
     constexpr int QTF = qtile_floats(KSTEPS);
     constexpr int RTF = rtile_floats(KSTEPS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void l2_topk_kernel(const float *__restrict
     float tau[R];
     uint32_t cnt[R];
 #pragma unroll
-    for (int rb = 0; rb < R; ++rb) { tau[rb] = __builtin_inff(); cnt[rb] = 0; }
+    for (int rb = 0; rb < R; ++rb) { tau[rb] = (dbg & 1) ? -__builtin_inff() : __builtin_inff(); cnt[rb] = 0; }
     uint2 *wbuf = smem + (size_t)wave * R * 32 * CAP;
 
     const int64_t t_begin = (int64_t)split * tiles_per_split;
@@ -242,56 +257,54 @@ __global__ __launch_bounds__(256, 1) void l2_topk_kernel(const float *__restrict
 
     if (R == 2) {
         for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (t + 1 < t_end) ? t + 1 : t;
+            const int64_t tn = (dbg & 2) ? t_begin : ((t + 1 < t_end) ? t + 1 : t);
             f32x16 accA = mfma_chain<KSTEPS, false>(y, xb[0], nullptr, lane);
-            filter_and_append<EPL>(accP, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)((t - 1) * 32));
+            filter_and_append<EPL, PEND>(accP, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)((t - 1) * 32));
             accP = mfma_chain<KSTEPS, true>(y, xb[R - 1], ybase + tn * RTF, lane);
-            filter_and_append<EPL>(accA, tau[0], cnt[0], wbuf, (uint32_t)(t * 32));
+            filter_and_append<EPL, PEND>(accA, tau[0], cnt[0], wbuf, (uint32_t)(t * 32));
         }
-        filter_and_append<EPL>(accP, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)((t_end - 1) * 32));
+        filter_and_append<EPL, PEND>(accP, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)((t_end - 1) * 32));
     } else {
         for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (t + 1 < t_end) ? t + 1 : t;
+            const int64_t tn = (dbg & 2) ? t_begin : ((t + 1 < t_end) ? t + 1 : t);
             f32x16 accA = mfma_chain<KSTEPS, true>(y, xb[0], ybase + tn * RTF, lane);
-            filter_and_append<EPL>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t - 1) * 32));
+            filter_and_append<EPL, PEND>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t - 1) * 32));
             accP = accA;
         }
-        filter_and_append<EPL>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t_end - 1) * 32));
+        filter_and_append<EPL, PEND>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t_end - 1) * 32));
     }
 
 #pragma unroll
     for (int rb = 0; rb < R; ++rb)
-        flush_block<EPL>(tau[rb], cnt[rb], wbuf + rb * 32 * CAP, (ttile0 + rb) * 32, split, S,
-                         cand_idx, cand_key, cand_tau);
+        flush_block<EPL, PEND>(tau[rb], cnt[rb], wbuf + rb * 32 * CAP, (ttile0 + rb) * 32, split, S,
+                               cand_idx, cand_key, cand_tau);
 }
 
 // ---- launch wrapper -------------------------------------------------------------------
-template <int KSTEPS, int R, int EPL>
+template <int KSTEPS, int R, int EPL, int PEND>
 static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
                              uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
-    const size_t lds = (size_t)4 * R * 32 * (64 * EPL) * sizeof(uint2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    const size_t lds = (size_t)4 * R * 32 * ListCfg<EPL, PEND>::CAP * sizeof(uint2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL, PEND>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(256);
-    hipLaunchKernelGGL((l2_topk_kernel<KSTEPS, R, EPL>), grid, block, lds, st, Xpk, Ypk, tiles_per_split,
-                       cand_idx, cand_key, cand_tau);
+    hipLaunchKernelGGL((l2_topk_kernel<KSTEPS, R, EPL, PEND>), grid, block, lds, st, Xpk, Ypk, tiles_per_split,
+                       cand_idx, cand_key, cand_tau, dbg);
     return hipGetLastError();
 }
 
-// ksteps must be one of the instantiated values (see l2_pick_ksteps); epl 1 -> L=32 (R=2), 2 -> L=64 (R=1).
+// ksteps must be one of the instantiated values; epl 1 -> L=32 (R=2), 2 -> L=64 (R=1).
+// Lists are L + 8*EPL entries: two workgroups (2 x 80 KB) per CU.
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split,
                           int S, int gx, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
-#define NABO_CASE(KS)                                                                                      \
-    case KS:                                                                                               \
-        return epl == 1 ? launch_one<KS, 2, 1>(Xpk, Ypk, tiles_per_split, S, gx, cand_idx, cand_key, cand_tau, st) \
-                        : launch_one<KS, 1, 2>(Xpk, Ypk, tiles_per_split, S, gx, cand_idx, cand_key, cand_tau, st);
+#define NABO_CASE(KS)                                                                                          \
+    case KS:                                                                                                   \
+        return epl == 1 ? launch_one<KS, 2, 1, 8>(Xpk, Ypk, tiles_per_split, S, gx, cand_idx, cand_key, cand_tau, st) \
+                        : launch_one<KS, 1, 2, 16>(Xpk, Ypk, tiles_per_split, S, gx, cand_idx, cand_key, cand_tau, st);
     switch (ksteps) {
         NABO_CASE(8)
         NABO_CASE(16)
