@@ -38,13 +38,36 @@ struct RefTile {
     f32x16 n;
 };
 
+// Load fragment group q of a packed tile: only the components that exist (the last group of a
+// KSTEPS that is not a multiple of 4 is partial; loading its unused lanes would hand hipcc dead
+// registers it reuses as temporaries -- and then guards with a full vmcnt(0)).
+template <int KSTEPS>
+__device__ __forceinline__ void load_group(f32x4 &dst, const float *__restrict__ tile_base, int q, int lane)
+{
+    constexpr int Q = q_groups(KSTEPS);
+    constexpr int TAIL = KSTEPS - 4 * (Q - 1);
+    const float *p = tile_base + (q * 64 + lane) * 4;
+    if (q < Q - 1 || TAIL == 4) {
+        dst = *reinterpret_cast<const f32x4 *>(p);
+    } else if (TAIL == 1) {
+        dst[0] = p[0];
+    } else if (TAIL == 2) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v = *reinterpret_cast<const f32x2 *>(p);
+        dst[0] = v[0]; dst[1] = v[1];
+    } else {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 v = *reinterpret_cast<const f32x2 *>(p);
+        dst[0] = v[0]; dst[1] = v[1]; dst[2] = p[2];
+    }
+}
+
 template <int KSTEPS>
 __device__ __forceinline__ void load_ref_tile(RefTile<KSTEPS> &y, const float *__restrict__ tile_base, int lane)
 {
     constexpr int Q = q_groups(KSTEPS);
-    const f32x4 *p = reinterpret_cast<const f32x4 *>(tile_base);
 #pragma unroll
-    for (int q = 0; q < Q; ++q) y.f[q] = p[q * 64 + lane];
+    for (int q = 0; q < Q; ++q) load_group<KSTEPS>(y.f[q], tile_base, q, lane);
     y.n = *reinterpret_cast<const f32x16 *>(tile_base + Q * 256 + (lane >> 5) * 16);
 }
 
@@ -69,11 +92,38 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb[s], acc, 0, 0, 0);
         if (RELOAD && ((s & 3) == 3 || s == KSTEPS - 1)) {
             __builtin_amdgcn_sched_barrier(0);
-            y.f[s >> 2] = reinterpret_cast<const f32x4 *>(next)[(s >> 2) * 64 + lane];
+            load_group<KSTEPS>(y.f[s >> 2], next, s >> 2, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     return acc;
+}
+
+// Two row-blocks against the same reference tile, MFMAs of the two accumulation chains
+// interleaved: consecutive MFMAs are independent (no dependent-issue bubble) and the chain
+// restart (C-in read, drain before the filter) is paid once per 2*KSTEPS MFMAs.  The tile
+// registers are reloaded in place for the next tile behind their last use.
+template <int KSTEPS>
+__device__ __forceinline__ void mfma_chain_pair(RefTile<KSTEPS> &y, const float (&xb0)[KSTEPS],
+                                                const float (&xb1)[KSTEPS], const float *__restrict__ next,
+                                                int lane, f32x16 &accA, f32x16 &accB)
+{
+    constexpr int Q = q_groups(KSTEPS);
+    accA = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb0[0], y.n, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb1[0], y.n, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    y.n = *reinterpret_cast<const f32x16 *>(next + Q * 256 + (lane >> 5) * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 1; s < KSTEPS; ++s) {
+        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb0[s], accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb1[s], accB, 0, 0, 0);
+        if ((s & 3) == 3 || s == KSTEPS - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_group<KSTEPS>(y.f[s >> 2], next, s >> 2, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 }
 
 // Candidate-list geometry: L = 32*EPL kept entries + PEND pending slots per row.
@@ -250,6 +300,9 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kerne
 
     RefTile<KSTEPS> y;
     load_ref_tile<KSTEPS>(y, ybase + t_begin * RTF, lane);
+    if ((dbg & 4) && ((blockIdx.x >> 8) & 1)) {          // experiment: stagger the two workgroups of a CU
+        for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);
+    }
 
     f32x16 accP;                  // chain whose filter is still pending
 #pragma unroll
@@ -257,16 +310,15 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kerne
 
     if (R == 2) {
         for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (dbg & 2) ? t_begin : ((t + 1 < t_end) ? t + 1 : t);
-            f32x16 accA = mfma_chain<KSTEPS, false>(y, xb[0], nullptr, lane);
-            filter_and_append<EPL, PEND>(accP, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)((t - 1) * 32));
-            accP = mfma_chain<KSTEPS, true>(y, xb[R - 1], ybase + tn * RTF, lane);
+            const int64_t tn = (dbg & 2) ? t_begin + ((t + 1) & 63) : ((t + 1 < t_end) ? t + 1 : t);
+            f32x16 accA, accB;
+            mfma_chain_pair<KSTEPS>(y, xb[0], xb[R - 1], ybase + tn * RTF, lane, accA, accB);
             filter_and_append<EPL, PEND>(accA, tau[0], cnt[0], wbuf, (uint32_t)(t * 32));
+            filter_and_append<EPL, PEND>(accB, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)(t * 32));
         }
-        filter_and_append<EPL, PEND>(accP, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)((t_end - 1) * 32));
     } else {
         for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (dbg & 2) ? t_begin : ((t + 1 < t_end) ? t + 1 : t);
+            const int64_t tn = (dbg & 2) ? t_begin + ((t + 1) & 63) : ((t + 1 < t_end) ? t + 1 : t);
             f32x16 accA = mfma_chain<KSTEPS, true>(y, xb[0], ybase + tn * RTF, lane);
             filter_and_append<EPL, PEND>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t - 1) * 32));
             accP = accA;
