@@ -19,10 +19,12 @@ hipError_t pack_ref_launch(const double *Y, int64_t n, int g, const double *cent
 hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *centre, int ksteps,
                              int64_t ntiles_total, float *out, double *xnorm, hipStream_t st);
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
-                          uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st);
+                          int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                          hipStream_t st);
+void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu);
 hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t n, int g, int metric, double f,
                            double *D, hipStream_t st);
-hipError_t refine_launch(const double *X, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
+hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef, double ymax_sqrt,
                          int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
@@ -145,7 +147,8 @@ struct nabo_index {
     DevBuf yt;
 
     // query workspace
-    DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_d, fails, failcnt, oidx, odist, nfound;
+    DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_idx2, cand_tau2, cand_d, fails, failcnt, oidx, odist, nfound;
+    int n_cu = 256;
 
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
@@ -188,6 +191,9 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
     ix->f = dist_factor;
     ix->base = ref_index_base;
     if (metric == NABO_METRIC_EUCLIDEAN) ix->ksteps = pick_ksteps(g);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        ix->n_cu = cus;
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&ix->ev[i]);
     if (e != hipSuccess) {
@@ -204,7 +210,7 @@ int nabo_index_destroy(nabo_index *ix)
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->normmax, &ix->yt,
-                      &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_d, &ix->fails,
+                      &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
@@ -319,39 +325,70 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
     HIP_TRY(hipEventRecord(ix->ev[0], st));
 
     if (ix->metric == NABO_METRIC_EUCLIDEAN) {
-        const int R = epl == 1 ? 2 : 1;
-        const int rows_per_wg = 4 * R * 32;
+        int rows_per_wg = 256, wg_per_cu = 1;
+        nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu);
+        const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
         const int64_t rows_pad = gx * rows_per_wg;
         const int Q = (ix->ksteps + 3) / 4;
-        // reference splits: enough workgroups to fill 256 CUs when there are few target rows
+        // kept-list length: k' + 8 slack (the certification needs a gap above the k'-th distance)
+        int lkeep = kk + 8;
+        if (lkeep < 16) lkeep = 16;
+        if (lkeep > L) lkeep = L;
+        { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= L) lkeep = lk; }   // experiments
+        // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
+        // chip is full.  Many rows: the last, partially filled round of workgroups is launched with
+        // its own split factor S2 so that it takes ~1/S2 of a round instead of a whole one.
+        int64_t gx_main = gx, gx_tail = 0;
+        int S2 = 1;
         S = env_int("NABO_SPLITS", 0);
-        if (S <= 0) {
+        const bool forced = S > 0;
+        if (!forced) {
             S = 1;
-            if (gx < 512) {
-                S = (int)((1024 + gx - 1) / gx);
+            if (gx < slots) {
+                S = (int)((2 * slots + gx - 1) / gx);
                 const int64_t max_by_tiles = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
                 if (S > max_by_tiles) S = (int)max_by_tiles;
-                if (S > 8) S = 8;
+            } else if (gx % slots != 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && ix->ref_tiles >= 256) {
+                const int64_t tail = gx % slots;
+                double best = 1.0;
+                for (int s2 = 2; s2 <= 8; ++s2) {
+                    const double t = (double)((tail * s2 + slots - 1) / slots) / s2;
+                    if (t < best - 1e-9) { best = t; S2 = s2; }
+                }
+                if (S2 > 1) { gx_tail = tail; gx_main = gx - tail; }
             }
         }
         if (S > 8) S = 8;
         if (S < 1) S = 1;
         if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
         const int64_t tps = (ix->ref_tiles + S - 1) / S;
-        if (tps * S > ix->ref_tiles_alloc) return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
+        const int64_t tps2 = (ix->ref_tiles + S2 - 1) / S2;
+        if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
+            return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
+        const int64_t rows_main = gx_main * rows_per_wg, rows_tail = gx_tail * rows_per_wg;
         if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * Q * 256 * sizeof(float)))) return rc;
         if ((rc = ix->xnorm.reserve((size_t)m * sizeof(double)))) return rc;
-        if ((rc = ix->cand_idx.reserve((size_t)rows_pad * S * L * sizeof(uint32_t)))) return rc;
-        if ((rc = ix->cand_tau.reserve((size_t)rows_pad * S * sizeof(float)))) return rc;
+        if ((rc = ix->cand_idx.reserve((size_t)rows_main * S * L * sizeof(uint32_t) + 16))) return rc;
+        if ((rc = ix->cand_tau.reserve((size_t)rows_main * S * sizeof(float) + 16))) return rc;
+        if (gx_tail > 0) {
+            if ((rc = ix->cand_idx2.reserve((size_t)rows_tail * S2 * L * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->cand_tau2.reserve((size_t)rows_tail * S2 * sizeof(float)))) return rc;
+        }
         if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
         if ((rc = ix->failcnt.reserve(sizeof(unsigned int)))) return rc;
         HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
         HIP_TRY(nabo::pack_query_launch(dX, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
                                         ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
         HIP_TRY(hipEventRecord(ix->ev[1], st));
-        HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S, (int)gx,
-                                     ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(), st));
+        if (gx_main > 0)
+            HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,
+                                         (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
+                                         ix->cand_tau.as<float>(), st));
+        if (gx_tail > 0)
+            HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps2, S2,
+                                         (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
+                                         ix->cand_tau2.as<float>(), st));
         HIP_TRY(hipEventRecord(ix->ev[2], st));
         if (env_int("NABO_DEBUG_ABLATE", 0) != 0) {     // kernel-timing experiments only: results are garbage
             HIP_TRY(hipEventRecord(ix->ev[3], st));
@@ -364,10 +401,17 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
             return NABO_OK;
         }
         const double err_coef = 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
-        HIP_TRY(nabo::refine_launch(dX, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
+        const int64_t m_main = rows_main < m ? rows_main : m;
+        HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ix->ymax_sqrt, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st));
+        if (gx_tail > 0)
+            HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
+                                        ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
+                                        ix->ymax_sqrt, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
+                                        ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(),
+                                        ix->failcnt.as<unsigned int>(), st));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -375,7 +419,7 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
                                         n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
                                         d_oidx, d_odist, st));
         HIP_TRY(hipEventRecord(ix->ev[4], st));
-        n_wg = gx * S;
+        n_wg = gx_main * S + gx_tail * S2;
     } else {
         const int64_t n_chunks = (ix->n + 63) / 64;
         const int64_t gx = (m + 63) / 64;

@@ -21,9 +21,11 @@
 //   * accumulator layout: lane (l&31) = target, register r / lane-half = reference, so a
 //     row's threshold is ONE VGPR and the filter of a chain is 8 v_min3 + 1 v_cmp, scheduled
 //     into the shadow of the next chain's MFMAs; only a hit takes the (out-of-line) append path;
-//   * candidate lists are L kept + PEND pending entries per row; two 4-wave workgroups fit a CU
-//     (2 x 80 KB LDS, <= 256 VGPRs), so each SIMD holds two waves and one wave's append /
-//     compaction / L2 waits are covered by the other wave's MFMAs.
+//   * candidate lists per row: `lkeep` kept entries + a few pending slots per lane half; a lane
+//     appends its own hits without talking to its partner half; a full pending list triggers a
+//     wave-wide sort that keeps the lkeep smallest and tightens the threshold;
+//   * two 4-wave workgroups fit a CU (2 x 80 KB LDS, <= 256 VGPRs), so each SIMD holds two waves
+//     and one wave's append / compaction / L2 waits are covered by the other wave's MFMAs.
 // Algorithmic work: 2*m*n*d flop on the MFMA pipe; HBM traffic is only the packed operands
 // (4*KSTEPS*2 bytes per cell) and L indices per row -- the kernel is MFMA-bound.
 #include <cstdlib>
@@ -99,181 +101,187 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
     return acc;
 }
 
-// Two row-blocks against the same reference tile, MFMAs of the two accumulation chains
-// interleaved: consecutive MFMAs are independent (no dependent-issue bubble) and the chain
-// restart (C-in read, drain before the filter) is paid once per 2*KSTEPS MFMAs.  The tile
-// registers are reloaded in place for the next tile behind their last use.
-template <int KSTEPS>
-__device__ __forceinline__ void mfma_chain_pair(RefTile<KSTEPS> &y, const float (&xb0)[KSTEPS],
-                                                const float (&xb1)[KSTEPS], const float *__restrict__ next,
-                                                int lane, f32x16 &accA, f32x16 &accB)
-{
-    constexpr int Q = q_groups(KSTEPS);
-    accA = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb0[0], y.n, 0, 0, 0);
-    accB = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb1[0], y.n, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    y.n = *reinterpret_cast<const f32x16 *>(next + Q * 256 + (lane >> 5) * 16);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 1; s < KSTEPS; ++s) {
-        accA = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb0[s], accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb1[s], accB, 0, 0, 0);
-        if ((s & 3) == 3 || s == KSTEPS - 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            load_group<KSTEPS>(y.f[s >> 2], next, s >> 2, lane);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-// Candidate-list geometry: L = 32*EPL kept entries + PEND pending slots per row.
-template <int EPL, int PEND>
+// Candidate-list geometry (per target row, ROW entries in the owning wave's LDS slice), with
+// ph = (ROW - 2 - lkeep) / 2 pending slots per lane half (whatever the kept list does not need):
+//   [0, lkeep)                      kept entries (the lkeep smallest seen so far, sorted)
+//   [lkeep, lkeep+ph]               pending slots of lane half 0 (+1 scratch slot at index ph)
+//   [lkeep+ph+1, lkeep+2ph+1]       pending slots of lane half 1 (+1 scratch slot)
+template <int EPL, int PH>
 struct ListCfg {
-    static constexpr int L = 32 * EPL;
-    static constexpr int CAP = L + PEND;
-    static_assert(CAP <= 64 * EPL, "a row must fit one wave-wide sort");
+    static constexpr int LMAX = 32 * EPL;                // largest lkeep
+    static constexpr int ROW = LMAX + 2 * (PH + 1);      // PH = pending slots per half at lkeep == LMAX
+    static_assert(ROW - 2 <= 64 * EPL, "a row must fit one wave-wide sort");
+    __device__ static int ph(int lkeep) { return (ROW - 2 - lkeep) >> 1; }
 };
 
-// Sort one row's buffer, keep the L smallest, return the new threshold (key of rank L-1).
-template <int EPL, int PEND>
-__device__ __forceinline__ float compact_row(uint2 *rowbuf, uint32_t count, float (&key)[EPL], uint32_t (&val)[EPL])
+struct RowState {           // per lane; lanes l and l+32 hold the same tau / kc, their own pc
+    float tau;              // nothing with score >= tau can still enter the kept list
+    uint32_t pc;            // pending entries of this lane half
+    uint32_t kc;            // kept entries
+};
+
+// Sort kept + both pending lists of one row, keep the lkeep smallest.  Returns the new kept
+// count; `tau_out` is the key of rank lkeep-1 when at least lkeep entries exist.
+template <int EPL, int PH>
+__device__ __forceinline__ uint32_t compact_row(uint2 *rowbuf, uint32_t kc, uint32_t pa, uint32_t pb, int lkeep,
+                                                float &tau_io, float (&key)[EPL], uint32_t (&val)[EPL])
 {
-    constexpr int L = ListCfg<EPL, PEND>::L;
+    const int ph = ListCfg<EPL, PH>::ph(lkeep);
     const int lane = lane_id();
+    const uint32_t total = kc + pa + pb;
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
-        const int e = r * 64 + lane;
+        const uint32_t e = (uint32_t)(r * 64 + lane);
         key[r] = __builtin_inff();
         val[r] = 0xFFFFFFFFu;
-        if ((uint32_t)e < count) {
-            uint2 v = rowbuf[e];
+        if (e < total) {
+            uint32_t src = e;                                         // kept
+            if (e >= kc) src = lkeep + (e - kc);                      // pending, half 0
+            if (e >= kc + pa) src = lkeep + (ph + 1) + (e - kc - pa); // pending, half 1
+            uint2 v = rowbuf[src];
             key[r] = __uint_as_float(v.x);
             val[r] = v.y;
         }
     }
     wave_bitonic_sort<EPL, float>(key, val);
+    const uint32_t nk = total < (uint32_t)lkeep ? total : (uint32_t)lkeep;
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
-        const int e = r * 64 + lane;
-        if (e < L) rowbuf[e] = make_uint2(__float_as_uint(key[r]), val[r]);
+        const uint32_t e = (uint32_t)(r * 64 + lane);
+        if (e < nk) rowbuf[e] = make_uint2(__float_as_uint(key[r]), val[r]);
     }
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[(L - 1) >> 6]), (L - 1) & 63));
+    if (total >= (uint32_t)lkeep) {
+        const int e = lkeep - 1;
+        float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[0]), e & 63));
+        if (EPL > 1 && e >= 64)
+            t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[EPL - 1]), e & 63));
+        tau_io = t;
+    }
+    return nk;
 }
 
-// Append every accumulator element below its row's threshold to that row's list.
-// lane l: target row (l & 31) of this row-block; register r / half (l >> 5): reference
-// jbase + cd_row(r, l >> 5).  Lanes l and l+32 share a row and keep identical tau / cnt.
-// A row whose list is full is compacted (sort, keep L, tighten tau) and its deferred hits are
-// re-examined against the new threshold.
-template <int EPL, int PEND>
-__device__ __forceinline__ void append_hits(const f32x16 &acc, float &tau, uint32_t &cnt,
-                                            uint2 *blockbuf /* this wave+rb: [32][CAP] */, uint32_t jbase)
+// Hit path.  lane l: target row (l & 31) of this row-block; register r of lane half h is
+// reference jb + cd_row(r, 0) (jb already contains 4*h).  Per iteration every hitting lane appends
+// its smallest outstanding score to its own pending list (one unconditional ds_write: lanes
+// without a hit write their scratch slot), knocks that register out and looks again; rows whose
+// pending list is full are compacted first.  No per-register branches: a VALU->SALU round trip
+// costs more than the ~80 VALU instructions of an iteration.
+template <int EPL, int PH>
+__device__ __forceinline__ void slow_append(f32x16 a, float m, RowState &st, uint2 *blockbuf, uint32_t jb, int lkeep)
 {
-    constexpr int CAP = ListCfg<EPL, PEND>::CAP, L = ListCfg<EPL, PEND>::L;
+    constexpr int ROW = ListCfg<EPL, PH>::ROW;
+    const int ph = ListCfg<EPL, PH>::ph(lkeep);
     const int lane = lane_id();
-    const int tl = lane & 31;
-    const int hh = lane >> 5;
-    uint2 *rowbuf = blockbuf + tl * CAP;
-    uint32_t pend = 0xFFFFu;
+    const int tl = lane & 31, hh = lane >> 5;
+    uint2 *sub = blockbuf + tl * ROW + lkeep + hh * (ph + 1);
+    bool hit = m < st.tau;
     for (;;) {
-        uint32_t defer = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool hit = ((pend >> r) & 1u) && (acc[r] < tau);
-            const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
-            if (mask != 0) {
-                const uint32_t h0 = ((uint32_t)mask >> tl) & 1u;
-                const uint32_t h1 = ((uint32_t)(mask >> 32) >> tl) & 1u;
-                const uint32_t pos = cnt + (hh ? h0 : 0u);
-                const bool ok = hit && pos < (uint32_t)CAP;
-                if (ok) rowbuf[pos] = make_uint2(__float_as_uint(acc[r]), jbase + (uint32_t)(cd_row(r, 0) + 4 * hh));
-                if (hit && !ok) defer |= (1u << r);
-                cnt = min(cnt + h0 + h1, (uint32_t)CAP);
+        const uint64_t fm = __builtin_amdgcn_ballot_w64(hit && st.pc >= (uint32_t)ph);
+        if (fm != 0) {
+            uint32_t rows = (uint32_t)fm | (uint32_t)(fm >> 32);
+            while (rows) {
+                const int row = __builtin_ctz(rows);
+                rows &= rows - 1;
+                const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)st.kc, row);
+                const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row);
+                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row + 32);
+                float nt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.tau), row));
+                float key[EPL];
+                uint32_t val[EPL];
+                const uint32_t nk = compact_row<EPL, PH>(blockbuf + row * ROW, kc, pa, pb, lkeep, nt, key, val);
+                if (tl == row) { st.tau = nt; st.pc = 0; st.kc = nk; }
             }
+            hit = m < st.tau;
+            if (__builtin_amdgcn_ballot_w64(hit) == 0) break;
+            continue;
         }
-        const uint64_t dm = __builtin_amdgcn_ballot_w64(defer != 0);
-        if (dm == 0) break;
-        uint32_t rows = (uint32_t)dm | (uint32_t)(dm >> 32);
-        while (rows) {
-            const int row = __builtin_ctz(rows);
-            rows &= rows - 1;
-            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, row);
-            float key[EPL];
-            uint32_t val[EPL];
-            const float nt = compact_row<EPL, PEND>(blockbuf + row * CAP, c, key, val);
-            if (tl == row) { tau = nt; cnt = min(c, (uint32_t)L); }
-        }
-        pend = defer;
+        // register holding the lane minimum
+        uint32_t rs = 0;
+#pragma unroll
+        for (int r = 15; r >= 1; --r) rs = (a[r] == m) ? (uint32_t)r : rs;
+        const uint32_t slot = hit ? st.pc : (uint32_t)ph;
+        sub[slot] = make_uint2(__float_as_uint(m), jb + (rs & 3u) + 8u * (rs >> 2));
+        st.pc += hit ? 1u : 0u;
+        // knock it out, look for another hit in the same lane
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = (hit && rs == (uint32_t)r) ? __builtin_inff() : a[r];
+        m = a[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) m = fminf(m, a[r]);
+        hit = m < st.tau;
+        if (__builtin_amdgcn_ballot_w64(hit) == 0) break;
     }
 }
 
-template <int EPL, int PEND>
-__device__ __forceinline__ void filter_and_append(const f32x16 &acc, float &tau, uint32_t &cnt,
-                                                  uint2 *blockbuf, uint32_t jbase)
+template <int EPL, int PH>
+__device__ __forceinline__ void filter_and_append(const f32x16 &acc, RowState &st, uint2 *blockbuf, uint32_t jb,
+                                                  int lkeep)
 {
-    bool any = false;
+    float m = acc[0];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) any |= (acc[r] < tau);
-    if (__builtin_amdgcn_ballot_w64(any) != 0) append_hits<EPL, PEND>(acc, tau, cnt, blockbuf, jbase);
+    for (int r = 1; r < 16; ++r) m = fminf(m, acc[r]);
+    if (__builtin_amdgcn_ballot_w64(m < st.tau) != 0) slow_append<EPL, PH>(acc, m, st, blockbuf, jb, lkeep);
 }
 
-// Final flush of one row-block: sort every row, emit L candidate indices (+ tau).
-template <int EPL, int PEND>
-__device__ __forceinline__ void flush_block(float &tau, uint32_t &cnt, uint2 *blockbuf,
-                                            int64_t grow0, int split, int S,
+// Final flush of one row-block: sort every row, emit the kept candidate indices (+ tau).
+template <int EPL, int PH>
+__device__ __forceinline__ void flush_block(RowState &st, uint2 *blockbuf, int64_t lrow0, int split, int S, int lkeep,
                                             uint32_t *__restrict__ cand_idx, float *__restrict__ cand_key,
                                             float *__restrict__ cand_tau)
 {
-    constexpr int CAP = ListCfg<EPL, PEND>::CAP, L = ListCfg<EPL, PEND>::L;
+    constexpr int LMAX = ListCfg<EPL, PH>::LMAX, ROW = ListCfg<EPL, PH>::ROW;
     const int lane = lane_id();
-    const int tl = lane & 31;
     for (int row = 0; row < 32; ++row) {
-        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cnt, row);
+        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)st.kc, row);
+        const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row);
+        const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row + 32);
+        float t_row = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.tau), row));
         float key[EPL];
         uint32_t val[EPL];
-        float nt = compact_row<EPL, PEND>(blockbuf + row * CAP, c, key, val);
-        float t_row = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tau), row));
-        if (c > (uint32_t)L) t_row = nt;           // entries were dropped: threshold = rank L-1 key
-        const int64_t o = ((grow0 + row) * S + split) * (int64_t)L;
+        const uint32_t nk = compact_row<EPL, PH>(blockbuf + row * ROW, kc, pa, pb, lkeep, t_row, key, val);
+        const int64_t o = ((lrow0 + row) * S + split) * (int64_t)LMAX;
 #pragma unroll
         for (int r = 0; r < EPL; ++r) {
-            const int e = r * 64 + lane;
-            if (e < L) {
-                cand_idx[o + e] = val[r];
-                if (cand_key) cand_key[o + e] = key[r];
+            const uint32_t e = (uint32_t)(r * 64 + lane);
+            if (e < (uint32_t)LMAX) {
+                cand_idx[o + e] = e < nk ? val[r] : 0xFFFFFFFFu;
+                if (cand_key) cand_key[o + e] = e < nk ? key[r] : __builtin_inff();
             }
         }
-        if (lane == 0) cand_tau[(grow0 + row) * S + split] = t_row;
-        if (tl == row) { tau = t_row; cnt = min(c, (uint32_t)L); }
+        if (lane == 0) cand_tau[(lrow0 + row) * S + split] = t_row;
     }
 }
 
 // Grid: x = target super-blocks (4 waves x R tiles of 32 rows), y = reference splits.
-// Xpk: [gridDim.x*4*R][qtile] packed target tiles (scaled by -2; padded tiles are zero).
+// Xpk: packed target tiles (scaled by -2; padded tiles are zero); this launch covers tiles
+//      [tile_off, tile_off + gridDim.x*4*R).
 // Ypk: [S*tiles_per_split][rtile] packed reference tiles (padding: zero fragments, +inf norm).
-// cand_idx/cand_key: [rows_pad][S][L], cand_tau: [rows_pad][S], rows_pad = gridDim.x*4*R*32.
+// cand_idx/cand_key: [rows_launch][S][LMAX], cand_tau: [rows_launch][S] (rows local to the launch).
 // Two waves per SIMD need <= 256 VGPRs; that holds while the resident target fragments
 // (R*KSTEPS registers) stay <= 64 -- larger shapes run one wave per SIMD without spilling.
-template <int KSTEPS, int R, int EPL, int PEND>
+template <int KSTEPS, int R, int EPL, int PH>
 __global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kernel(const float *__restrict__ Xpk,
-                                                         const float *__restrict__ Ypk,
-                                                         int tiles_per_split,
-                                                         uint32_t *__restrict__ cand_idx,
-                                                         float *__restrict__ cand_key,
-                                                         float *__restrict__ cand_tau,
-                                                         int dbg /* ablation switches, 0 in production */)
+                                                                                  const float *__restrict__ Ypk,
+                                                                                  int tiles_per_split,
+                                                                                  int64_t tile_off, int lkeep,
+                                                                                  uint32_t *__restrict__ cand_idx,
+                                                                                  float *__restrict__ cand_key,
+                                                                                  float *__restrict__ cand_tau,
+                                                                                  int dbg /* ablation, 0 in production */)
 {
-    constexpr int CAP = ListCfg<EPL, PEND>::CAP;
+    constexpr int ROW = ListCfg<EPL, PH>::ROW;
     constexpr int QTF = qtile_floats(KSTEPS);
     constexpr int RTF = rtile_floats(KSTEPS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint2 *smem = reinterpret_cast<uint2 *>(smem_raw);
 
     const int lane = lane_id();
+    const int hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = blockIdx.y;
     const int S = gridDim.y;
-    const int64_t ttile0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+    const int64_t ltile0 = ((int64_t)blockIdx.x * 4 + wave) * R;     // local to this launch
+    const int64_t ttile0 = tile_off + ltile0;
 
     // resident target fragments
     float xb[R][KSTEPS];
@@ -288,11 +296,14 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kerne
                 if (4 * q + e < KSTEPS) xb[rb][4 * q + e] = v[e];
         }
     }
-    float tau[R];
-    uint32_t cnt[R];
+    RowState st[R];
 #pragma unroll
-    for (int rb = 0; rb < R; ++rb) { tau[rb] = (dbg & 1) ? -__builtin_inff() : __builtin_inff(); cnt[rb] = 0; }
-    uint2 *wbuf = smem + (size_t)wave * R * 32 * CAP;
+    for (int rb = 0; rb < R; ++rb) {
+        st[rb].tau = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
+        st[rb].pc = 0;
+        st[rb].kc = 0;
+    }
+    uint2 *wbuf = smem + (size_t)wave * R * 32 * ROW;
 
     const int64_t t_begin = (int64_t)split * tiles_per_split;
     const int64_t t_end = t_begin + tiles_per_split;
@@ -300,9 +311,6 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kerne
 
     RefTile<KSTEPS> y;
     load_ref_tile<KSTEPS>(y, ybase + t_begin * RTF, lane);
-    if ((dbg & 4) && ((blockIdx.x >> 8) & 1)) {          // experiment: stagger the two workgroups of a CU
-        for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);
-    }
 
     f32x16 accP;                  // chain whose filter is still pending
 #pragma unroll
@@ -310,53 +318,65 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kerne
 
     if (R == 2) {
         for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (dbg & 2) ? t_begin + ((t + 1) & 63) : ((t + 1 < t_end) ? t + 1 : t);
-            f32x16 accA, accB;
-            mfma_chain_pair<KSTEPS>(y, xb[0], xb[R - 1], ybase + tn * RTF, lane, accA, accB);
-            filter_and_append<EPL, PEND>(accA, tau[0], cnt[0], wbuf, (uint32_t)(t * 32));
-            filter_and_append<EPL, PEND>(accB, tau[R - 1], cnt[R - 1], wbuf + (R - 1) * 32 * CAP, (uint32_t)(t * 32));
+            const int64_t tn = (t + 1 < t_end) ? t + 1 : t;
+            f32x16 accA = mfma_chain<KSTEPS, false>(y, xb[0], nullptr, lane);
+            filter_and_append<EPL, PH>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, (uint32_t)((t - 1) * 32 + 4 * hh), lkeep);
+            accP = mfma_chain<KSTEPS, true>(y, xb[R - 1], ybase + tn * RTF, lane);
+            filter_and_append<EPL, PH>(accA, st[0], wbuf, (uint32_t)(t * 32 + 4 * hh), lkeep);
         }
+        filter_and_append<EPL, PH>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, (uint32_t)((t_end - 1) * 32 + 4 * hh), lkeep);
     } else {
         for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (dbg & 2) ? t_begin + ((t + 1) & 63) : ((t + 1 < t_end) ? t + 1 : t);
+            const int64_t tn = (t + 1 < t_end) ? t + 1 : t;
             f32x16 accA = mfma_chain<KSTEPS, true>(y, xb[0], ybase + tn * RTF, lane);
-            filter_and_append<EPL, PEND>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t - 1) * 32));
+            filter_and_append<EPL, PH>(accP, st[0], wbuf, (uint32_t)((t - 1) * 32 + 4 * hh), lkeep);
             accP = accA;
         }
-        filter_and_append<EPL, PEND>(accP, tau[0], cnt[0], wbuf, (uint32_t)((t_end - 1) * 32));
+        filter_and_append<EPL, PH>(accP, st[0], wbuf, (uint32_t)((t_end - 1) * 32 + 4 * hh), lkeep);
     }
 
 #pragma unroll
     for (int rb = 0; rb < R; ++rb)
-        flush_block<EPL, PEND>(tau[rb], cnt[rb], wbuf + rb * 32 * CAP, (ttile0 + rb) * 32, split, S,
-                               cand_idx, cand_key, cand_tau);
+        flush_block<EPL, PH>(st[rb], wbuf + rb * 32 * ROW, (ltile0 + rb) * 32, split, S, lkeep, cand_idx, cand_key,
+                             cand_tau);
 }
 
 // ---- launch wrapper -------------------------------------------------------------------
-template <int KSTEPS, int R, int EPL, int PEND>
-static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
-                             uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
+template <int KSTEPS, int R, int EPL, int PH>
+static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx, int64_t tile_off,
+                             int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
     static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
-    const size_t lds = (size_t)4 * R * 32 * ListCfg<EPL, PEND>::CAP * sizeof(uint2);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL, PEND>),
+    const size_t lds = (size_t)4 * R * 32 * ListCfg<EPL, PH>::ROW * sizeof(uint2);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL, PH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(256);
-    hipLaunchKernelGGL((l2_topk_kernel<KSTEPS, R, EPL, PEND>), grid, block, lds, st, Xpk, Ypk, tiles_per_split,
-                       cand_idx, cand_key, cand_tau, dbg);
+    hipLaunchKernelGGL((l2_topk_kernel<KSTEPS, R, EPL, PH>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off,
+                       lkeep, cand_idx, cand_key, cand_tau, dbg);
     return hipGetLastError();
 }
 
-// ksteps must be one of the instantiated values; epl 1 -> L=32 (R=2), 2 -> L=64 (R=1).
-// Lists are L + 8*EPL entries: two workgroups (2 x 80 KB) per CU.
-hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split,
-                          int S, int gx, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
+// Rows per workgroup and co-resident workgroups per CU of the variant that will run.
+void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu)
 {
-#define NABO_CASE(KS)                                                                                          \
-    case KS:                                                                                                   \
-        return epl == 1 ? launch_one<KS, 2, 1, 8>(Xpk, Ypk, tiles_per_split, S, gx, cand_idx, cand_key, cand_tau, st) \
-                        : launch_one<KS, 1, 2, 16>(Xpk, Ypk, tiles_per_split, S, gx, cand_idx, cand_key, cand_tau, st);
+    const int R = epl == 1 ? 2 : 1;
+    *rows_per_wg = 4 * R * 32;
+    *wg_per_cu = (R * ksteps <= 64) ? 2 : 1;
+}
+
+// ksteps must be one of the instantiated values; epl 1 -> lists of <= 32 (R=2), 2 -> <= 64 (R=1).
+// Row lists take 40 (80) entries: two workgroups (2 x 80 KB) per CU.
+hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
+                          int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                          hipStream_t st)
+{
+#define NABO_CASE(KS)                                                                                                 \
+    case KS:                                                                                                          \
+        return epl == 1 ? launch_one<KS, 2, 1, 3>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+                                                  cand_tau, st)                                                       \
+                        : launch_one<KS, 1, 2, 7>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+                                                  cand_tau, st);
     switch (ksteps) {
         NABO_CASE(8)
         NABO_CASE(16)

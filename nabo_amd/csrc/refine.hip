@@ -84,7 +84,7 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 
 // One wave per target row; NCL = ceil(S*L/64) candidates per lane.
 template <int NCL>
-__global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t m,
+__global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                      const double *__restrict__ Y, int g,
                                                      const uint32_t *__restrict__ cand_idx,
                                                      const float *__restrict__ cand_tau, int S, int L,
@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                                                      uint32_t *__restrict__ fail_rows,
                                                      unsigned int *__restrict__ fail_count)
 {
+    // rows [row0, m) of X; candidate arrays are indexed by the row LOCAL to this launch
     const int lane = lane_id();
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = row0 + lrow;
     if (row >= m) return;
     const double *x = X + row * g;
     const int ncand = S * L;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         key[r] = __builtin_inf();
         val[r] = 0xFFFFFFFFu;
         if (e < ncand) {
-            const uint32_t j = cand_idx[row * ncand + e];
+            const uint32_t j = cand_idx[lrow * ncand + e];
             if (j != 0xFFFFFFFFu) {
                 val[r] = j;
                 key[r] = euclid_exact(x, Y + (int64_t)j * g, g);
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     const int kk = k + drop;
     // threshold below which no reference was discarded by the filter (min over splits)
     float tmin = __builtin_inff();
-    for (int s = lane; s < S; s += 64) tmin = fminf(tmin, cand_tau[row * S + s]);
+    for (int s = lane; s < S; s += 64) tmin = fminf(tmin, cand_tau[lrow * S + s]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
 
@@ -256,16 +258,17 @@ hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t 
     return hipGetLastError();
 }
 
-hipError_t refine_launch(const double *X, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
+hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                          double ymax_sqrt, int k, int drop, int64_t base, int64_t n_valid_total,
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
                          uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st)
 {
     const int ncl = (S * L + 63) / 64;
-    dim3 grid((unsigned)((m + 3) / 4)), block(256);
+    if (m <= row0) return hipSuccess;
+    dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
 #define NABO_RF(N)                                                                                               \
-    hipLaunchKernelGGL((refine_kernel<N>), grid, block, 0, st, X, m, Y, g, cand_idx, cand_tau, S, L, xnorm,       \
+    hipLaunchKernelGGL((refine_kernel<N>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, L, xnorm, \
                        err_coef, ymax_sqrt, k, drop, base, n_valid_total, masked_list, n_masked_list, out_idx,    \
                        out_dist, fail_rows, fail_count)
     if (ncl <= 1) NABO_RF(1);
