@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- k-NN mapping throughput on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--m M --n N --d D --k K]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--targets M --refs N --dims D --neighbors K]
 
 A step = one full k-NN build of the workload: pack the (sharded) references, fused
 distance + top-k on the MFMA pipe, float64 refine, and for N>1 the RCCL exchange + merge.
@@ -30,7 +30,7 @@ def cpu_baseline(d, k):
     cores, on a bounded sample of the same workload."""
     import oracle
     from nabo_amd._synth import pca_like
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, min(os.cpu_count() or 1, 16))      # the GPU box's CPU share for one GPU
     n_s, m_s = 100000, 1024
     Y = pca_like(n_s, d, seed=1003)
     X = pca_like(m_s, d, seed=2003)
@@ -54,18 +54,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--m", type=int, default=1000000)
-    ap.add_argument("--n", type=int, default=1000000)
-    ap.add_argument("--d", type=int, default=50)
-    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--targets", dest="m", type=int, default=1000000)
+    ap.add_argument("--refs", dest="n", type=int, default=1000000)
+    ap.add_argument("--dims", dest="d", type=int, default=50)
+    ap.add_argument("--neighbors", dest="k", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1 or os.environ.get("NABO_BENCH_FORCE_DIST") == "1"    # rehearsal of the N>1 code on 1 GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
+    if use_dist:
+        # torch bundles its own HIP runtime: it must be loaded BEFORE libnabo_knn.so so that the
+        # process ends up with ONE libamdhip64 (the library then binds to torch's copy)
+        import torch  # noqa: F401
     import nabo_amd
     from nabo_amd import _knn
     from nabo_amd._dist import shard_bounds
@@ -79,7 +84,7 @@ def main():
     Y = pca_like(n, d, seed=1003)[lo:hi]
     X = pca_like(m, d, seed=2003)
 
-    if world > 1:
+    if use_dist:
         import torch
         import torch.distributed as dist
         from nabo_amd._dist import ShardedKnn, gpu_callables
@@ -99,7 +104,7 @@ def main():
     index = nabo_amd.KnnIndex(hi - lo, d, metric=nabo_amd.EUCLIDEAN, ref_index_base=lo, device=dev)
     stats = []
 
-    if world > 1:
+    if use_dist:
         lk, mg = gpu_callables(index, dev)
         sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev))
 
@@ -130,13 +135,13 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
     # light self-check outside the timed region (rank 0): sorted rows, valid indices
-    if world == 1 and not os.environ.get("NABO_DEBUG_ABLATE"):
+    if not use_dist and not os.environ.get("NABO_DEBUG_ABLATE"):
         gi = dI.download((m, k), np.int64)
         gd = dD.download((m, k), np.float64)
         assert gi.min() >= 0 and gi.max() < n and (np.diff(gd[:: max(1, m // 4096)], axis=1) >= 0).all()
@@ -153,10 +158,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "knn_build_s": dt / a.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 MFMA filter + f64 refine (results float64-exact)", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, euclidean, refs sharded %d-way"
                                    % (n // 1000, m // 1000, d, k, world),
-                       "parallelism": "ref-shard%d" % world},
+                       "parallelism": "ref-shard%d" % world,
+                       "arithmetic": "fp32 MFMA score filter, float64 re-evaluation: indices and distances equal the "
+                                     "reference's float64 path"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "kernel": "l2_topk_kernel (v_mfma_f32_32x32x2_f32)", "kernel_ms": t_kernel * 1e3},
@@ -164,10 +171,10 @@ def main():
                           ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
             "fallback_rows": int(np.max([s["fallback_rows"] for s in stats])),
         }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not use_dist:
             line["cpu_baseline"] = cpu_baseline(d, k)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
