@@ -288,7 +288,8 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
 {
     if (!ix || !X || !out_idx || !out_dist) return fail(NABO_E_INVALID, "NULL argument");
     if (!ix->have_ref) return fail(NABO_E_INVALID, "nabo_index_set_ref has not been called");
-    if (m < 1) return fail(NABO_E_INVALID, "m=%lld must be >= 1", (long long)m);
+    if (m < 0) return fail(NABO_E_INVALID, "m=%lld must be >= 0", (long long)m);
+    if (m == 0) return NABO_OK;                      // no target cells: nothing to do (reference loops are empty)
     const int drop = drop_first ? 1 : 0;
     const int kk = k + drop;
     if (k < 1) return fail(NABO_E_INVALID, "k=%d must be >= 1", k);

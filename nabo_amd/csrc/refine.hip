@@ -145,8 +145,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             certified = bound > dk * dk * (1.0 + 1e-12);
         }
     } else {
-        // fewer candidates than k': fine only if the filter never discarded anything
-        certified = (tmin == __builtin_inff()) || ((int64_t)nreal >= n_valid_total);
+        // fewer candidates than k': only legitimate when EVERY unmasked reference is a candidate
+        // (tiny reference sets).  Anything else (e.g. non-finite fp32 scores) goes to the exact path.
+        certified = (int64_t)nreal >= n_valid_total;
     }
     if (!certified) {
         if (lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = (uint32_t)row;

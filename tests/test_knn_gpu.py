@@ -223,3 +223,35 @@ def test_config2_100k_sampled_rows(gpu_lib):
     chk = oracle.pairwise(X[rows[:8]], Y[gi[rows[0]]], 0)[0]
     assert np.array_equal(chk, gd[rows[0]])
     assert st["fallback_rows"] < n // 100
+
+
+def test_far_from_origin_and_badly_scaled_inputs(gpu_lib):
+    """Centring + the certification must keep results exact when the cloud sits far from the origin
+    and when components differ by many orders of magnitude."""
+    Y = pca_like(5000, 30, seed=61)
+    X = pca_like(300, 30, seed=62)
+    for shift, scale in ((1e4, 1.0), (0.0, 1e-6), (-3e5, 1e3)):
+        Ys, Xs = Y * scale + shift, X * scale + shift
+        gi, gd = gpu_lib.knn(Xs, Ys, 15, metric=0)
+        oi, od = oracle.knn(Xs, Ys, 15, 0, nthreads=8)
+        _check(gi, gd, oi, od)
+
+
+def test_overflowing_fp32_scores_fall_back_to_the_exact_path(gpu_lib):
+    """Magnitudes whose squares overflow fp32: the filter sees inf/NaN, the guard must notice and the
+    float64 fallback must still answer exactly."""
+    Y = pca_like(600, 8, seed=63) * 1e25
+    X = pca_like(20, 8, seed=64) * 1e25
+    ix = gpu_lib.KnnIndex(600, 8, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, 5)
+    st = ix.last_stats()
+    ix.close()
+    oi, od = oracle.knn(X, Y, 5, 0)
+    _check(gi, gd, oi, od)
+    assert st["fallback_rows"] == 20
+
+
+def test_zero_target_rows_is_a_no_op(gpu_lib):
+    Y = pca_like(100, 5, seed=65)
+    gi, gd = gpu_lib.knn(np.empty((0, 5)), Y, 3)
+    assert gi.shape == (0, 3) and gd.shape == (0, 3)
