@@ -22,11 +22,23 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st);
 void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu);
+// f16x3 variant (l2h_topk.hip)
+hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned int *out_bits, hipStream_t st);
+hipError_t pack_href_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int ks16,
+                            int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
+                            hipStream_t st);
+hipError_t pack_hquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int ks16,
+                              int64_t ntiles_total, unsigned char *out, double *xnorm, hipStream_t st);
+hipError_t l2h_topk_launch(int ks16, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                           int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           hipStream_t st);
+void l2h_topk_geometry(int ks16, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
+int l2h_pick_ks16(int g);
 hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t n, int g, int metric, double f,
                            double *D, hipStream_t st);
 hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef, double ymax_sqrt,
-                         int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
+                         double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
                          unsigned int *fail_count, hipStream_t st);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
@@ -138,11 +150,15 @@ struct nabo_index {
     int64_t n_masked = 0;
     int n_masked_list = 0;
 
-    // Euclidean path
+    // Euclidean path.  mode 0: fp32 MFMA (l2_topk.hip); mode 1: f16x3 split (l2h_topk.hip, experimental)
+    int mode = 0;
+    int ks16 = 0;
+    double hscale = 1.0;
     int ksteps = 0;
-    DevBuf centre, ypk, normmax;
+    DevBuf centre, ypk, yhpk, normmax;
+    bool packed_f32 = false, packed_f16 = false;
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
-    double ymax_sqrt = 0.0;
+    double ymax_sqrt = 0.0, ymax_sqrt_h = 0.0;
     // Canberra path
     DevBuf yt;
 
@@ -153,6 +169,49 @@ struct nabo_index {
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
 };
+
+// Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernel.
+static int ensure_packed(nabo_index *ix, bool want_h)
+{
+    if (want_h ? ix->packed_f16 : ix->packed_f32) return NABO_OK;
+    hipStream_t st = ix->stream;
+    int rc;
+    if ((rc = ix->normmax.reserve(2 * sizeof(unsigned int)))) return rc;
+    HIP_TRY(hipMemsetAsync(ix->normmax.p, 0, 2 * sizeof(unsigned int), st));
+    unsigned int bits[2] = {0, 0};
+    if (want_h) {
+        const size_t tile_bytes = (size_t)2 * ix->ks16 * 1024 + 128;
+        if ((rc = ix->yhpk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
+        // power-of-two scale: |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
+        HIP_TRY(nabo::maxabs_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->normmax.as<unsigned int>() + 1, st));
+        HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float amax;
+        memcpy(&amax, &bits[1], sizeof(amax));
+        int e = 0;
+        if (amax > 0 && std::isfinite(amax)) e = 12 - (int)std::ceil(std::log2((double)amax));
+        if (e > 60) e = 60;
+        if (e < -60) e = -60;
+        ix->hscale = std::ldexp(1.0, e);
+        HIP_TRY(nabo::pack_href_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->ks16,
+                                       ix->ref_tiles_alloc, ix->dmask, ix->yhpk.as<unsigned char>(),
+                                       ix->normmax.as<unsigned int>(), st));
+    } else {
+        const int Q = (ix->ksteps + 3) / 4;
+        const size_t tile_bytes = ((size_t)Q * 256 + 32) * sizeof(float);
+        if ((rc = ix->ypk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
+        HIP_TRY(nabo::pack_ref_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->ksteps, ix->ref_tiles_alloc,
+                                      ix->dmask, ix->ypk.as<float>(), ix->normmax.as<unsigned int>(), st));
+    }
+    HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float fmax;
+    memcpy(&fmax, &bits[0], sizeof(fmax));
+    const double v = std::sqrt((double)fmax) * (1.0 + 1e-6);
+    if (want_h) { ix->ymax_sqrt_h = v; ix->packed_f16 = true; }
+    else { ix->ymax_sqrt = v; ix->packed_f32 = true; }
+    return NABO_OK;
+}
 
 extern "C" {
 
@@ -190,7 +249,14 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
     ix->metric = metric;
     ix->f = dist_factor;
     ix->base = ref_index_base;
-    if (metric == NABO_METRIC_EUCLIDEAN) ix->ksteps = pick_ksteps(g);
+    if (metric == NABO_METRIC_EUCLIDEAN) {
+        ix->ksteps = pick_ksteps(g);
+        const char *md = getenv("NABO_L2_MODE");
+        if (md && strcmp(md, "f16x3") == 0 && nabo::l2h_pick_ks16(g) > 0) {
+            ix->mode = 1;
+            ix->ks16 = nabo::l2h_pick_ks16(g);
+        }
+    }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
         ix->n_cu = cus;
@@ -209,7 +275,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->normmax, &ix->yt,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -256,23 +322,12 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         }
     }
     if (ix->metric == NABO_METRIC_EUCLIDEAN) {
-        const int Q = (ix->ksteps + 3) / 4;
-        const size_t rtf = (size_t)Q * 256 + 32;
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 16;      // room for split padding (+inf-norm tiles)
+        ix->packed_f32 = ix->packed_f16 = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
-        if ((rc = ix->ypk.reserve((size_t)ix->ref_tiles_alloc * rtf * sizeof(float)))) return rc;
-        if ((rc = ix->normmax.reserve(sizeof(unsigned int)))) return rc;
-        HIP_TRY(hipMemsetAsync(ix->normmax.p, 0, sizeof(unsigned int), st));
         HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
-        HIP_TRY(nabo::pack_ref_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->ksteps, ix->ref_tiles_alloc,
-                                      ix->dmask, ix->ypk.as<float>(), ix->normmax.as<unsigned int>(), st));
-        unsigned int bits = 0;
-        HIP_TRY(hipMemcpyAsync(&bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        float fmax;
-        memcpy(&fmax, &bits, sizeof(fmax));
-        ix->ymax_sqrt = std::sqrt((double)fmax) * (1.0 + 1e-6);
+        if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
     } else {
         const int64_t chunks = (ix->n + 63) / 64;
         if ((rc = ix->yt.reserve((size_t)chunks * 64 * ix->g * sizeof(double)))) return rc;
@@ -326,8 +381,17 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
     HIP_TRY(hipEventRecord(ix->ev[0], st));
 
     if (ix->metric == NABO_METRIC_EUCLIDEAN) {
-        int rows_per_wg = 256, wg_per_cu = 1;
-        nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu);
+        int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = L;
+        bool use_h = false;
+        if (ix->mode == 1 && epl == 1) {
+            nabo::l2h_topk_geometry(ix->ks16, &rows_per_wg, &wg_per_cu, &lkeep_max);
+            use_h = kk + 4 <= lkeep_max;            // needs at least 4 entries of slack
+        }
+        if (!use_h) {
+            lkeep_max = L;
+            nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu);
+        }
+        if ((rc = ensure_packed(ix, use_h))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
         const int64_t rows_pad = gx * rows_per_wg;
@@ -335,8 +399,8 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         // kept-list length: k' + 8 slack (the certification needs a gap above the k'-th distance)
         int lkeep = kk + 8;
         if (lkeep < 16) lkeep = 16;
-        if (lkeep > L) lkeep = L;
-        { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= L) lkeep = lk; }   // experiments
+        if (lkeep > lkeep_max) lkeep = lkeep_max;
+        { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }   // experiments
         // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
         // chip is full.  Many rows: the last, partially filled round of workgroups is launched with
         // its own split factor S2 so that it takes ~1/S2 of a round instead of a whole one.
@@ -368,7 +432,8 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
             return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
         const int64_t rows_main = gx_main * rows_per_wg, rows_tail = gx_tail * rows_per_wg;
-        if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * Q * 256 * sizeof(float)))) return rc;
+        const size_t xtile_bytes = use_h ? (size_t)2 * ix->ks16 * 1024 : (size_t)Q * 256 * sizeof(float);
+        if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * xtile_bytes))) return rc;
         if ((rc = ix->xnorm.reserve((size_t)m * sizeof(double)))) return rc;
         if ((rc = ix->cand_idx.reserve((size_t)rows_main * S * L * sizeof(uint32_t) + 16))) return rc;
         if ((rc = ix->cand_tau.reserve((size_t)rows_main * S * sizeof(float) + 16))) return rc;
@@ -379,17 +444,32 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
         if ((rc = ix->failcnt.reserve(sizeof(unsigned int)))) return rc;
         HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
-        HIP_TRY(nabo::pack_query_launch(dX, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
-                                        ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
+        if (use_h)
+            HIP_TRY(nabo::pack_hquery_launch(dX, m, g, ix->centre.as<double>(), ix->hscale, ix->ks16, rows_pad / 32,
+                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), st));
+        else
+            HIP_TRY(nabo::pack_query_launch(dX, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
+                                            ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
         HIP_TRY(hipEventRecord(ix->ev[1], st));
-        if (gx_main > 0)
-            HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,
-                                         (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
-                                         ix->cand_tau.as<float>(), st));
-        if (gx_tail > 0)
-            HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps2, S2,
-                                         (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
-                                         ix->cand_tau2.as<float>(), st));
+        if (use_h) {
+            if (gx_main > 0)
+                HIP_TRY(nabo::l2h_topk_launch(ix->ks16, ix->xpk.as<unsigned char>(), ix->yhpk.as<unsigned char>(),
+                                              (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
+                                              ix->cand_tau.as<float>(), st));
+            if (gx_tail > 0)
+                HIP_TRY(nabo::l2h_topk_launch(ix->ks16, ix->xpk.as<unsigned char>(), ix->yhpk.as<unsigned char>(),
+                                              (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
+                                              ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(), st));
+        } else {
+            if (gx_main > 0)
+                HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,
+                                             (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
+                                             ix->cand_tau.as<float>(), st));
+            if (gx_tail > 0)
+                HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps2, S2,
+                                             (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
+                                             ix->cand_tau2.as<float>(), st));
+        }
         HIP_TRY(hipEventRecord(ix->ev[2], st));
         if (env_int("NABO_DEBUG_ABLATE", 0) != 0) {     // kernel-timing experiments only: results are garbage
             HIP_TRY(hipEventRecord(ix->ev[3], st));
@@ -401,16 +481,21 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
             ix->ms[1] = tt;
             return NABO_OK;
         }
-        const double err_coef = 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
+        // rounding-error coefficient of the filter score, relative to (||x|| + max||y||)^2
+        const double err_coef = use_h
+                                    ? 1.05 * ((48.0 * ix->ks16 + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20))
+                                    : 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
+        const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0;
+        const double ymax_sqrt = use_h ? ix->ymax_sqrt_h : ix->ymax_sqrt;
         const int64_t m_main = rows_main < m ? rows_main : m;
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
-                                    ix->xnorm.as<double>(), err_coef, ix->ymax_sqrt, k, drop, ix->base, n_valid,
+                                    ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
-                                        ix->ymax_sqrt, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
+                                        ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(),
                                         ix->failcnt.as<unsigned int>(), st));
         HIP_TRY(hipEventRecord(ix->ev[3], st));

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                                                      const uint32_t *__restrict__ cand_idx,
                                                      const float *__restrict__ cand_tau, int S, int L,
                                                      const double *__restrict__ xnorm, double err_coef,
-                                                     double ymax_sqrt, int k, int drop, int64_t base,
+                                                     double ymax_sqrt, double tau_scale, int k, int drop, int64_t base,
                                                      int64_t n_valid_total,
                                                      const uint32_t *__restrict__ masked_list, int n_masked_list,
                                                      int64_t *__restrict__ out_idx, double *__restrict__ out_dist,
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         if (tmin != __builtin_inff()) {
             const double sx = sqrt(xnorm[row]);
             const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
-            const double bound = ((double)tmin + xnorm[row] - E) * (1.0 - 1e-12);
+            const double bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);   // tau in score units
             certified = bound > dk * dk * (1.0 + 1e-12);
         }
     } else {
@@ -261,7 +261,7 @@ hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t 
 
 hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
-                         double ymax_sqrt, int k, int drop, int64_t base, int64_t n_valid_total,
+                         double ymax_sqrt, double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total,
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
                          uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st)
 {
@@ -270,7 +270,8 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
 #define NABO_RF(N)                                                                                               \
     hipLaunchKernelGGL((refine_kernel<N>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, L, xnorm, \
-                       err_coef, ymax_sqrt, k, drop, base, n_valid_total, masked_list, n_masked_list, out_idx,    \
+                       err_coef, ymax_sqrt, tau_scale, k, drop, base, n_valid_total, masked_list, n_masked_list,  \
+                       out_idx,                                                                                   \
                        out_dist, fail_rows, fail_count)
     if (ncl <= 1) NABO_RF(1);
     else if (ncl <= 2) NABO_RF(2);

@@ -255,3 +255,25 @@ def test_zero_target_rows_is_a_no_op(gpu_lib):
     Y = pca_like(100, 5, seed=65)
     gi, gd = gpu_lib.knn(np.empty((0, 5)), Y, 3)
     assert gi.shape == (0, 3) and gd.shape == (0, 3)
+
+
+@pytest.mark.parametrize("m,n,g,k,drop", [(257, 4097, 50, 15, False), (1000, 1000, 15, 11, True),
+                                          (2000, 30000, 30, 20, True), (130, 5000, 64, 30, False),
+                                          (64, 3000, 100, 11, False)])
+def test_f16x3_mode_gives_the_same_bits(gpu_lib, m, n, g, k, drop):
+    """Experimental NABO_L2_MODE=f16x3 (f16 split on the matrix pipe as the candidate filter): the
+    float64 refine + certification make it return exactly what the fp32-MFMA path and the oracle do.
+    Shapes outside its instantiation (g > 64 or k + drop > 24) silently use the fp32 kernel."""
+    Y = pca_like(n, g, seed=1000 + n + g)
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
+    os.environ["NABO_L2_MODE"] = "f16x3"
+    try:
+        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, k, drop_first=drop)
+        st = ix.last_stats()
+        ix.close()
+    finally:
+        del os.environ["NABO_L2_MODE"]
+    oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
+    _check(gi, gd, oi, od)
+    assert st["fallback_rows"] == 0
