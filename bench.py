@@ -79,7 +79,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
     m, n, d, k = a.m, a.n, a.d, a.k
-    dev = local_rank if world > 1 else 0
+    backend = os.environ.get("NABO_BENCH_BACKEND", "nccl")     # "gloo": N ranks rehearsed on ONE GPU
+    dev = local_rank if (world > 1 and backend == "nccl") else 0
     lo, hi = shard_bounds(n, world, rank)
     Y = pca_like(n, d, seed=1003)[lo:hi]
     X = pca_like(m, d, seed=2003)
@@ -89,7 +90,10 @@ def main():
         import torch.distributed as dist
         from nabo_amd._dist import ShardedKnn, gpu_callables
         torch.cuda.set_device(dev)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
         tX = torch.from_numpy(X).to("cuda:%d" % dev)
         tY = torch.from_numpy(np.ascontiguousarray(Y)).to("cuda:%d" % dev)
         torch.cuda.synchronize()
@@ -115,6 +119,7 @@ def main():
             return out
 
         def sync():
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
     else:
@@ -136,7 +141,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % dev) if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -146,6 +151,16 @@ def main():
         gd = dD.download((m, k), np.float64)
         assert gi.min() >= 0 and gi.max() < n and (np.diff(gd[:: max(1, m // 4096)], axis=1) >= 0).all()
 
+    if use_dist and os.environ.get("NABO_BENCH_CHECK") == "1":
+        # rehearsal check: the sharded result must equal one unsharded index on the same data
+        full = pca_like(n, d, seed=1003)
+        ref_ix = nabo_amd.KnnIndex(n, d, metric=nabo_amd.EUCLIDEAN, device=dev).set_ref(full)
+        ri, rd = ref_ix.query(X, k)
+        ref_ix.close()
+        oi, od = step()
+        same = bool((oi.cpu().numpy() == ri).all() and (od.cpu().numpy() == rd).all())
+        print("rank %d sharded == unsharded: %s" % (rank, same), flush=True)
+        assert same
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events, kernel's own stream

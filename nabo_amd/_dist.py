@@ -56,6 +56,25 @@ class ShardedKnn:
         self.device = device
         self.world = dist_module.get_world_size() if dist_module.is_initialized() else 1
         self.rank = dist_module.get_rank() if dist_module.is_initialized() else 0
+        # rehearsal mode: device tensors but a CPU-only backend (gloo) -> stage collectives through host
+        self.stage = (dist_module.is_initialized() and dist_module.get_backend() == "gloo"
+                      and str(device).startswith("cuda"))
+
+    def _a2a(self, recv, send):
+        if self.stage:
+            r, s = recv.cpu(), send.cpu()
+            self.dist.all_to_all_single(r, s)
+            recv.copy_(r)
+        else:
+            self.dist.all_to_all_single(recv, send)
+
+    def _gather(self, full, part):
+        if self.stage:
+            f, p = full.cpu(), part.cpu()
+            self.dist.all_gather_into_tensor(f, p)
+            full.copy_(f)
+        else:
+            self.dist.all_gather_into_tensor(full, part)
 
     def query(self, X, m, k, drop_first=False):
         import torch
@@ -75,13 +94,13 @@ class ShardedKnn:
             idx, dst = pi, pd
         recv_i = torch.empty((N, mr, kk), dtype=torch.int64, device=self.device)
         recv_d = torch.empty((N, mr, kk), dtype=torch.float64, device=self.device)
-        self.dist.all_to_all_single(recv_i.view(-1), idx.contiguous().view(-1))
-        self.dist.all_to_all_single(recv_d.view(-1), dst.contiguous().view(-1))
+        self._a2a(recv_i.view(-1), idx.contiguous().view(-1))
+        self._a2a(recv_d.view(-1), dst.contiguous().view(-1))
         oi, od = self.merge(recv_i, recv_d, k, drop_first)
         full_i = torch.empty((m_pad, k), dtype=torch.int64, device=self.device)
         full_d = torch.empty((m_pad, k), dtype=torch.float64, device=self.device)
-        self.dist.all_gather_into_tensor(full_i.view(-1), oi.contiguous().view(-1))
-        self.dist.all_gather_into_tensor(full_d.view(-1), od.contiguous().view(-1))
+        self._gather(full_i.view(-1), oi.contiguous().view(-1))
+        self._gather(full_d.view(-1), od.contiguous().view(-1))
         return full_i[:m], full_d[:m]
 
 

@@ -87,19 +87,34 @@ __global__ __launch_bounds__(256) void canberra_topk_kernel(const double *__rest
             const int64_t row = row0 + t;
             if (row >= m) break;
             const double *x = X + row * g;
-            double dist = 0.0;
+            const double tau_t = tau[t];
+            // Pass 1 (3 float64 ops per dimension): count the in-window dimensions with the reference's
+            // exact test.  Every out-of-window dimension adds exactly 1 and every in-window term is >= 0,
+            // so dist >= g - n_in rigorously (adding ones is exact, rounding is monotone): a pair whose
+            // bound already reaches the row threshold cannot enter the list and skips the divisions.
+            int n_in = 0;
             for (int k = 0; k < g; ++k) {
                 const double xv = x[k], yv = yt[(int64_t)k * 64];
-                const double absx = fabs(xv);
-                const double num = fabs(__dsub_rn(xv, yv));
-                if (num < __dmul_rn(f, absx)) {
-                    const double den = __dadd_rn(__dadd_rn(absx, fabs(yv)), 0.01);
-                    dist = __dadd_rn(dist, __ddiv_rn(num, den));
-                } else {
-                    dist = __dadd_rn(dist, 1.0);
+                n_in += (fabs(__dsub_rn(xv, yv)) < __dmul_rn(f, fabs(xv))) ? 1 : 0;
+            }
+            const bool maybe = valid && ((double)(g - n_in) < tau_t);
+            double dist = __builtin_inf();
+            if (__builtin_amdgcn_ballot_w64(maybe) != 0) {
+                // Pass 2: the reference expression, term by term in its order (nabo/_mapping.py:36-44)
+                dist = 0.0;
+                for (int k = 0; k < g; ++k) {
+                    const double xv = x[k], yv = yt[(int64_t)k * 64];
+                    const double absx = fabs(xv);
+                    const double num = fabs(__dsub_rn(xv, yv));
+                    if (num < __dmul_rn(f, absx)) {
+                        const double den = __dadd_rn(__dadd_rn(absx, fabs(yv)), 0.01);
+                        dist = __dadd_rn(dist, __ddiv_rn(num, den));
+                    } else {
+                        dist = __dadd_rn(dist, 1.0);
+                    }
                 }
             }
-            bool pend = valid && (dist < tau[t]);
+            bool pend = maybe && (dist < tau_t);
             uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
             while (pm != 0) {
                 const int c = cnt[t];

@@ -129,6 +129,8 @@ def run_case(tag):
                 sc = mapping_score(nodes, tnodes, tedges)
                 gs = dict(zip([str(x) for x in g["score_%s_nodes" % tn]], g["score_%s_vals" % tn]))
                 out["t_%s_score_maxerr" % tn] = float(max(abs(sc[n] - gs[n]) for n in gs))
+                sc2 = nabo_amd.get_mapping_score(map_fn, "WT", tn)          # the product's own function
+                out["t_%s_score_api_maxerr" % tn] = float(max(abs(sc2[n] - gs[n]) for n in gs))
         # use_stored_distances: rebuild the graphs from the stored lists only
         with redirect_stdout(buf):
             m2 = nabo_amd.Mapping(map_fn, "WT", ref_fn, "data")
