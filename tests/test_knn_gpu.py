@@ -277,3 +277,30 @@ def test_f16x3_mode_gives_the_same_bits(gpu_lib, m, n, g, k, drop):
     oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
     _check(gi, gd, oi, od)
     assert st["fallback_rows"] == 0
+
+
+def test_tail_round_split_rows_are_exact(gpu_lib):
+    """More target workgroups than resident slots: the last, partially filled round is launched with its
+    own reference split (api.hip "tail round").  Rows of BOTH launches must match the oracle."""
+    m, n = 140000, 20000               # 547 workgroups of 256 rows on 512 slots -> 35-workgroup tail
+    Y = pca_like(n, 50, seed=71)
+    X = pca_like(m, 50, seed=72)
+    ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, 15)
+    st = ix.last_stats()
+    ix.close()
+    assert st["workgroups"] > 547            # the tail really was split
+    rows = np.concatenate([np.arange(0, 300), np.arange(131072 - 150, 131072 + 150), np.arange(m - 300, m)])
+    oi, od = oracle.knn(X[rows], Y, 15, 0, nthreads=8)
+    _check(gi[rows], gd[rows], oi, od)
+    assert (np.diff(gd, axis=1) >= 0).all() and gi.min() >= 0 and gi.max() < n
+
+
+@pytest.mark.parametrize("g,k", [(1, 1), (2, 3), (3, 1)])
+def test_tiny_dimensionality(gpu_lib, g, k):
+    Y = pca_like(700, g, seed=81)
+    X = pca_like(90, g, seed=82)
+    for metric in (0, 1):
+        gi, gd = gpu_lib.knn(X, Y, k, metric=metric)
+        oi, od = oracle.knn(X, Y, k, metric)
+        _check(gi, gd, oi, od)
