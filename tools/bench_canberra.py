@@ -1,13 +1,53 @@
-"""Times the exact mod-Canberra k-NN kernel (diagnostic)."""
-import sys, os, time
+"""Secondary benchmark: the exact mod-Canberra k-NN kernel on one MI355X,
+with the oracle's CPU timing beside it.  Prints one JSON line (same field meanings as bench.py).
+
+    python tools/bench_canberra.py [targets refs dims k]      default 100000 100000 50 15
+
+Roofline: the kernel is float64-VALU bound (compare / add / IEEE divide per dimension; nothing for MFMA).
+Algorithmic work per (pair, dimension) = the reference's 9 float64 operations (nabo/_mapping.py:37-44:
+abs, sub, abs, mul, cmp, abs, add, add, div/add); peak = 39.3e12 float64 VALU instructions/s
+(MI355X: 78.6 TFLOP/s float64 vector, an FMA counting 2).  An IEEE divide expands to ~30 instructions, so the
+executed instruction count is several times the algorithmic one.
+"""
+import json
+import os
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
-import nabo_amd
-from nabo_amd._synth import pca_like
+import numpy as np  # noqa: E402
+
+import nabo_amd  # noqa: E402
+import oracle  # noqa: E402
+from nabo_amd._synth import pca_like  # noqa: E402
+
 m, n, d, k = [int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (100000, 100000, 50, 15))]
-Y = pca_like(n, d, 1003); X = pca_like(m, d, 2003)
+Y = pca_like(n, d, 1003)
+X = pca_like(m, d, 2003)
 ix = nabo_amd.KnnIndex(n, d, metric=nabo_amd.MOD_CANBERRA, dist_factor=0.25).set_ref(Y)
 ix.query(X[:1000], k)
-t0 = time.perf_counter(); gi, gd = ix.query(X, k); dt = time.perf_counter() - t0
+steps = 3
+t0 = time.perf_counter()
+for _ in range(steps):
+    gi, gd = ix.query(X, k)
+dt = (time.perf_counter() - t0) / steps
 st = ix.last_stats()
-print("canberra %dx%dx%d k=%d: %.3f s wall, topk kernel %.1f ms, %.3g pairs/s, splits=%d" % (m, n, d, k, dt, st["ms_topk"], m * n / (st["ms_topk"] * 1e-3), st["splits"]))
+ix.close()
+rows = np.random.default_rng(0).choice(m, 128, replace=False)
+cores = max(1, min(os.cpu_count() or 1, 16))
+t0 = time.perf_counter()
+oi, od = oracle.knn(X[rows], Y, k, oracle.MOD_CANBERRA, 0.25, nthreads=cores)
+tc = time.perf_counter() - t0
+assert np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od), "GPU result differs from the oracle"
+t_k = st["ms_topk"] * 1e-3
+alg_ops = 9.0 * m * n * d
+print(json.dumps({
+    "metric": "cell-pair distances/s (mod-Canberra k-NN, dist_factor 0.25)", "value": m * n / dt,
+    "unit": "cell-pair distances/s", "n_gpus": 1, "ms_per_step": dt * 1e3, "higher_is_better": True,
+    "dtype": "f64", "data": "synthetic",
+    "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, modified Canberra" % (n // 1000, m // 1000, d, k)},
+    "roofline": {"bound": "valu-f64", "achieved": alg_ops / t_k / 1e12, "peak": 39.3, "unit": "T float64 ops/s",
+                 "frac": alg_ops / t_k / 39.3e12, "kernel": "canberra_topk_kernel", "kernel_ms": st["ms_topk"]},
+    "cpu_baseline": {"value": len(rows) * n / tc, "unit": "cell-pair distances/s", "cores": cores, "kind": "port",
+                     "sample": "%d targets x %d refs, d=%d, OpenMP" % (len(rows), n, d)},
+    "parity": "128 sampled rows bit-equal to the oracle (indices and distances)"}))
