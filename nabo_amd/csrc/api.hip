@@ -40,7 +40,8 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef, double ymax_sqrt,
                          double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
-                         unsigned int *fail_count, hipStream_t st);
+                         unsigned int *fail_count, hipStream_t st, int canberra = 0, double cb_f = 0.0,
+                         float cb_plateau = 0.0f);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
                              int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
@@ -55,6 +56,18 @@ hipError_t merge_local_launch(const double *cand_d, const uint32_t *cand_i, int6
                               int64_t base, int64_t *out_idx, double *out_dist, int *n_found, hipStream_t st);
 hipError_t merge_parts_launch(const double *parts_d, const int64_t *parts_i, int n_parts, int64_t m, int kp, int k,
                               int drop, int64_t *out_idx, double *out_dist, hipStream_t st);
+// fp32 lower-bound Canberra filter (canberra_f32.hip) + helpers (refine.hip)
+hipError_t cbf_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, float *xq, unsigned int *flag,
+                                   hipStream_t st);
+hipError_t cbf_pack_refs_launch(const double *Y, int64_t n, int g, int gp, float *ycf, unsigned int *flag,
+                                hipStream_t st);
+int cbf_pick_gp(int g);
+void cbf_constants(int g, float *slack, float *plateau);
+hipError_t cbf_filter_launch(int gp, int epl, const float *xq, int64_t m, const float *ycf, int64_t n, int g,
+                             const uint8_t *mask, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st);
+hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
+hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
+                               int64_t *out_idx, double *out_dist, hipStream_t st);
 hipError_t snn_counts_launch(const int64_t *t_idx, int64_t m, const int64_t *r_idx, int64_t n, int k, int32_t *out,
                              hipStream_t st);
 }  // namespace nabo
@@ -159,10 +172,13 @@ struct nabo_index {
     bool packed_f32 = false, packed_f16 = false;
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
     double ymax_sqrt = 0.0, ymax_sqrt_h = 0.0;
-    // Canberra path
-    DevBuf yt;
+    // Canberra path: exact kernel operands (yt) and the fp32 lower-bound filter's (ycf)
+    DevBuf yt, ycf, cbflag;
+    int cb_gp = 0;
+    bool cb_f32 = false;          // filter usable for these references (fits fp32, g <= 128)
 
     // query workspace
+    DevBuf xfail, tmpi, tmpd;
     DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_idx2, cand_tau2, cand_d, fails, failcnt, oidx, odist, nfound;
     int n_cu = 256;
 
@@ -275,7 +291,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->cbflag, &ix->xfail, &ix->tmpi, &ix->tmpd,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -332,6 +348,19 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         const int64_t chunks = (ix->n + 63) / 64;
         if ((rc = ix->yt.reserve((size_t)chunks * 64 * ix->g * sizeof(double)))) return rc;
         HIP_TRY(nabo::transpose_ref_launch(ix->dY, ix->n, ix->g, ix->yt.as<double>(), st));
+        ix->cb_gp = nabo::cbf_pick_gp(ix->g);
+        ix->cb_f32 = false;
+        const char *cm = getenv("NABO_CANBERRA_MODE");
+        if (ix->cb_gp > 0 && !(cm && strcmp(cm, "exact") == 0)) {
+            unsigned int flag = 0;
+            if ((rc = ix->ycf.reserve((size_t)chunks * 64 * ix->cb_gp * sizeof(float)))) return rc;
+            if ((rc = ix->cbflag.reserve(4 * sizeof(unsigned int)))) return rc;
+            HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
+            HIP_TRY(nabo::cbf_pack_refs_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->ycf.as<float>(), ix->cbflag.as<unsigned int>(), st));
+            HIP_TRY(hipMemcpyAsync(&flag, ix->cbflag.p, sizeof(flag), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            ix->cb_f32 = (flag == 0);
+        }
         HIP_TRY(hipStreamSynchronize(st));
     }
     ix->have_ref = true;
@@ -520,19 +549,73 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         }
         if (S > 16) S = 16;
         if (S < 1) S = 1;
-        if ((rc = ix->cand_d.reserve((size_t)m * S * L * sizeof(double)))) return rc;
-        if ((rc = ix->cand_idx.reserve((size_t)m * S * L * sizeof(uint32_t)))) return rc;
-        HIP_TRY(hipEventRecord(ix->ev[1], st));
-        HIP_TRY(nabo::canberra_topk_launch(epl, dX, m, ix->yt.as<double>(), ix->n, g, ix->f, ix->dmask, S,
-                                           ix->cand_d.as<double>(), ix->cand_idx.as<uint32_t>(), st));
-        HIP_TRY(hipEventRecord(ix->ev[2], st));
-        HIP_TRY(nabo::merge_local_launch(ix->cand_d.as<double>(), ix->cand_idx.as<uint32_t>(), m, S * L, k, drop,
-                                         ix->base, d_oidx, d_odist, nullptr, st));
-        HIP_TRY(hipEventRecord(ix->ev[3], st));
-        if (n_valid < kk)
-            HIP_TRY(nabo::masked_tail_launch(dX, m, ix->dY, g, ix->metric, ix->f, ix->mlistbuf.as<uint32_t>(),
-                                             ix->n_masked_list, (int)n_valid, k, drop, ix->base, d_oidx, d_odist, st));
-        HIP_TRY(hipEventRecord(ix->ev[4], st));
+        bool done = false;
+        if (ix->cb_f32 && n_valid >= kk) {
+            // fp32 lower-bound filter -> float64 refine + certification -> exact re-solve of uncertified rows
+            float slack, plateau;
+            nabo::cbf_constants(g, &slack, &plateau);
+            if ((rc = ix->xpk.reserve((size_t)m * ix->cb_gp * 2 * sizeof(float)))) return rc;
+            if ((rc = ix->cand_idx.reserve((size_t)m * S * L * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->cand_tau.reserve((size_t)m * S * sizeof(float)))) return rc;
+            if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
+            HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
+            unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();
+            HIP_TRY(nabo::cbf_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->xpk.as<float>(), d_flag, st));
+            HIP_TRY(hipEventRecord(ix->ev[1], st));
+            HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), m, ix->ycf.as<float>(), ix->n, g,
+                                            ix->dmask, S, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), st));
+            HIP_TRY(hipEventRecord(ix->ev[2], st));
+            HIP_TRY(nabo::refine_launch(dX, 0, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
+                                        nullptr, 0.0, 0.0, 1.0, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
+                                        ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(), d_failcnt, st, 1,
+                                        ix->f, plateau));
+            HIP_TRY(hipEventRecord(ix->ev[3], st));
+            unsigned int hf[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(hf, ix->cbflag.p, sizeof(hf), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (hf[0] == 0) {                    // targets fit fp32: results stand, re-solve uncertified rows
+                n_fail = hf[1];
+                if (n_fail > 0) {
+                    const int64_t nf = n_fail;
+                    int S3 = 1;
+                    const int64_t gx3 = (nf + 63) / 64;
+                    if (gx3 < 512) {
+                        S3 = (int)((1024 + gx3 - 1) / gx3);
+                        if (S3 > n_chunks) S3 = (int)n_chunks;
+                        if (S3 > 16) S3 = 16;
+                    }
+                    if ((rc = ix->xfail.reserve((size_t)nf * g * sizeof(double)))) return rc;
+                    if ((rc = ix->cand_d.reserve((size_t)nf * S3 * L * sizeof(double)))) return rc;
+                    if ((rc = ix->cand_idx2.reserve((size_t)nf * S3 * L * sizeof(uint32_t)))) return rc;
+                    if ((rc = ix->tmpi.reserve((size_t)nf * k * sizeof(int64_t)))) return rc;
+                    if ((rc = ix->tmpd.reserve((size_t)nf * k * sizeof(double)))) return rc;
+                    HIP_TRY(nabo::gather_rows_launch(dX, ix->fails.as<uint32_t>(), nf, g, ix->xfail.as<double>(), st));
+                    HIP_TRY(nabo::canberra_topk_launch(epl, ix->xfail.as<double>(), nf, ix->yt.as<double>(), ix->n, g, ix->f,
+                                                       ix->dmask, S3, ix->cand_d.as<double>(), ix->cand_idx2.as<uint32_t>(), st));
+                    HIP_TRY(nabo::merge_local_launch(ix->cand_d.as<double>(), ix->cand_idx2.as<uint32_t>(), nf, S3 * L, k, drop,
+                                                     ix->base, ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), nullptr, st));
+                    HIP_TRY(nabo::scatter_rows_launch(ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), ix->fails.as<uint32_t>(), nf,
+                                                      k, d_oidx, d_odist, st));
+                }
+                HIP_TRY(hipEventRecord(ix->ev[4], st));
+                done = true;
+            }
+        }
+        if (!done) {
+            if ((rc = ix->cand_d.reserve((size_t)m * S * L * sizeof(double)))) return rc;
+            if ((rc = ix->cand_idx.reserve((size_t)m * S * L * sizeof(uint32_t)))) return rc;
+            HIP_TRY(hipEventRecord(ix->ev[1], st));
+            HIP_TRY(nabo::canberra_topk_launch(epl, dX, m, ix->yt.as<double>(), ix->n, g, ix->f, ix->dmask, S,
+                                               ix->cand_d.as<double>(), ix->cand_idx.as<uint32_t>(), st));
+            HIP_TRY(hipEventRecord(ix->ev[2], st));
+            HIP_TRY(nabo::merge_local_launch(ix->cand_d.as<double>(), ix->cand_idx.as<uint32_t>(), m, S * L, k, drop,
+                                             ix->base, d_oidx, d_odist, nullptr, st));
+            HIP_TRY(hipEventRecord(ix->ev[3], st));
+            if (n_valid < kk)
+                HIP_TRY(nabo::masked_tail_launch(dX, m, ix->dY, g, ix->metric, ix->f, ix->mlistbuf.as<uint32_t>(),
+                                                 ix->n_masked_list, (int)n_valid, k, drop, ix->base, d_oidx, d_odist, st));
+            HIP_TRY(hipEventRecord(ix->ev[4], st));
+        }
         n_wg = gx * S;
     }
     if (!out_on_device) {

@@ -83,14 +83,21 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 }
 
 // One wave per target row; NCL = ceil(S*L/64) candidates per lane.
-template <int NCL>
+// CANB = false: Euclidean candidates from the fp32 / f16x3 score filter, certified with the
+//               rounding-error bound E (header comment).
+// CANB = true : modified-Canberra candidates from the fp32 LOWER-BOUND filter (canberra_f32.hip):
+//               every non-candidate has exact distance >= tau, so the row is certified when
+//               tau > d_(k') strictly, or when tau is the all-dimensions-out-of-window plateau (then
+//               every non-candidate is at distance exactly g and carries a larger index than the kept
+//               plateau entries of its split).
+template <int NCL, bool CANB>
 __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                      const double *__restrict__ Y, int g,
                                                      const uint32_t *__restrict__ cand_idx,
                                                      const float *__restrict__ cand_tau, int S, int L,
                                                      const double *__restrict__ xnorm, double err_coef,
-                                                     double ymax_sqrt, double tau_scale, int k, int drop, int64_t base,
-                                                     int64_t n_valid_total,
+                                                     double ymax_sqrt, double tau_scale, double cb_f, float cb_plateau,
+                                                     int k, int drop, int64_t base, int64_t n_valid_total,
                                                      const uint32_t *__restrict__ masked_list, int n_masked_list,
                                                      int64_t *__restrict__ out_idx, double *__restrict__ out_dist,
                                                      uint32_t *__restrict__ fail_rows,
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             const uint32_t j = cand_idx[lrow * ncand + e];
             if (j != 0xFFFFFFFFu) {
                 val[r] = j;
-                key[r] = euclid_exact(x, Y + (int64_t)j * g, g);
+                key[r] = CANB ? canberra_exact(x, Y + (int64_t)j * g, g, cb_f) : euclid_exact(x, Y + (int64_t)j * g, g);
             }
         }
     }
@@ -138,7 +145,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
 #pragma unroll
         for (int r = 0; r < NCL; ++r)
             if ((e >> 6) == r) dk = __shfl(key[r], e & 63, 64);
-        if (tmin != __builtin_inff()) {
+        if (CANB) {
+            if (tmin != __builtin_inff()) certified = ((double)tmin > dk) || (tmin == cb_plateau);
+        } else if (tmin != __builtin_inff()) {
             const double sx = sqrt(xnorm[row]);
             const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
             const double bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);   // tau in score units
@@ -164,7 +173,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             od[o] = key[r];
         }
     }
-    if (nreal < kk) emit_masked_tail(x, Y, g, 0, 0.0, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
+    if (nreal < kk)
+        emit_masked_tail(x, Y, g, CANB ? 1 : 0, cb_f, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
 }
 
 // Exact brute force for flagged rows: one 256-thread block per row, k' selection passes over
@@ -251,6 +261,42 @@ hipError_t masked_tail_launch(const double *X, int64_t m, const double *Y, int g
     return hipGetLastError();
 }
 
+// Uncertified rows are re-solved as one dense batch: gather their float64 rows, scatter the answers.
+__global__ void gather_rows_kernel(const double *__restrict__ X, const uint32_t *__restrict__ rows, int64_t nrows, int g,
+                                   double *__restrict__ out)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nrows * g) return;
+    out[e] = X[(int64_t)rows[e / g] * g + e % g];
+}
+
+__global__ void scatter_rows_kernel(const int64_t *__restrict__ si, const double *__restrict__ sd,
+                                    const uint32_t *__restrict__ rows, int64_t nrows, int k,
+                                    int64_t *__restrict__ out_idx, double *__restrict__ out_dist)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nrows * k) return;
+    const int64_t o = (int64_t)rows[e / k] * k + e % k;
+    out_idx[o] = si[e];
+    out_dist[o] = sd[e];
+}
+
+hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st)
+{
+    if (nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nrows * g + 255) / 256)), dim3(256), 0, st, X, rows, nrows, g, out);
+    return hipGetLastError();
+}
+
+hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
+                               int64_t *out_idx, double *out_dist, hipStream_t st)
+{
+    if (nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((nrows * k + 255) / 256)), dim3(256), 0, st, si, sd, rows, nrows,
+                       k, out_idx, out_dist);
+    return hipGetLastError();
+}
+
 hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t n, int g, int metric, double f,
                            double *D, hipStream_t st)
 {
@@ -263,20 +309,28 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                          double ymax_sqrt, double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total,
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
-                         uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st)
+                         uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st, int canberra = 0,
+                         double cb_f = 0.0, float cb_plateau = 0.0f)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
 #define NABO_RF(N)                                                                                               \
-    hipLaunchKernelGGL((refine_kernel<N>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, L, xnorm, \
-                       err_coef, ymax_sqrt, tau_scale, k, drop, base, n_valid_total, masked_list, n_masked_list,  \
-                       out_idx,                                                                                   \
-                       out_dist, fail_rows, fail_count)
+    do {                                                                                                         \
+        if (canberra)                                                                                            \
+            hipLaunchKernelGGL((refine_kernel<N, true>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
+                               L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
+                               n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
+        else                                                                                                     \
+            hipLaunchKernelGGL((refine_kernel<N, false>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
+                               L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
+                               n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
+    } while (0)
     if (ncl <= 1) NABO_RF(1);
     else if (ncl <= 2) NABO_RF(2);
     else if (ncl <= 4) NABO_RF(4);
     else if (ncl <= 8) NABO_RF(8);
+    else if (ncl <= 16) NABO_RF(16);
     else return hipErrorInvalidValue;
 #undef NABO_RF
     return hipGetLastError();

@@ -304,3 +304,46 @@ def test_tiny_dimensionality(gpu_lib, g, k):
         gi, gd = gpu_lib.knn(X, Y, k, metric=metric)
         oi, od = oracle.knn(X, Y, k, metric)
         _check(gi, gd, oi, od)
+
+
+def test_canberra_filter_path_stress(gpu_lib):
+    """The fp32 lower-bound filter + float64 refine + exact re-solve of uncertified rows must equal the
+    exact kernel (NABO_CANBERRA_MODE=exact) and the oracle on adversarial inputs: dist_factor > 1,
+    values near the window boundary, tiny and huge magnitudes, exact duplicates, plateau ties."""
+    rng = np.random.default_rng(17)
+    cases = []
+    Y = pca_like(6000, 24, seed=91); X = pca_like(400, 24, seed=92)
+    cases.append(("plain", X, Y, 0.25))
+    cases.append(("f>1", X, Y, 2.5))
+    cases.append(("f tiny", X, Y, 1e-3))
+    Yb = Y.copy(); Xb = X.copy()
+    Yb[:, :8] = Xb[rng.integers(0, 400, 6000), :8] * (1 + 0.25 * rng.choice([-1, 1], (6000, 8)) * (1 + rng.uniform(-1e-7, 1e-7, (6000, 8))))
+    cases.append(("boundary", Xb, Yb, 0.25))             # |x-y| ~ f|x| to 1e-7: borderline window tests
+    cases.append(("scaled 1e-30", X * 1e-30, Y * 1e-30, 0.25))
+    cases.append(("scaled 1e+20", X * 1e20, Y * 1e20, 0.25))
+    Yd = Y.copy(); Yd[100:160] = Yd[100]
+    cases.append(("duplicates", np.vstack([Yd[100:102], X[:50]]), Yd, 0.25))
+    cases.append(("far apart", rng.standard_normal((80, 24)) * 0.01, rng.standard_normal((3000, 24)) * 100, 0.25))
+    Xz = X.copy(); Xz[:, ::3] = 0.0
+    cases.append(("zeros in x", Xz, Y, 0.25))
+    for name, Xc, Yc, f in cases:
+        gi, gd = gpu_lib.knn(Xc, Yc, 15, metric=1, dist_factor=f)
+        oi, od = oracle.knn(Xc, Yc, 15, 1, f, nthreads=8)
+        assert np.array_equal(gi, oi), name
+        assert np.array_equal(gd, od), name
+    # magnitudes beyond fp32: the pack kernels flag it and the exact kernel answers
+    gi, gd = gpu_lib.knn(X * 1e60, Y * 1e60, 7, metric=1)
+    oi, od = oracle.knn(X * 1e60, Y * 1e60, 7, 1, 0.25, nthreads=8)
+    _check(gi, gd, oi, od)
+
+
+def test_canberra_filter_equals_exact_kernel(gpu_lib):
+    Y = pca_like(20000, 50, seed=93); X = pca_like(3000, 50, seed=94)
+    mask = np.zeros(20000, np.uint8); mask[::7] = 1
+    a = gpu_lib.knn(X, Y, 20, metric=1, dist_factor=0.25, ref_mask=mask, drop_first=True)
+    os.environ["NABO_CANBERRA_MODE"] = "exact"
+    try:
+        b = gpu_lib.knn(X, Y, 20, metric=1, dist_factor=0.25, ref_mask=mask, drop_first=True)
+    finally:
+        del os.environ["NABO_CANBERRA_MODE"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
