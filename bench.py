@@ -109,8 +109,10 @@ def main():
     stats = []
 
     if use_dist:
-        lk, mg = gpu_callables(index, dev)
-        sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev))
+        lk, mg, lc = gpu_callables(index, dev)
+        if os.environ.get("NABO_DIST_LOCAL_CERT") == "1":      # A/B: every shard certifies its own top-k'
+            lc = None
+        sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev), local_cand=lc)
 
         def step():
             index.set_ref(y_device_ptr=y_ptr)

@@ -91,6 +91,16 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
                      int32_t k, int32_t drop_first,
                      int64_t *out_idx, double *out_dist, int32_t out_on_device);
 
+/* Shard mode (reference rows sharded over GPUs with GLOBAL certification, nabo_amd/_dist.py): the first
+ * n_cand (<= 32) entries of the shard's order rows WITHOUT a local verdict -- out_idx [m,n_cand] (global
+ * indices, -1 = absent), out_dist [m,n_cand] (exact float64, +inf = absent) -- and out_bound [m]: a lower
+ * bound on the exact SQUARED distance of every reference of this shard that is not in the emitted list
+ * (+inf: nothing else exists; -inf: unknown, the caller must fall back to nabo_index_query).  Euclidean
+ * only, device pointers for the three outputs.  A merged k'-th distance d with d^2 < min over shards of
+ * out_bound is the exact global k'-th distance. */
+int nabo_index_query_candidates(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m,
+                                int32_t n_cand, int64_t *out_idx, double *out_dist, double *out_bound);
+
 /* HIP-event timings (ms) and counters of the LAST nabo_index_query on this index.
  * ms[0] pack targets, ms[1] distance+top-k kernel (the dominant kernel), ms[2] float64
  * refine, ms[3] exact fallback for guard-flagged rows, ms[4] total on-stream.

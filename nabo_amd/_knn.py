@@ -95,6 +95,11 @@ class KnnIndex:
         _lib.check(_lib.lib().nabo_index_query(self._h, int(x_ptr), 1, int(m), int(k), int(bool(drop_first)),
                                                int(out_idx_ptr), int(out_dist_ptr), 1))
 
+    def query_candidates_device(self, x_ptr, m, n_cand, out_idx_ptr, out_dist_ptr, out_bound_ptr):
+        """Shard mode: first n_cand order-row entries + the bound on everything else (device pointers)."""
+        _lib.check(_lib.lib().nabo_index_query_candidates(self._h, int(x_ptr), 1, int(m), int(n_cand),
+                                                          int(out_idx_ptr), int(out_dist_ptr), int(out_bound_ptr)))
+
     def last_stats(self):
         ms = (C.c_double * 5)()
         cn = (C.c_int64 * 4)()

@@ -42,6 +42,10 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
                          unsigned int *fail_count, hipStream_t st, int canberra = 0, double cb_f = 0.0,
                          float cb_plateau = 0.0f);
+hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
+                              const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
+                              double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
+                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
                              int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
@@ -367,8 +371,10 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
     return NABO_OK;
 }
 
-int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k,
-                     int32_t drop_first, int64_t *out_idx, double *out_dist, int32_t out_on_device)
+// cand_mode: shard mode of nabo_index_query_candidates -- k is the number of candidates per row to emit,
+// out_bound [m] receives the squared-distance bound of everything not emitted; no local certification.
+static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k, int32_t drop_first,
+                      int64_t *out_idx, double *out_dist, int32_t out_on_device, bool cand_mode, double *out_bound)
 {
     if (!ix || !X || !out_idx || !out_dist) return fail(NABO_E_INVALID, "NULL argument");
     if (!ix->have_ref) return fail(NABO_E_INVALID, "nabo_index_set_ref has not been called");
@@ -377,7 +383,10 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
     const int drop = drop_first ? 1 : 0;
     const int kk = k + drop;
     if (k < 1) return fail(NABO_E_INVALID, "k=%d must be >= 1", k);
-    if (kk > ix->n) return fail(NABO_E_INVALID, "k + drop_first = %d exceeds the %lld references", kk, (long long)ix->n);
+    if (kk > ix->n && !cand_mode)
+        return fail(NABO_E_INVALID, "k + drop_first = %d exceeds the %lld references", kk, (long long)ix->n);
+    if (cand_mode && (ix->metric != NABO_METRIC_EUCLIDEAN || !out_bound || !out_on_device || k > 32))
+        return fail(NABO_E_INVALID, "candidate mode: Euclidean metric, device outputs, <= 32 candidates");
     if (kk > NABO_MAX_K) return fail(NABO_E_UNSUPPORTED, "k + drop_first = %d exceeds NABO_MAX_K=%d", kk, NABO_MAX_K);
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -402,7 +411,7 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         d_oidx = ix->oidx.as<int64_t>();
         d_odist = ix->odist.as<double>();
     }
-    const int epl = kk <= 24 ? 1 : 2;
+    const int epl = (kk <= 24 || cand_mode) ? 1 : 2;
     const int L = 32 * epl;
     unsigned int n_fail = 0;
     int S = 1;
@@ -414,7 +423,7 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         bool use_h = false;
         if (ix->mode == 1 && epl == 1) {
             nabo::l2h_topk_geometry(ix->ks16, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            use_h = kk + 4 <= lkeep_max;            // needs at least 4 entries of slack
+            use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
         if (!use_h) {
             lkeep_max = L;
@@ -428,6 +437,7 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         // kept-list length: k' + 8 slack (the certification needs a gap above the k'-th distance)
         int lkeep = kk + 8;
         if (lkeep < 16) lkeep = 16;
+        if (cand_mode) lkeep = kk < 4 ? 4 : kk;
         if (lkeep > lkeep_max) lkeep = lkeep_max;
         { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }   // experiments
         // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
@@ -517,6 +527,31 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
         const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0;
         const double ymax_sqrt = use_h ? ix->ymax_sqrt_h : ix->ymax_sqrt;
         const int64_t m_main = rows_main < m ? rows_main : m;
+        if (cand_mode) {
+            HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(),
+                                             S, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
+                                             n_valid, d_oidx, d_odist, out_bound, st));
+            if (gx_tail > 0)
+                HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
+                                                 ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
+                                                 ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st));
+            HIP_TRY(hipEventRecord(ix->ev[3], st));
+            HIP_TRY(hipEventRecord(ix->ev[4], st));
+            HIP_TRY(hipEventRecord(ix->ev[5], st));
+            HIP_TRY(hipStreamSynchronize(st));
+            float tt = 0;
+            for (int i = 0; i < 4; ++i) {
+                HIP_TRY(hipEventElapsedTime(&tt, ix->ev[i], ix->ev[i + 1]));
+                ix->ms[i] = tt;
+            }
+            HIP_TRY(hipEventElapsedTime(&tt, ix->ev[0], ix->ev[5]));
+            ix->ms[4] = tt;
+            ix->counters[0] = 0;
+            ix->counters[1] = S;
+            ix->counters[2] = L;
+            ix->counters[3] = gx_main * S + gx_tail * S2;
+            return NABO_OK;
+        }
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
@@ -636,6 +671,18 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
     ix->counters[2] = L;
     ix->counters[3] = n_wg;
     return NABO_OK;
+}
+
+int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k,
+                     int32_t drop_first, int64_t *out_idx, double *out_dist, int32_t out_on_device)
+{
+    return query_impl(ix, X, x_on_device, m, k, drop_first, out_idx, out_dist, out_on_device, false, nullptr);
+}
+
+int nabo_index_query_candidates(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t n_cand,
+                                int64_t *out_idx, double *out_dist, double *out_bound)
+{
+    return query_impl(ix, X, x_on_device, m, n_cand, 0, out_idx, out_dist, 1, true, out_bound);
 }
 
 int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4])

@@ -177,6 +177,78 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         emit_masked_tail(x, Y, g, CANB ? 1 : 0, cb_f, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
 }
 
+// Shard mode (reference rows sharded over GPUs, global certification -- nabo_amd/_dist.py): no local
+// verdict.  Emits the row's candidates in exact float64 order (first `kout`, absent = idx -1 / +inf) and
+// `bound`, a lower bound on the exact SQUARED distance of every reference of this shard that is NOT among
+// the emitted candidates: min over splits of (tau * scale + ||x~||^2 - E), and additionally the squared
+// distance of the first candidate that did not fit into `kout`.  +inf when nothing was dropped, -inf when
+// the filter saw non-finite scores (forces the exact second phase).
+template <int NCL>
+__global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
+                                                          const double *__restrict__ Y, int g,
+                                                          const uint32_t *__restrict__ cand_idx,
+                                                          const float *__restrict__ cand_tau, int S, int L,
+                                                          const double *__restrict__ xnorm, double err_coef,
+                                                          double ymax_sqrt, double tau_scale, int kout, int64_t base,
+                                                          int64_t n_valid_total, int64_t *__restrict__ out_idx,
+                                                          double *__restrict__ out_dist, double *__restrict__ out_bound)
+{
+    const int lane = lane_id();
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = row0 + lrow;
+    if (row >= m) return;
+    const double *x = X + row * g;
+    const int ncand = S * L;
+    double key[NCL];
+    uint32_t val[NCL];
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) {
+        const int e = r * 64 + lane;
+        key[r] = __builtin_inf();
+        val[r] = 0xFFFFFFFFu;
+        if (e < ncand) {
+            const uint32_t j = cand_idx[lrow * ncand + e];
+            if (j != 0xFFFFFFFFu) {
+                val[r] = j;
+                key[r] = euclid_exact(x, Y + (int64_t)j * g, g);
+            }
+        }
+    }
+    wave_bitonic_sort<NCL, double>(key, val);
+    int nreal = 0;
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) nreal += __popcll(__builtin_amdgcn_ballot_w64(val[r] != 0xFFFFFFFFu));
+    float tmin = __builtin_inff();
+    for (int s = lane; s < S; s += 64) tmin = fminf(tmin, cand_tau[lrow * S + s]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+    double bound = __builtin_inf();
+    if (tmin != __builtin_inff()) {
+        const double sx = sqrt(xnorm[row]);
+        const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
+        bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);
+    } else if ((int64_t)nreal < n_valid_total) {
+        bound = -__builtin_inf();          // nothing "dropped" yet references are missing: non-finite scores
+    }
+    if (nreal > kout) {                    // candidates beyond kout are not reported either
+        double dn = 0.0;
+#pragma unroll
+        for (int r = 0; r < NCL; ++r)
+            if ((kout >> 6) == r) dn = __shfl(key[r], kout & 63, 64);
+        bound = fmin(bound, dn * dn * (1.0 - 1e-12));
+    }
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) {
+        const int e = r * 64 + lane;
+        if (e < kout) {
+            const bool real = e < nreal;
+            out_idx[row * kout + e] = real ? base + (int64_t)val[r] : -1;
+            out_dist[row * kout + e] = real ? key[r] : __builtin_inf();
+        }
+    }
+    if (lane == 0) out_bound[row] = bound;
+}
+
 // Exact brute force for flagged rows: one 256-thread block per row, k' selection passes over
 // all references (each pass picks the smallest (d, j) strictly after the previous pick).
 __global__ __launch_bounds__(256) void exact_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
@@ -333,6 +405,26 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
     else if (ncl <= 16) NABO_RF(16);
     else return hipErrorInvalidValue;
 #undef NABO_RF
+    return hipGetLastError();
+}
+
+hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
+                              const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
+                              double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
+                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st)
+{
+    const int ncl = (S * L + 63) / 64;
+    if (m <= row0) return hipSuccess;
+    dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
+#define NABO_RC(N)                                                                                                  \
+    hipLaunchKernelGGL((refine_cand_kernel<N>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, L, xnorm, \
+                       err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx, out_dist, out_bound)
+    if (ncl <= 1) NABO_RC(1);
+    else if (ncl <= 2) NABO_RC(2);
+    else if (ncl <= 4) NABO_RC(4);
+    else if (ncl <= 8) NABO_RC(8);
+    else return hipErrorInvalidValue;
+#undef NABO_RC
     return hipGetLastError();
 }
 

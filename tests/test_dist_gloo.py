@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir):
+def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir, certified=False, sorted_refs=False):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -33,7 +33,23 @@ def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     Y = pca_like(n, g, seed=11)
     X = pca_like(m, g, seed=12)
+    if sorted_refs:                 # neighbours concentrate in one shard: forces the second (exact) round
+        Y = Y[np.argsort(Y[:, 0])]
     lo, hi = shard_bounds(n, world, rank)
+
+    def local_cand(Xt, ncand):
+        """What nabo_index_query_candidates returns, stated with the oracle: the shard's first ncand
+        order-row entries and (as the bound) the squared distance of the next one."""
+        kq = min(ncand + 1, hi - lo)
+        i, d = oracle.knn(Xt.numpy(), Y[lo:hi], kq, 0)
+        mm = i.shape[0]
+        oi = np.full((mm, ncand), -1, dtype=np.int64)
+        od = np.full((mm, ncand), np.inf)
+        take = min(ncand, kq)
+        oi[:, :take] = i[:, :take] + lo
+        od[:, :take] = d[:, :take]
+        ob = d[:, ncand] ** 2 if kq > ncand else np.full(mm, np.inf)
+        return torch.from_numpy(oi), torch.from_numpy(od), torch.from_numpy(np.ascontiguousarray(ob))
 
     def local_knn(Xt, kk):
         i, d = oracle.knn(Xt.numpy(), Y[lo:hi], kk, metric)
@@ -43,27 +59,39 @@ def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir):
         i, d = merge_numpy(pi.numpy(), pd.numpy(), kq, dropq)
         return torch.from_numpy(i), torch.from_numpy(d)
 
-    sk = ShardedKnn(dist, local_knn, merge, torch.device("cpu"))
+    sk = ShardedKnn(dist, local_knn, merge, torch.device("cpu"), local_cand=local_cand if certified else None)
     oi, od = sk.query(torch.from_numpy(X), m, k, drop)
-    np.savez(os.path.join(out_dir, "r%d.npz" % rank), idx=oi.numpy(), dist=od.numpy())
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), idx=oi.numpy(), dist=od.numpy(), unc=sk.last_uncertified)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,m,n,drop,metric", [(2, 101, 600, False, 0), (2, 64, 501, True, 0), (3, 50, 400, False, 1)])
-def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric):
+@pytest.mark.parametrize("world,m,n,drop,metric,certified,sorted_refs", [
+    (2, 101, 600, False, 0, False, False), (2, 64, 501, True, 0, False, False), (3, 50, 400, False, 1, False, False),
+    (2, 101, 600, True, 0, True, False),        # global certification, ragged m, positional drop
+    (3, 77, 900, False, 0, True, False),
+    (3, 60, 900, False, 0, True, True),         # one shard holds the neighbours -> second round
+])
+def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric, certified, sorted_refs):
     import torch.multiprocessing as mp
     import oracle
     from nabo_amd._synth import pca_like
     g, k = 12, 7
+    if certified:
+        k = 15
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, m, n, g, k, drop, metric, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, m, n, g, k, drop, metric, str(tmp_path), certified, sorted_refs),
+             nprocs=world, join=True)
     Y = pca_like(n, g, seed=11)
+    if sorted_refs:
+        Y = Y[np.argsort(Y[:, 0])]
     X = pca_like(m, g, seed=12)
     oi, od = oracle.knn(X, Y, k, metric, drop_first=drop)
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), "r%d.npz" % r))
         assert np.array_equal(z["idx"], oi) and np.array_equal(z["dist"], od)
+        if sorted_refs:
+            assert int(z["unc"]) > 0         # the exact second round really ran
 
 
 def test_shard_bounds_cover_everything():

@@ -193,6 +193,39 @@ def test_resident_index_shard_base_and_merge(gpu_lib):
     _check(gi, gd, oi, od)
 
 
+def test_shard_candidates_and_their_bound(gpu_lib):
+    """nabo_index_query_candidates: the emitted list is the exact head of the shard's order row and the
+    bound is a true lower bound on the squared distance of everything not emitted (global certification)."""
+    from nabo_amd import _knn
+    n, g, m = 6001, 30, 513
+    Y = pca_like(n, g, seed=43)
+    X = pca_like(m, g, seed=44)
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[::7] = 1
+    full_i, full_d = oracle.knn(X, Y, 40, 0, ref_mask=mask, nthreads=8)
+    ix = gpu_lib.KnnIndex(n, g, metric=0, ref_index_base=1000).set_ref(Y, ref_mask=mask)
+    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
+    for nc in (1, 9, 16, 32):
+        di, dd, db = _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * 8)
+        ix.query_candidates_device(dx.ptr, m, nc, di.ptr, dd.ptr, db.ptr)
+        ci, cd, cb = di.download((m, nc), np.int64), dd.download((m, nc), np.float64), db.download((m,), np.float64)
+        have = ci >= 0
+        # whatever is emitted is the exact prefix, in canonical order, with exact float64 distances
+        assert np.array_equal(np.where(have, ci - 1000, -1), np.where(have, full_i[:, :nc], -1))
+        assert np.array_equal(np.where(have, cd, 0.0), np.where(have, full_d[:, :nc], 0.0))
+        assert np.all(np.isinf(cd[~have]))
+        assert have[:, 0].all() or nc == 1
+        # bound: every reference not emitted is at squared distance >= bound (or the bound says "unknown")
+        cnt = have.sum(1)
+        nxt = full_d[np.arange(m), np.minimum(cnt, 39)] ** 2
+        known = np.isfinite(cb)
+        assert known.mean() > 0.95
+        assert np.all(cb[known] <= nxt[known] * (1 + 1e-12))
+        assert np.all(cb[known] > 0)
+        assert not np.any(cb == np.inf)          # n - masked > n_cand here: something else always exists
+    ix.close()
+
+
 def test_snn_counts_kernel_vs_oracle(gpu_lib):
     Y = pca_like(2000, 20, seed=51)
     idx, _ = oracle.knn(Y, Y, 11, 0, drop_first=True, nthreads=8)
