@@ -25,7 +25,7 @@ import numpy as np
 from . import _knn
 from ._lib import EUCLIDEAN, MOD_CANBERRA
 
-__all__ = ["Mapping"]
+__all__ = ["Mapping", "write_dense_pca"]
 
 _COL_IDX, _COL_DIST, _COL_CELLS = "__knn_idx", "__knn_dist", "__knn_cells"
 
@@ -43,20 +43,85 @@ def _uid(n=30):
     return "".join(random.choice(string.ascii_lowercase) for _ in range(n))
 
 
+_DENSE_MAT, _DENSE_CELLS = "__pca_matrix", "__pca_cells"
+
+
+def write_dense_pca(fn, grp, cells, Z):
+    """Dense input layout: one [N, n_comps] float64 matrix + the cell names, in
+    place of the one-dataset-per-cell group `Dataset.transform_pca` writes (nabo/_dataset.py:1028).
+    `Mapping` reads either; cells are still taken in name order, so results do not depend on the layout."""
+    h5py = _h5py()
+    Z = np.ascontiguousarray(Z, dtype=np.float64)
+    if Z.ndim != 2 or Z.shape[0] != len(cells):
+        raise ValueError("ERROR: Z must be [len(cells), n_comps]")
+    with h5py.File(fn, mode="a") as h5:
+        if grp in h5:
+            del h5[grp]
+        g = h5.create_group(grp)
+        g.create_dataset(_DENSE_MAT, data=Z)
+        g.create_dataset(_DENSE_CELLS, data=np.array([c.encode("ascii") for c in cells]))
+
+
+def _group_cells(g):
+    """Cell names of a PCA group in the reference's order (HDF5 name order, nabo/_mapping.py:79,404)."""
+    if _DENSE_MAT in g:
+        return sorted(x.decode("UTF-8") for x in g[_DENSE_CELLS][:])
+    return [x for x in g]
+
+
+def _read_rows(g, names, width, dtype):
+    """[len(names), width] array of the first `width` entries of the 1-D datasets `names` of group g.
+    Uses h5py's low-level API: the high-level `g[name][:w]` costs ~190 us per dataset, this ~35 us."""
+    h5py = _h5py()
+    gid = g.id
+    out = np.empty((len(names), width), dtype=dtype)
+    buf = np.empty(max(width, 1), dtype=dtype)
+    for i, c in enumerate(names):
+        ds = h5py.h5d.open(gid, c.encode("utf-8"))
+        shp = ds.shape
+        if len(shp) != 1 or shp[0] < width:
+            raise ValueError("ERROR: dataset %s has shape %s, need at least %d entries" % (c, shp, width))
+        if shp[0] != buf.shape[0]:
+            buf = np.empty(shp[0], dtype=dtype)
+        ds.read(h5py.h5s.ALL, h5py.h5s.ALL, buf)
+        out[i] = buf[:width]
+    return out
+
+
+def _write_rows(g, names, arr):
+    """One 1-D dataset per row of `arr` (the reference's per-cell layout), low-level API."""
+    h5py = _h5py()
+    arr = np.ascontiguousarray(arr)
+    gid = g.id
+    tid = h5py.h5t.py_create(arr.dtype)
+    space = h5py.h5s.create_simple((arr.shape[1],))
+    for i, c in enumerate(names):
+        ds = h5py.h5d.create(gid, c.encode("utf-8"), tid, space)
+        ds.write(h5py.h5s.ALL, h5py.h5s.ALL, arr[i])
+
+
 def _read_group_matrix(fn, grp, cells, use_comps):
     """Gather the per-cell float64 vectors `[:use_comps]` (nabo/_mapping.py:105,113) into one
-    dense C-contiguous [n_cells, use_comps] array -- once, instead of once per tile."""
+    dense C-contiguous [n_cells, use_comps] array -- once, instead of once per tile.  A group written
+    by `write_dense_pca` is read as one matrix."""
     h5py = _h5py()
     with h5py.File(fn, mode="r") as h5:
         g = h5[grp]
         if cells is None:
-            cells = [x for x in g]
-        out = np.empty((len(cells), use_comps), dtype=np.float64)
-        for i, c in enumerate(cells):
-            v = g[c][:use_comps]
-            if v.shape[0] != use_comps:
-                raise ValueError("ERROR: cell %s has only %d components, use_comps=%d" % (c, v.shape[0], use_comps))
-            out[i] = v
+            cells = _group_cells(g)
+        if _DENSE_MAT in g:
+            names = [x.decode("UTF-8") for x in g[_DENSE_CELLS][:]]
+            Z = g[_DENSE_MAT]
+            if Z.shape[1] < use_comps:
+                raise ValueError("ERROR: the PCA matrix has only %d components, use_comps=%d" % (Z.shape[1], use_comps))
+            pos = {c: i for i, c in enumerate(names)}
+            rows = np.array([pos[c] for c in cells], dtype=np.int64)
+            out = np.ascontiguousarray(Z[:, :use_comps][rows] if len(rows) else np.empty((0, use_comps)))
+            return cells, out
+        try:
+            out = _read_rows(g, cells, use_comps, np.float64)
+        except ValueError as e:
+            raise ValueError("ERROR: use_comps=%d: %s" % (use_comps, e)) from None
     return cells, out
 
 
@@ -84,26 +149,33 @@ def snn_edges(t_idx, r_idx, k, device=0):
     return tt.astype(np.int64), t_idx[tt, ss].astype(np.int64), w
 
 
-class _Components:
-    """Connected components of an undirected edge list (union-find)."""
-
-    def __init__(self, n):
-        self.p = np.arange(n)
-
-    def find(self, a):
-        p = self.p
-        while p[a] != a:
-            p[a] = p[p[a]]
-            a = p[a]
-        return a
-
-    def union(self, a, b):
-        ra, rb = self.find(a), self.find(b)
-        if ra != rb:
-            self.p[max(ra, rb)] = min(ra, rb)
-
-    def labels(self):
-        return np.array([self.find(i) for i in range(len(self.p))])
+def _component_labels(n, a, b):
+    """Connected-component label (= smallest member index) of every node of an undirected edge
+    list: label hooking + pointer jumping, vectorised.  Labels are member indices and never increase,
+    the smallest member keeps its own, so the fixed point is the component minimum."""
+    lab = np.arange(n, dtype=np.int64)
+    a = np.asarray(a, dtype=np.int64)
+    b = np.asarray(b, dtype=np.int64)
+    if a.size == 0:
+        return lab
+    while True:
+        la, lb = lab[a], lab[b]
+        lo, hi = np.minimum(la, lb), np.maximum(la, lb)
+        cut = hi != lo
+        if not cut.any():
+            return lab
+        a, b = a[cut], b[cut]                # edges inside one component stay there: drop them
+        new = lab.copy()
+        new[hi[cut]] = lo[cut]               # hook the larger root under the smaller one: every write is a
+                                             # strict decrease, so whichever of several writers wins is fine
+        while True:                          # flatten
+            nn = new[new]
+            if np.array_equal(nn, new):
+                break
+            new = nn
+        if np.array_equal(new, lab):
+            return lab
+        lab = new
 
 
 class Mapping:
@@ -145,6 +217,7 @@ class Mapping:
         self._distFactor = None
         self._chunkSize = None
         self._refMatrix = None          # cached dense reference [:use_comps]
+        self._knnCache = {}             # sorted-dist group -> (cells, idx[N,k]) written by this object
 
     # ---- metadata (nabo/_mapping.py:322-406) ---------------------------------------------
     @staticmethod
@@ -159,7 +232,7 @@ class Mapping:
 
     def _load_ref_cells(self):
         with _h5py().File(self._refPcaFn, mode="r") as h5:
-            return [x for x in h5[self._refPcaGrp]]          # HDF5 name order (:404)
+            return _group_cells(h5[self._refPcaGrp])         # HDF5 name order (:404)
 
     def _create_metadata(self, h5):
         for key in list(h5.keys()):
@@ -240,18 +313,24 @@ class Mapping:
             sg.create_dataset(_COL_CELLS, data=[c.encode("ascii") for c in cells])
             dg.create_dataset(_COL_DIST, data=dist)
         else:
-            for i, c in enumerate(cells):
-                sg.create_dataset(c, data=idx[i])
-                dg.create_dataset(c, data=dist[i])
+            _write_rows(sg, cells, idx)
+            _write_rows(dg, cells, dist)
+        # what calc_snn reads next; the file stays the hand-off for later sessions (use_stored_distances)
+        self._knnCache[sorted_dist_grp] = (list(cells), idx)
 
-    @staticmethod
-    def _load_knn(h5, sorted_dist_grp):
+    def _load_knn(self, h5, sorted_dist_grp):
+        if sorted_dist_grp in self._knnCache:
+            return self._knnCache[sorted_dist_grp]
         sg = h5[sorted_dist_grp]
         if _COL_IDX in sg:
             cells = [x.decode("UTF-8") for x in sg[_COL_CELLS][:]]
             return cells, sg[_COL_IDX][:]
         cells = [x for x in sg]
-        return cells, np.stack([sg[c][:] for c in cells]) if cells else np.empty((0, 0), dtype=np.int64)
+        if not cells:
+            return cells, np.empty((0, 0), dtype=np.int64)
+        width = min(sg[c].shape[0] for c in (cells[0], cells[-1]))
+        width = min(width, self._k) if self._k is not None else width
+        return cells, _read_rows(sg, cells, width, np.int64)
 
     def calc_dist(self, target_fn, target_grp, dist_grp, sorted_dist_grp, ignore_ref_cells):
         """Euclidean (reference vs itself) or modified Canberra (target vs reference) distances,
@@ -284,10 +363,7 @@ class Mapping:
         one gets an edge from its member closest (Euclidean) to any cell of those larger components.
         The reference walks full order rows; here it is a masked 1-NN query on the GPU.
         Returns (new edges, number of components before the round)."""
-        uf = _Components(n)
-        for a, b in zip(edges_a, edges_b):
-            uf.union(int(a), int(b))
-        lab = uf.labels()
+        lab = _component_labels(n, edges_a, edges_b)
         comps, sizes = np.unique(lab, return_counts=True)
         if len(comps) == 1:
             return [], 1
@@ -352,33 +428,86 @@ class Mapping:
 
     def _dump_graph(self, out_grp, t_cells, target_name, is_ref, et, ej, ew, extra):
         """The a10 wire format (nabo/_mapping.py:252-273): per node one dataset of
-        (neighbour name, weight) rows coerced to byte strings."""
-        ref_nodes = [c + "_" + self.refName for c in self.refCells]
-        t_nodes = [c + "_" + target_name for c in t_cells]
-        adj = [dict() for _ in t_cells]
+        (neighbour name, weight) rows coerced to byte strings.  Rows of a node keep the order in which
+        the reference's graph would have gained them (edge insertion order, first occurrence wins).
+        Built as ONE [rows,2] byte-string array sliced per node; datasets are created through h5py's
+        low-level API (one create+write per node is what the format costs)."""
+        h5py = _h5py()
+        n_t, n_r = len(t_cells), len(self.refCells)
+        et = np.asarray(et, dtype=np.int64)
+        ej = np.asarray(ej, dtype=np.int64)
+        ew = np.asarray(ew, dtype=np.float64)
+        ref_nodes = np.array([(c + "_" + self.refName).encode("ascii") for c in self.refCells])
+        t_nodes_s = [c + "_" + target_name for c in t_cells]
+        E = et.shape[0]
         if is_ref:
+            # neighbour ids: position in refCells.  Each SNN edge (t, j) lists j under t and t under j;
+            # repair edges (reference-cell positions) follow, in both directions.
             pos = {c: i for i, c in enumerate(t_cells)}
-            rpos = [pos[c] for c in self.refCells]
-            for t, j, w in zip(et, ej, ew):
-                adj[t][ref_nodes[j]] = w
-                adj[rpos[j]][t_nodes[t]] = w
-            for a, b, w in extra:            # repair edges are given in reference-cell positions
-                adj[rpos[a]][ref_nodes[b]] = w
-                adj[rpos[b]][ref_nodes[a]] = w
+            rpos = np.array([pos[c] for c in self.refCells], dtype=np.int64)       # refCells position -> t position
+            tref = np.empty(n_t, dtype=np.int64)
+            tref[rpos] = np.arange(n_r)                                             # t position -> refCells position
+            xa = np.array([a for a, _, _ in extra], dtype=np.int64)
+            xb = np.array([b for _, b, _ in extra], dtype=np.int64)
+            xw = np.array([w for _, _, w in extra], dtype=np.float64)
+            node = np.concatenate([np.stack([et, rpos[ej]], 1).reshape(-1), np.stack([rpos[xa], rpos[xb]], 1).reshape(-1)])
+            nb = np.concatenate([np.stack([ej, tref[et]], 1).reshape(-1), np.stack([xb, xa], 1).reshape(-1)])
+            w = np.concatenate([np.repeat(ew, 2), np.repeat(xw, 2)])
         else:
-            for t, j, w in zip(et, ej, ew):
-                adj[t][ref_nodes[j]] = w
-        with _h5py().File(self._h5Fn, mode="a") as h5:
+            node, nb, w = et, ej, ew
+        # group by node, keep insertion order inside a node, drop repeated (node, neighbour) pairs:
+        # a dict keeps the first position and the last value, as networkx's adjacency does
+        seq = np.arange(node.shape[0])
+        o = np.lexsort((seq, nb, node))
+        node_o, nb_o = node[o], nb[o]
+        first = np.ones(o.shape[0], dtype=bool)
+        first[1:] = (node_o[1:] != node_o[:-1]) | (nb_o[1:] != nb_o[:-1])
+        grp_id = np.cumsum(first) - 1
+        last_of = np.zeros(int(first.sum()), dtype=np.int64)
+        last_of[grp_id] = np.arange(o.shape[0])                 # last duplicate of every pair (ascending writes)
+        keep_first = o[first]
+        w_keep = w[o[last_of]]
+        node_k, nb_k = node[keep_first], nb[keep_first]
+        o2 = np.lexsort((keep_first, node_k))                   # by node, then insertion order
+        node_k, nb_k, w_keep = node_k[o2], nb_k[o2], w_keep[o2]
+        counts = np.bincount(node_k, minlength=n_t)
+        starts = np.concatenate([[0], np.cumsum(counts)])
+        # weights take few distinct values: format each once (numpy's float -> bytes coercion is repr)
+        uw, winv = np.unique(w_keep, return_inverse=True)
+        wtxt = np.array([repr(float(x)).encode("ascii") for x in uw]) if len(uw) else np.empty(0, dtype="S1")
+        width = max(32, ref_nodes.dtype.itemsize if n_r else 1)
+        rows = np.empty((node_k.shape[0], 2), dtype="S%d" % width)
+        if node_k.shape[0]:
+            rows[:, 0] = ref_nodes[nb_k]
+            rows[:, 1] = wtxt[winv]
+        name_len = np.char.str_len(ref_nodes) if n_r else np.zeros(0, dtype=np.int64)
+        uniform = (n_r == 0) or int(name_len.max()) <= 32       # else the S-width differs per node (max over its rows)
+        with h5py.File(self._h5Fn, mode="a") as h5:
             if out_grp in h5:
                 del h5[out_grp]
             out = h5.create_group(out_grp)
-            for node, nb in zip(t_nodes, adj):
-                if len(nb) == 0:
-                    out.create_dataset(node, data=np.empty((0,), dtype=np.float64))
+            gid = out.id
+            tid = h5py.h5t.py_create(rows.dtype)
+            f64 = h5py.h5t.py_create(np.dtype(np.float64))
+            spaces = {}
+            empty = np.empty((0,), dtype=np.float64)
+            for t in range(n_t):
+                c = int(counts[t])
+                name = t_nodes_s[t].encode("utf-8")
+                if c == 0:
+                    ds = h5py.h5d.create(gid, name, f64, h5py.h5s.create_simple((0,)))
                     continue
-                rows = [(n2.encode("ascii"), repr(float(w)).encode("ascii")) for n2, w in nb.items()]
-                width = max(32, max(len(r[0]) for r in rows))
-                out.create_dataset(node, data=np.array(rows, dtype="S%d" % width))
+                blk = rows[starts[t]:starts[t] + c]
+                if not uniform:
+                    wd = max(32, int(name_len[nb_k[starts[t]:starts[t] + c]].max()))
+                    if wd != width:
+                        out.create_dataset(t_nodes_s[t], data=blk.astype("S%d" % wd))
+                        continue
+                sp = spaces.get(c)
+                if sp is None:
+                    sp = spaces[c] = h5py.h5s.create_simple((c, 2))
+                ds = h5py.h5d.create(gid, name, tid, sp)
+                ds.write(h5py.h5s.ALL, h5py.h5s.ALL, blk)
 
     # ---- entry points (nabo/_mapping.py:526-541, :557-621) ----------------------------------
     def make_ref_graph(self, use_stored_distances=False):

@@ -146,6 +146,17 @@ def run_case(tag):
             m3.make_ref_graph()
         _, edges3, _ = read_graph_like_reference(map2, "WT", "reference")
         out["columnar_same_graph"] = edges3 == edges
+        # dense [N, n_comps] input (rows deliberately NOT in name order) gives the same graph
+        ref_dense = os.path.join(td, "ref_dense.h5")
+        perm = np.random.default_rng(3).permutation(len(rn))
+        nabo_amd.write_dense_pca(ref_dense, "data", [str(rn[i]) for i in perm], np.asarray(ref)[perm])
+        map3 = os.path.join(td, "mapping_dense.h5")
+        with redirect_stdout(buf):
+            m4 = nabo_amd.Mapping(map3, "WT", ref_dense, "data", overwrite=True)
+            m4.set_parameters(uc, k, f, chunk)
+            m4.make_ref_graph()
+        _, edges4, _ = read_graph_like_reference(map3, "WT", "reference")
+        out["dense_input_same_graph"] = (edges4 == edges) and (list(m4.refCells) == list(m.refCells))
     return out
 
 
@@ -195,6 +206,25 @@ def run_validate():
         out["different_cells_on_reopen"] = raises(ValueError, M, map_fn, "WT", ref2, "data")
         m2 = M(map_fn, "WT", ref_fn, "data")
         out["reopen_keeps_uid"] = m2._refGraphGrpName == m._refGraphGrpName
+        # host I/O helpers: dense input == per-cell input; too-short vectors are refused
+        from nabo_amd import _mapping as MM
+        Z = pca_like(12, 6, 1)
+        dense_fn = os.path.join(td, "dense.h5")
+        perm = np.random.default_rng(0).permutation(12)
+        nabo_amd.write_dense_pca(dense_fn, "data", [names[i] for i in perm], Z[perm])
+        c1, A = MM._read_group_matrix(ref_fn, "data", None, 5)
+        c2, B = MM._read_group_matrix(dense_fn, "data", None, 5)
+        out["dense_equals_per_cell"] = bool(c1 == c2 and np.array_equal(A, B) and
+                                            np.array_equal(A, Z[np.argsort(names)][:, :5]))
+        out["too_many_comps_per_cell"] = raises(ValueError, MM._read_group_matrix, ref_fn, "data", None, 7)
+        out["too_many_comps_dense"] = raises(ValueError, MM._read_group_matrix, dense_fn, "data", None, 7)
+        with h5py.File(os.path.join(td, "rows.h5"), "w") as h5:
+            gg = h5.create_group("g")
+            I = np.arange(36, dtype=np.int64).reshape(12, 3)
+            MM._write_rows(gg, names, I)
+            out["rows_roundtrip"] = bool(np.array_equal(MM._read_rows(gg, names, 3, np.int64), I) and
+                                         np.array_equal(np.stack([gg[c][:] for c in names]), I) and
+                                         np.array_equal(MM._read_rows(gg, names, 2, np.int64), I[:, :2]))
     return out
 
 
