@@ -25,7 +25,7 @@ if REPO not in sys.path:
 PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 
 
-def cpu_baseline(d, k):
+def cpu_baseline(d, k, metric=0):
     """The oracle (bit-equal port of the reference's CPU arithmetic + selection), all host
     cores, on a bounded sample of the same workload."""
     import oracle
@@ -34,15 +34,15 @@ def cpu_baseline(d, k):
     n_s, m_s = 100000, 1024
     Y = pca_like(n_s, d, seed=1003)
     X = pca_like(m_s, d, seed=2003)
-    oracle.knn(X[:64], Y, k, 0, nthreads=cores)          # warm up threads / page in
+    oracle.knn(X[:64], Y, k, metric, nthreads=cores)          # warm up threads / page in
     t0 = time.perf_counter()
-    oracle.knn(X, Y, k, 0, nthreads=cores)
+    oracle.knn(X, Y, k, metric, nthreads=cores)
     dt = time.perf_counter() - t0
     # scale the sample towards ~10-20 s of CPU work
     reps = int(max(1, min(16, 12.0 / max(dt, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        oracle.knn(X, Y, k, 0, nthreads=cores)
+        oracle.knn(X, Y, k, metric, nthreads=cores)
     dt = time.perf_counter() - t0
     return {"value": reps * m_s * n_s / dt, "unit": "cell-pair distances/s", "cores": cores, "kind": "port",
             "sample": "%d x (%d targets x %d refs), d=%d, k=%d, float64 sequential + ordered top-k, OpenMP"
@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--refs", dest="n", type=int, default=1000000)
     ap.add_argument("--dims", dest="d", type=int, default=50)
     ap.add_argument("--neighbors", dest="k", type=int, default=15)
+    ap.add_argument("--metric", choices=["euclidean", "cosine"], default="euclidean",
+                    help="cosine is an extension (BASELINE configs[4]); the headline workload is euclidean")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -105,12 +107,13 @@ def main():
         dD = _knn.DeviceBuffer(m * k * 8, dev)
         x_ptr, y_ptr = dX.ptr, dY.ptr
 
-    index = nabo_amd.KnnIndex(hi - lo, d, metric=nabo_amd.EUCLIDEAN, ref_index_base=lo, device=dev)
+    metric_id = nabo_amd.COSINE if a.metric == "cosine" else nabo_amd.EUCLIDEAN
+    index = nabo_amd.KnnIndex(hi - lo, d, metric=metric_id, ref_index_base=lo, device=dev)
     stats = []
 
     if use_dist:
         lk, mg, lc = gpu_callables(index, dev)
-        if os.environ.get("NABO_DIST_LOCAL_CERT") == "1":      # A/B: every shard certifies its own top-k'
+        if os.environ.get("NABO_DIST_LOCAL_CERT") == "1" or a.metric != "euclidean":   # A/B; candidates are Euclidean-only
             lc = None
         sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev), local_cand=lc)
 
@@ -156,7 +159,7 @@ def main():
     if use_dist and os.environ.get("NABO_BENCH_CHECK") == "1":
         # rehearsal check: the sharded result must equal one unsharded index on the same data
         full = pca_like(n, d, seed=1003)
-        ref_ix = nabo_amd.KnnIndex(n, d, metric=nabo_amd.EUCLIDEAN, device=dev).set_ref(full)
+        ref_ix = nabo_amd.KnnIndex(n, d, metric=metric_id, device=dev).set_ref(full)
         ri, rd = ref_ix.query(X, k)
         ref_ix.close()
         oi, od = step()
@@ -171,7 +174,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            wl = "%dk ref x %dk target, d=%d, k=%d, euclidean, refs sharded %d-way" % (n // 1000, m // 1000, d, k, world)
+            wl = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, world)
             if wl in tj and not os.environ.get("NABO_L2_MODE"):
                 traffic = {"gb_per_step": (2.0 * tj[wl]["fetch_kb"] + tj[wl]["write_kb"]) * 1024 / 1e9,
                            "source": tj[wl]["source"]}
@@ -185,8 +188,8 @@ def main():
             "knn_build_s": dt / a.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, euclidean, refs sharded %d-way"
-                                   % (n // 1000, m // 1000, d, k, world),
+            "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way"
+                                   % (n // 1000, m // 1000, d, k, a.metric, world),
                        "parallelism": "ref-shard%d" % world,
                        "arithmetic": "fp32 MFMA score filter, float64 re-evaluation: indices and distances equal the "
                                      "reference's float64 path"},
@@ -197,8 +200,30 @@ def main():
                           ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
             "fallback_rows": int(np.max([s["fallback_rows"] for s in stats])),
         }
+        if world == 1 and not use_dist and not os.environ.get("NABO_L2_MODE") and not os.environ.get("NABO_DEBUG_ABLATE") \
+                and os.environ.get("NABO_BENCH_ALT", "1") == "1" and d <= 64 and a.metric == "euclidean":
+            # informational, NOT the headline: the same step with the filter on the f16 matrix pipe
+            # (3-product hi/lo split), outside the timed region; results must be the same bits
+            os.environ["NABO_L2_MODE"] = "f16x3"
+            alt = nabo_amd.KnnIndex(n, d, metric=nabo_amd.EUCLIDEAN, device=dev)
+            del os.environ["NABO_L2_MODE"]
+            aI, aD = _knn.DeviceBuffer(m * k * 8, dev), _knn.DeviceBuffer(m * k * 8, dev)
+            ts = []
+            for _ in range(3):
+                sync()
+                t0 = time.perf_counter()
+                alt.set_ref(y_device_ptr=y_ptr)
+                alt.query_device(x_ptr, m, k, False, aI.ptr, aD.ptr)
+                sync()
+                ts.append(time.perf_counter() - t0)
+            st = alt.last_stats()
+            same = bool(np.array_equal(aI.download((m, k), np.int64), gi) and np.array_equal(aD.download((m, k), np.float64), gd))
+            alt.close()
+            line["alt_f16x3"] = {"ms_per_step": min(ts[1:]) * 1e3, "value": m * n / min(ts[1:]), "kernel_ms": st["ms_topk"],
+                                 "fallback_rows": st["fallback_rows"], "same_bits_as_f32_path": same,
+                                 "note": "opt-in NABO_L2_MODE=f16x3; 3x v_mfma_f32_32x32x16_f16 per K-slab"}
         if not a.no_cpu_baseline and world == 1 and not use_dist:
-            line["cpu_baseline"] = cpu_baseline(d, k)
+            line["cpu_baseline"] = cpu_baseline(d, k, metric_id)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()

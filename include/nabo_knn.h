@@ -13,6 +13,10 @@
  *       metric 0: nabo/_mapping.py:16-26  _euclidean_dist   sqrt(sum_k (x-y)^2), k ascending,
  *                                         separate multiply/add (no FMA), correctly rounded sqrt
  *       metric 1: nabo/_mapping.py:29-45  _mod_canberra_dist (asymmetric: x = target, y = reference)
+ *       metric 2: EXTENSION, not in the reference (BASELINE.json configs[4] names a cosine metric the
+ *                 reference lacks; parity pinned only by this build's own oracle): cosine distance
+ *                 1 - <x,y>/(sqrt<x,x>*sqrt<y,y>), sums in ascending k with separate multiply/add;
+ *                 a zero vector is at distance 1 from everything
  *   - ordering replaces the mask + np.argsort of nabo/_mapping.py:135-146: refs flagged in
  *     ref_mask sort to the END (numpy.ma NaN-fill), all others by (distance ascending,
  *     reference index ascending) -- the canonical total order where the reference's unstable
@@ -35,6 +39,7 @@ extern "C" {
 
 #define NABO_METRIC_EUCLIDEAN    0   /* nabo/_mapping.py:16-26, selected when intra_ref (:119-121) */
 #define NABO_METRIC_MOD_CANBERRA 1   /* nabo/_mapping.py:29-45, selected otherwise      (:122-124) */
+#define NABO_METRIC_COSINE       2   /* extension (no reference counterpart): Euclidean filter on unit rows */
 
 #define NABO_OK            0
 #define NABO_E_INVALID    -1   /* bad argument (the Python shim raises ValueError)            */
@@ -44,7 +49,7 @@ extern "C" {
 #define NABO_E_UNSUPPORTED -5  /* shape outside what the kernels are instantiated for         */
 
 /* Limits of the instantiated kernels. */
-#define NABO_MAX_COMPS      128  /* use_comps (g) for the Euclidean MFMA kernel               */
+#define NABO_MAX_COMPS      128  /* use_comps (g) for the Euclidean / cosine MFMA kernel      */
 #define NABO_MAX_K           56  /* k + drop_first (candidate lists hold 32 or 64 entries)     */
 
 const char *nabo_version(void);

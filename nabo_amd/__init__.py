@@ -2,10 +2,10 @@
 
 Public names mirror the reference's `nabo` package for this path (`Mapping`), plus the
 array-level entry points of the C ABI (`knn`, `pairwise`, `KnnIndex`)."""
-from ._lib import EUCLIDEAN, MOD_CANBERRA, NaboError, device_count  # noqa: F401
+from ._lib import EUCLIDEAN, MOD_CANBERRA, COSINE, NaboError, device_count  # noqa: F401
 from ._knn import knn, pairwise, KnnIndex, snn_counts  # noqa: F401
 from ._mapping import Mapping, write_dense_pca  # noqa: F401
 from ._score import get_mapping_score, mapping_score_from_edges  # noqa: F401
 
-__all__ = ["Mapping", "write_dense_pca", "get_mapping_score", "mapping_score_from_edges", "knn", "pairwise", "KnnIndex", "snn_counts", "device_count", "EUCLIDEAN", "MOD_CANBERRA",
+__all__ = ["Mapping", "write_dense_pca", "get_mapping_score", "mapping_score_from_edges", "knn", "pairwise", "KnnIndex", "snn_counts", "device_count", "EUCLIDEAN", "MOD_CANBERRA", "COSINE",
            "NaboError"]

@@ -8,6 +8,7 @@ SO_PATH = os.path.join(HERE, "libnabo_knn.so")
 
 EUCLIDEAN = 0
 MOD_CANBERRA = 1
+COSINE = 2          # extension: not in the reference (include/nabo_knn.h)
 MAX_COMPS = 128
 MAX_K = 56
 

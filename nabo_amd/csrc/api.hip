@@ -40,12 +40,13 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef, double ymax_sqrt,
                          double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
-                         unsigned int *fail_count, hipStream_t st, int canberra = 0, double cb_f = 0.0,
+                         unsigned int *fail_count, hipStream_t st, int metric = 0, double cb_f = 0.0,
                          float cb_plateau = 0.0f);
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
                               int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st);
+hipError_t normalise_rows_launch(const double *X, int64_t m, int g, double *out, hipStream_t st);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
                              int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
@@ -162,7 +163,8 @@ struct nabo_index {
     bool have_ref = false;
 
     const double *dY = nullptr;      // [n,g] float64 on device (borrowed or == ybuf)
-    DevBuf ybuf, maskbuf, mlistbuf;
+    const double *dYp = nullptr;     // what the MFMA filter packs: dY, or the unit-length rows (cosine)
+    DevBuf ybuf, ynbuf, xnbuf, maskbuf, mlistbuf;
     const uint8_t *dmask = nullptr;
     int64_t n_masked = 0;
     int n_masked_list = 0;
@@ -203,7 +205,7 @@ static int ensure_packed(nabo_index *ix, bool want_h)
         const size_t tile_bytes = (size_t)2 * ix->ks16 * 1024 + 128;
         if ((rc = ix->yhpk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
         // power-of-two scale: |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
-        HIP_TRY(nabo::maxabs_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->normmax.as<unsigned int>() + 1, st));
+        HIP_TRY(nabo::maxabs_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->normmax.as<unsigned int>() + 1, st));
         HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         float amax;
@@ -213,14 +215,14 @@ static int ensure_packed(nabo_index *ix, bool want_h)
         if (e > 60) e = 60;
         if (e < -60) e = -60;
         ix->hscale = std::ldexp(1.0, e);
-        HIP_TRY(nabo::pack_href_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->ks16,
+        HIP_TRY(nabo::pack_href_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->ks16,
                                        ix->ref_tiles_alloc, ix->dmask, ix->yhpk.as<unsigned char>(),
                                        ix->normmax.as<unsigned int>(), st));
     } else {
         const int Q = (ix->ksteps + 3) / 4;
         const size_t tile_bytes = ((size_t)Q * 256 + 32) * sizeof(float);
         if ((rc = ix->ypk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
-        HIP_TRY(nabo::pack_ref_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), ix->ksteps, ix->ref_tiles_alloc,
+        HIP_TRY(nabo::pack_ref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->ksteps, ix->ref_tiles_alloc,
                                       ix->dmask, ix->ypk.as<float>(), ix->normmax.as<unsigned int>(), st));
     }
     HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
@@ -252,11 +254,11 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
     *out = nullptr;
     if (n_ref < 1 || n_ref >= 0xFFFFFFF0ll) return fail(NABO_E_INVALID, "n_ref=%lld out of range", (long long)n_ref);
     if (g < 1) return fail(NABO_E_INVALID, "g=%d must be >= 1", g);
-    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_MOD_CANBERRA)
+    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_MOD_CANBERRA && metric != NABO_METRIC_COSINE)
         return fail(NABO_E_INVALID, "unknown metric %d", metric);
     if (metric == NABO_METRIC_MOD_CANBERRA && !(dist_factor > 0))
         return fail(NABO_E_INVALID, "dist_factor must be > 0");          // nabo/_mapping.py:516-521
-    if (metric == NABO_METRIC_EUCLIDEAN && g > NABO_MAX_COMPS)
+    if (metric != NABO_METRIC_MOD_CANBERRA && g > NABO_MAX_COMPS)
         return fail(NABO_E_UNSUPPORTED, "g=%d exceeds NABO_MAX_COMPS=%d", g, NABO_MAX_COMPS);
     if (ref_index_base < 0) return fail(NABO_E_INVALID, "ref_index_base must be >= 0");
     int rc = use_device(device);
@@ -269,7 +271,7 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
     ix->metric = metric;
     ix->f = dist_factor;
     ix->base = ref_index_base;
-    if (metric == NABO_METRIC_EUCLIDEAN) {
+    if (metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ksteps = pick_ksteps(g);
         const char *md = getenv("NABO_L2_MODE");
         if (md && strcmp(md, "f16x3") == 0 && nabo::l2h_pick_ks16(g) > 0) {
@@ -295,7 +297,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->cbflag, &ix->xfail, &ix->tmpi, &ix->tmpd,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->cbflag, &ix->xfail, &ix->tmpi, &ix->tmpd,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -341,12 +343,21 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
             ix->n_masked_list = (int)lst.size();
         }
     }
-    if (ix->metric == NABO_METRIC_EUCLIDEAN) {
+    if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 16;      // room for split padding (+inf-norm tiles)
         ix->packed_f32 = ix->packed_f16 = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
-        HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
+        if (ix->metric == NABO_METRIC_COSINE) {
+            // cosine: the filter sees unit-length rows, NOT centred (a shift changes angles)
+            if ((rc = ix->ynbuf.reserve(ybytes))) return rc;
+            HIP_TRY(nabo::normalise_rows_launch(ix->dY, ix->n, ix->g, ix->ynbuf.as<double>(), st));
+            HIP_TRY(hipMemsetAsync(ix->centre.p, 0, (size_t)ix->g * sizeof(double), st));
+            ix->dYp = ix->ynbuf.as<double>();
+        } else {
+            HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
+            ix->dYp = ix->dY;
+        }
         if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
     } else {
         const int64_t chunks = (ix->n + 63) / 64;
@@ -418,7 +429,14 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
     int64_t n_wg = 0;
     HIP_TRY(hipEventRecord(ix->ev[0], st));
 
-    if (ix->metric == NABO_METRIC_EUCLIDEAN) {
+    if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
+        const bool cosine = ix->metric == NABO_METRIC_COSINE;
+        const double *dXp = dX;                           // what the filter packs
+        if (cosine) {
+            if ((rc = ix->xnbuf.reserve((size_t)m * g * sizeof(double)))) return rc;
+            HIP_TRY(nabo::normalise_rows_launch(dX, m, g, ix->xnbuf.as<double>(), st));
+            dXp = ix->xnbuf.as<double>();
+        }
         int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = L;
         bool use_h = false;
         if (ix->mode == 1 && epl == 1) {
@@ -484,10 +502,10 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if ((rc = ix->failcnt.reserve(sizeof(unsigned int)))) return rc;
         HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
         if (use_h)
-            HIP_TRY(nabo::pack_hquery_launch(dX, m, g, ix->centre.as<double>(), ix->hscale, ix->ks16, rows_pad / 32,
+            HIP_TRY(nabo::pack_hquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->ks16, rows_pad / 32,
                                              ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), st));
         else
-            HIP_TRY(nabo::pack_query_launch(dX, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
+            HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
         HIP_TRY(hipEventRecord(ix->ev[1], st));
         if (use_h) {
@@ -555,13 +573,13 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
-                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st));
+                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(),
-                                        ix->failcnt.as<unsigned int>(), st));
+                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -712,7 +730,7 @@ int nabo_pairwise(const double *X, int64_t m, const double *Y, int64_t n, int32_
 {
     if (!X || !Y || !D) return fail(NABO_E_INVALID, "NULL argument");
     if (m < 1 || n < 1 || g < 1) return fail(NABO_E_INVALID, "empty operand");
-    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_MOD_CANBERRA)
+    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_MOD_CANBERRA && metric != NABO_METRIC_COSINE)
         return fail(NABO_E_INVALID, "unknown metric %d", metric);
     if (m > 65535) return fail(NABO_E_UNSUPPORTED, "nabo_pairwise is the tile-sized seam: m <= 65535");
     int rc = use_device(device);

@@ -47,6 +47,49 @@ __device__ __forceinline__ double canberra_exact(const double *__restrict__ x, c
     return dist;
 }
 
+// EXTENSION (not in the reference, parity unpinned -- oracle/nabo_oracle.c cosine_pair): cosine distance
+// 1 - <x,y> / (sqrt<x,x> * sqrt<y,y>), sums in ascending k, rounded multiply then rounded add; a zero
+// vector is at distance 1 from everything.
+__device__ __forceinline__ double cosine_exact(const double *__restrict__ x, const double *__restrict__ y, int g)
+{
+    double dot = 0.0, nx = 0.0, ny = 0.0;
+    for (int k = 0; k < g; ++k) {
+        const double xv = x[k], yv = y[k];
+        dot = __dadd_rn(dot, __dmul_rn(xv, yv));
+        nx = __dadd_rn(nx, __dmul_rn(xv, xv));
+        ny = __dadd_rn(ny, __dmul_rn(yv, yv));
+    }
+    if (nx == 0.0 || ny == 0.0) return 1.0;
+    return __dsub_rn(1.0, __ddiv_rn(dot, __dmul_rn(__dsqrt_rn(nx), __dsqrt_rn(ny))));
+}
+
+// metric: 0 Euclidean, 1 modified Canberra, 2 cosine
+__device__ __forceinline__ double exact_dist(int metric, const double *__restrict__ x, const double *__restrict__ y,
+                                             int g, double f)
+{
+    return metric == 0 ? euclid_exact(x, y, g) : metric == 1 ? canberra_exact(x, y, g, f) : cosine_exact(x, y, g);
+}
+
+// Rows scaled to unit length in float64 (zero rows stay zero): the cosine metric runs the Euclidean
+// filter on these, since ||x^ - y^||^2 = 2 * (1 - cos).
+__global__ void normalise_rows_kernel(const double *__restrict__ X, int64_t m, int g, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double *x = X + i * g;
+    double nx = 0.0;
+    for (int k = 0; k < g; ++k) nx = __dadd_rn(nx, __dmul_rn(x[k], x[k]));
+    const double s = __dsqrt_rn(nx);
+    for (int k = 0; k < g; ++k) out[i * g + k] = nx == 0.0 ? 0.0 : __ddiv_rn(x[k], s);
+}
+
+hipError_t normalise_rows_launch(const double *X, int64_t m, int g, double *out, hipStream_t st)
+{
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(normalise_rows_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, X, m, g, out);
+    return hipGetLastError();
+}
+
 // ---- fine seam: dense D[m,n] (a1 / a2 literal) -------------------------------------------
 __global__ void pairwise_kernel(const double *__restrict__ X, int64_t m, const double *__restrict__ Y, int64_t n,
                                 int g, int metric, double f, double *__restrict__ D)
@@ -55,7 +98,7 @@ __global__ void pairwise_kernel(const double *__restrict__ X, int64_t m, const d
     const int64_t i = blockIdx.y;
     if (j >= n || i >= m) return;
     const double *x = X + i * g, *y = Y + j * g;
-    D[i * n + j] = metric == 0 ? euclid_exact(x, y, g) : canberra_exact(x, y, g, f);
+    D[i * n + j] = exact_dist(metric, x, y, g, f);
 }
 
 // Rows with fewer valid (unmasked) references than k': the order row continues with the
@@ -74,7 +117,7 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
         if (q < n_masked_list) {
             const uint32_t j = masked_list[q];
             oi[o] = base + j;
-            od[o] = metric == 0 ? euclid_exact(x, Y + (int64_t)j * g, g) : canberra_exact(x, Y + (int64_t)j * g, g, f);
+            od[o] = exact_dist(metric, x, Y + (int64_t)j * g, g, f);
         } else {
             oi[o] = -1;
             od[o] = __builtin_nan("");
@@ -83,14 +126,19 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 }
 
 // One wave per target row; NCL = ceil(S*L/64) candidates per lane.
-// CANB = false: Euclidean candidates from the fp32 / f16x3 score filter, certified with the
+// MET = 0: Euclidean candidates from the fp32 / f16x3 score filter, certified with the
 //               rounding-error bound E (header comment).
-// CANB = true : modified-Canberra candidates from the fp32 LOWER-BOUND filter (canberra_f32.hip):
+// MET = 1: modified-Canberra candidates from the fp32 LOWER-BOUND filter (canberra_f32.hip):
 //               every non-candidate has exact distance >= tau, so the row is certified when
 //               tau > d_(k') strictly, or when tau is the all-dimensions-out-of-window plateau (then
 //               every non-candidate is at distance exactly g and carries a larger index than the kept
 //               plateau entries of its split).
-template <int NCL, bool CANB>
+// MET = 2: cosine candidates from the Euclidean filter run on unit-length rows x^, y^ (float64, then
+//               packed like any other input).  The Euclidean certificate bounds ||x^-y^||^2 of every
+//               non-candidate from below by B; ||x^-y^||^2 = 2(1-cos) up to the float64 rounding of the
+//               normalisation and of cosine_exact itself (< 1e-13 for g <= 128), so the row is certified
+//               when  B/2 - 2e-13 > c_(k')  (exact cosine value of the k'-th candidate).
+template <int NCL, int MET>
 __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                      const double *__restrict__ Y, int g,
                                                      const uint32_t *__restrict__ cand_idx,
@@ -121,7 +169,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             const uint32_t j = cand_idx[lrow * ncand + e];
             if (j != 0xFFFFFFFFu) {
                 val[r] = j;
-                key[r] = CANB ? canberra_exact(x, Y + (int64_t)j * g, g, cb_f) : euclid_exact(x, Y + (int64_t)j * g, g);
+                key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, cb_f);
             }
         }
     }
@@ -145,13 +193,13 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
 #pragma unroll
         for (int r = 0; r < NCL; ++r)
             if ((e >> 6) == r) dk = __shfl(key[r], e & 63, 64);
-        if (CANB) {
+        if (MET == 1) {
             if (tmin != __builtin_inff()) certified = ((double)tmin > dk) || (tmin == cb_plateau);
         } else if (tmin != __builtin_inff()) {
             const double sx = sqrt(xnorm[row]);
             const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
             const double bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);   // tau in score units
-            certified = bound > dk * dk * (1.0 + 1e-12);
+            certified = MET == 2 ? (0.5 * bound - 2e-13 > dk) : (bound > dk * dk * (1.0 + 1e-12));
         }
     } else {
         // fewer candidates than k': only legitimate when EVERY unmasked reference is a candidate
@@ -174,7 +222,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         }
     }
     if (nreal < kk)
-        emit_masked_tail(x, Y, g, CANB ? 1 : 0, cb_f, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
+        emit_masked_tail(x, Y, g, MET, cb_f, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
 }
 
 // Shard mode (reference rows sharded over GPUs, global certification -- nabo_amd/_dist.py): no local
@@ -278,7 +326,7 @@ __global__ __launch_bounds__(256) void exact_rows_kernel(const double *__restric
         const uint32_t pj = prev_j;
         for (int64_t j = threadIdx.x; j < n; j += 256) {
             if (mask && mask[j]) continue;
-            const double d = metric == 0 ? euclid_exact(x, Y + j * g, g) : canberra_exact(x, Y + j * g, g, f);
+            const double d = exact_dist(metric, x, Y + j * g, g, f);
             if (hp && !kv_less<double>(pd, pj, d, (uint32_t)j)) continue;   // not after previous pick
             if (kv_less<double>(d, (uint32_t)j, bd, bj)) { bd = d; bj = (uint32_t)j; }
         }
@@ -381,7 +429,7 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                          double ymax_sqrt, double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total,
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
-                         uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st, int canberra = 0,
+                         uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st, int metric = 0,
                          double cb_f = 0.0, float cb_plateau = 0.0f)
 {
     const int ncl = (S * L + 63) / 64;
@@ -389,12 +437,16 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
 #define NABO_RF(N)                                                                                               \
     do {                                                                                                         \
-        if (canberra)                                                                                            \
-            hipLaunchKernelGGL((refine_kernel<N, true>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
+        if (metric == 1)                                                                                         \
+            hipLaunchKernelGGL((refine_kernel<N, 1>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S,   \
+                               L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
+                               n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
+        else if (metric == 2)                                                                                    \
+            hipLaunchKernelGGL((refine_kernel<N, 2>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S,   \
                                L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
                                n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
         else                                                                                                     \
-            hipLaunchKernelGGL((refine_kernel<N, false>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
+            hipLaunchKernelGGL((refine_kernel<N, 0>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S,   \
                                L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
                                n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
     } while (0)

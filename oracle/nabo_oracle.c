@@ -55,17 +55,34 @@ static inline double canberra_pair(const double *x, const double *y, int g, doub
     return dist;
 }
 
-/* metric: 0 euclidean (a1), 1 modified canberra (a2) */
+/* EXTENSION -- NOT in the reference (BASELINE.json's config 5 asks for a cosine
+ * metric the reference does not have), so this definition is the build's own and its parity is
+ * UNPINNED by any reference output: cosine distance 1 - <x,y> / (sqrt<x,x> * sqrt<y,y>), the three sums
+ * accumulated in ascending k with separate multiply and add like a1; a zero vector is at distance 1
+ * from everything. */
+static inline double cosine_pair(const double *x, const double *y, int g)
+{
+    double dot = 0.0, nx = 0.0, ny = 0.0;
+    for (int k = 0; k < g; ++k) {
+        dot += x[k] * y[k];
+        nx += x[k] * x[k];
+        ny += y[k] * y[k];
+    }
+    if (nx == 0.0 || ny == 0.0) return 1.0;
+    return 1.0 - dot / (sqrt(nx) * sqrt(ny));
+}
+
+/* metric: 0 euclidean (a1), 1 modified canberra (a2), 2 cosine (extension, see above) */
 static inline double pair_dist(const double *x, const double *y, int g, int metric, double f)
 {
-    return metric == 0 ? euclid_pair(x, y, g) : canberra_pair(x, y, g, f);
+    return metric == 0 ? euclid_pair(x, y, g) : metric == 1 ? canberra_pair(x, y, g, f) : cosine_pair(x, y, g);
 }
 
 /* Literal a1/a2 kernel seam (_mapping.py:120-124): caller-allocated D[m,n]. */
 int oracle_pairwise(const double *X, int64_t m, const double *Y, int64_t n, int32_t g,
                     int32_t metric, double dist_factor, double *D, int32_t nthreads)
 {
-    if (metric != 0 && metric != 1) return -1;
+    if (metric < 0 || metric > 2) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -100,7 +117,7 @@ int oracle_knn(const double *X, int64_t m, const double *Y, int64_t n, int32_t g
                int32_t metric, double dist_factor, const uint8_t *ref_mask, int32_t drop_first,
                int64_t *out_idx, double *out_dist, int32_t nthreads)
 {
-    if (metric != 0 && metric != 1) return -1;
+    if (metric < 0 || metric > 2) return -1;
     int kk = k + (drop_first ? 1 : 0);
     if (k < 1 || kk > n) return -2;
 #ifdef _OPENMP

@@ -8,6 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SO = os.path.join(HERE, "libnabo_oracle.so")
 EUCLIDEAN, MOD_CANBERRA = 0, 1
+COSINE = 2        # extension, not in the reference (parity unpinned) -- see nabo_oracle.c
 _lib = None
 
 

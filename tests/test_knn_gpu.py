@@ -380,3 +380,63 @@ def test_canberra_filter_equals_exact_kernel(gpu_lib):
     finally:
         del os.environ["NABO_CANBERRA_MODE"]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---- cosine metric: an EXTENSION (BASELINE.json configs[4]); no reference counterpart, so parity is
+# against this build's own oracle definition only ("parity unpinned") --------------------
+def test_cosine_pairwise_bit_exact_vs_oracle(gpu_lib):
+    rng = np.random.default_rng(9)
+    for g in (1, 7, 50, 100):
+        x = rng.standard_normal((70, g)) * np.exp(rng.uniform(-8, 8, (70, 1)))
+        y = rng.standard_normal((90, g)) * np.exp(rng.uniform(-8, 8, (90, 1)))
+        y[5] = 0.0
+        x[3] = 0.0
+        y[7] = x[11] * 3.0                  # parallel rows: distance ~0 (may round to +-1 ulp of 0)
+        assert np.array_equal(gpu_lib.pairwise(x, y, 2), oracle.pairwise(x, y, 2))
+
+
+@pytest.mark.parametrize("m,n,g,k,drop", [(1, 40, 5, 3, False), (100, 1000, 30, 11, True), (257, 4097, 50, 15, False),
+                                          (64, 20000, 50, 15, False), (300, 6000, 100, 50, True),
+                                          (200, 3000, 128, 30, False)])
+def test_cosine_knn_vs_oracle(gpu_lib, m, n, g, k, drop):
+    Y = pca_like(n, g, seed=3000 + n + g)
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=4000 + m + g)
+    gi, gd = gpu_lib.knn(X, Y, k, metric=2, drop_first=drop)
+    oi, od = oracle.knn(X, Y, k, 2, drop_first=drop, nthreads=8)
+    _check(gi, gd, oi, od)
+
+
+def test_cosine_is_scale_free_and_handles_zero_rows_masks_and_duplicates(gpu_lib):
+    rng = np.random.default_rng(21)
+    n, m, g, k = 5000, 300, 40, 15
+    Y = pca_like(n, g, seed=77) * np.exp(rng.uniform(-6, 6, (n, 1)))      # wildly different row lengths
+    X = pca_like(m, g, seed=78) * np.exp(rng.uniform(-6, 6, (m, 1)))
+    Y[10] = 0.0
+    Y[11] = 0.0
+    X[5] = 0.0                               # zero target: every distance is 1 -> index order, exact path
+    Y[200:216] = Y[100] * np.arange(1, 17)[:, None]       # 16 parallel copies: exact ties in angle
+    X[7] = Y[100] * 0.5
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[::5] = 1
+    ix = gpu_lib.KnnIndex(n, g, metric=2).set_ref(Y, ref_mask=mask)
+    gi, gd = ix.query(X, k)
+    st = ix.last_stats()
+    ix.close()
+    oi, od = oracle.knn(X, Y, k, 2, ref_mask=mask, nthreads=8)
+    _check(gi, gd, oi, od)
+    assert st["fallback_rows"] >= 1          # the zero row cannot be certified by the filter
+    assert st["fallback_rows"] < m // 4      # ... but ordinary rows are
+
+
+def test_cosine_config5_shape_sampled(gpu_lib):
+    """BASELINE configs[4] shape (d=100, k=50, cosine) at 200k references; a row sample against the oracle."""
+    n, g, k = 200000, 100, 50
+    Y = pca_like(n, g, seed=5005)
+    ix = gpu_lib.KnnIndex(n, g, metric=2).set_ref(Y)
+    gi, gd = ix.query(Y[:20000], k, drop_first=True)
+    st = ix.last_stats()
+    ix.close()
+    rows = np.random.default_rng(1).choice(20000, 64, replace=False)
+    oi, od = oracle.knn(Y[rows], Y, k, 2, drop_first=True, nthreads=8)
+    _check(gi[rows], gd[rows], oi, od)
+    assert st["fallback_rows"] < 200
