@@ -68,8 +68,16 @@ hipError_t cbf_pack_refs_launch(const double *Y, int64_t n, int g, int gp, float
                                 hipStream_t st);
 int cbf_pick_gp(int g);
 void cbf_constants(int g, float *slack, float *plateau);
-hipError_t cbf_filter_launch(int gp, int epl, const float *xq, int64_t m, const float *ycf, int64_t n, int g,
-                             const uint8_t *mask, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st);
+int cbf_lists_per_split();
+int cbf_rows_per_wg(int epl);
+hipError_t cbf_filter_launch(int gp, int epl, const float *xq, const void *xh, int64_t m, const float *ycf,
+                             const void *ych, int64_t n, int g, const uint8_t *mask, int S, uint32_t *cand_idx,
+                             float *cand_tau, hipStream_t st);
+hipError_t cbf_pack_refs_rows_launch(const double *Y, int64_t n, int g, int gp, float *yrow, hipStream_t st);
+hipError_t cbf_colmax_launch(const double *Y, int64_t n, int g, unsigned int *colmax, hipStream_t st);
+hipError_t cbf_pack_refs16_launch(const double *Y, int64_t n, int g, int gp, const double *scale, void *ych, hipStream_t st);
+hipError_t cbf_pack_targets16_launch(const double *X, int64_t m, int g, int gp, double f, const double *scale, void *xh,
+                                     hipStream_t st);
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
 hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
                                int64_t *out_idx, double *out_dist, hipStream_t st);
@@ -179,7 +187,7 @@ struct nabo_index {
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
     double ymax_sqrt = 0.0, ymax_sqrt_h = 0.0;
     // Canberra path: exact kernel operands (yt) and the fp32 lower-bound filter's (ycf)
-    DevBuf yt, ycf, cbflag;
+    DevBuf yt, ycf, yrow, cbflag, ych, cbscale, xh;    // ych/xh: packed f16 operands of the counting pass, cbscale [g] doubles
     int cb_gp = 0;
     bool cb_f32 = false;          // filter usable for these references (fits fp32, g <= 128)
 
@@ -297,7 +305,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->cbflag, &ix->xfail, &ix->tmpi, &ix->tmpd,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -368,13 +376,39 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         const char *cm = getenv("NABO_CANBERRA_MODE");
         if (ix->cb_gp > 0 && !(cm && strcmp(cm, "exact") == 0)) {
             unsigned int flag = 0;
-            if ((rc = ix->ycf.reserve((size_t)chunks * 64 * ix->cb_gp * sizeof(float)))) return rc;
+            if ((rc = ix->ycf.reserve((size_t)chunks * 64 * ix->cb_gp * sizeof(float)))) return rc;      // chunk-major (range check)
+            if ((rc = ix->yrow.reserve((size_t)ix->n * ix->cb_gp * sizeof(float)))) return rc;           // row-major (bound pass)
             if ((rc = ix->cbflag.reserve(4 * sizeof(unsigned int)))) return rc;
             HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
             HIP_TRY(nabo::cbf_pack_refs_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->ycf.as<float>(), ix->cbflag.as<unsigned int>(), st));
             HIP_TRY(hipMemcpyAsync(&flag, ix->cbflag.p, sizeof(flag), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             ix->cb_f32 = (flag == 0);
+            if (ix->cb_f32) {
+                // per-dimension power-of-two scales for the f16 counting pass: max |s_k y_k| in (2^13, 2^14]
+                std::vector<unsigned int> cm((size_t)ix->g, 0u);
+                std::vector<double> sc((size_t)ix->g, 1.0);
+                if ((rc = ix->cbscale.reserve((size_t)ix->g * sizeof(double)))) return rc;
+                HIP_TRY(hipMemsetAsync(ix->cbscale.p, 0, (size_t)ix->g * sizeof(unsigned int), st));
+                HIP_TRY(nabo::cbf_colmax_launch(ix->dY, ix->n, ix->g, ix->cbscale.as<unsigned int>(), st));
+                HIP_TRY(hipMemcpyAsync(cm.data(), ix->cbscale.p, (size_t)ix->g * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                for (int k = 0; k < ix->g; ++k) {
+                    float mx;
+                    memcpy(&mx, &cm[k], sizeof(mx));
+                    if (mx > 0.0f && std::isfinite(mx)) {
+                        int e = 14 - (int)std::ceil(std::log2((double)mx) + 1e-9);
+                        if (e > 120) e = 120;
+                        if (e < -120) e = -120;
+                        sc[k] = std::ldexp(1.0, e);
+                    }
+                }
+                HIP_TRY(hipMemcpyAsync(ix->cbscale.p, sc.data(), (size_t)ix->g * sizeof(double), hipMemcpyHostToDevice, st));
+                if ((rc = ix->ych.reserve((size_t)chunks * 64 * ix->cb_gp * 2))) return rc;
+                HIP_TRY(nabo::cbf_pack_refs_rows_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->yrow.as<float>(), st));
+                HIP_TRY(nabo::cbf_pack_refs16_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
+                HIP_TRY(hipStreamSynchronize(st));      // sc goes out of scope
+            }
         }
         HIP_TRY(hipStreamSynchronize(st));
     }
@@ -603,22 +637,57 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (S > 16) S = 16;
         if (S < 1) S = 1;
         bool done = false;
+        const int S_exact = S;
         if (ix->cb_f32 && n_valid >= kk) {
             // fp32 lower-bound filter -> float64 refine + certification -> exact re-solve of uncertified rows
             float slack, plateau;
             nabo::cbf_constants(g, &slack, &plateau);
+            // filter geometry: T rows per workgroup, 2 workgroups per CU resident; every (row, split) ends
+            // with `lists` candidate lists (one per wave).  Splits fill the chip when there are few rows and
+            // trim the last, partially filled round of workgroups when there are many.
+            const int lists = nabo::cbf_lists_per_split();
+            const int64_t gxf = (m + nabo::cbf_rows_per_wg(epl) - 1) / nabo::cbf_rows_per_wg(epl);
+            const int64_t slots = (int64_t)ix->n_cu * 8;                 // one-wave workgroups, 2 per SIMD
+            int Sf = env_int("NABO_SPLITS", 0);
+            int s_max = 1024 / (lists * L);                   // refine handles <= 1024 candidates per row
+            if (s_max > n_chunks / (8 * lists)) s_max = (int)(n_chunks / (8 * lists));
+            if (s_max < 1) s_max = 1;
+            if (Sf <= 0) {
+                Sf = 1;
+                double best = 1e30;
+                for (int s2 = 1; s2 <= s_max; ++s2) {
+                    // full-length rounds of workgroups, and ~8 % more bound evaluations per extra split
+                    // (every list warms up on its own): measured on 100k x 100k, d = 50
+                    const double cost = (double)((gxf * s2 + slots - 1) / slots) / s2 * (1.0 + 0.08 * (s2 - 1));
+                    if (cost < best - 1e-9) { best = cost; Sf = s2; }
+                }
+            }
+            if (Sf > s_max) Sf = s_max;
+            S = Sf;
+            const int SL = Sf * lists;
             if ((rc = ix->xpk.reserve((size_t)m * ix->cb_gp * 2 * sizeof(float)))) return rc;
-            if ((rc = ix->cand_idx.reserve((size_t)m * S * L * sizeof(uint32_t)))) return rc;
-            if ((rc = ix->cand_tau.reserve((size_t)m * S * sizeof(float)))) return rc;
+            if ((rc = ix->xh.reserve((size_t)m * ix->cb_gp * 4))) return rc;
+            if ((rc = ix->cand_idx.reserve((size_t)m * SL * L * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->cand_tau.reserve((size_t)m * SL * sizeof(float) + 16))) return rc;
             if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
+            const bool dbg_counts = (env_int("NABO_DEBUG_ABLATE", 0) & 4) != 0;
+            if (dbg_counts) HIP_TRY(hipMemsetAsync(ix->cand_tau.as<float>() + (size_t)m * SL, 0, 8, st));
             HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
             unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();
             HIP_TRY(nabo::cbf_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->xpk.as<float>(), d_flag, st));
+            HIP_TRY(nabo::cbf_pack_targets16_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbscale.as<double>(), ix->xh.p, st));
             HIP_TRY(hipEventRecord(ix->ev[1], st));
-            HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), m, ix->ycf.as<float>(), ix->n, g,
-                                            ix->dmask, S, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), st));
+            HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), ix->xh.p, m, ix->yrow.as<float>(), ix->ych.p,
+                                            ix->n, g, ix->dmask, Sf, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), st));
             HIP_TRY(hipEventRecord(ix->ev[2], st));
-            HIP_TRY(nabo::refine_launch(dX, 0, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
+            if (dbg_counts) {
+                unsigned int c2[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(c2, ix->cand_tau.as<float>() + (size_t)m * SL, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                fprintf(stderr, "[nabo debug] canberra filter: splits=%d survivors=%u (%.1f per row) batches=%u\n", Sf, c2[0],
+                        (double)c2[0] / (double)m, c2[1]);
+            }
+            HIP_TRY(nabo::refine_launch(dX, 0, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), SL, L,
                                         nullptr, 0.0, 0.0, 1.0, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(), d_failcnt, st, 1,
                                         ix->f, plateau));
@@ -655,6 +724,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             }
         }
         if (!done) {
+            S = S_exact;
             if ((rc = ix->cand_d.reserve((size_t)m * S * L * sizeof(double)))) return rc;
             if ((rc = ix->cand_idx.reserve((size_t)m * S * L * sizeof(uint32_t)))) return rc;
             HIP_TRY(hipEventRecord(ix->ev[1], st));

@@ -14,6 +14,8 @@
 //   nlb = max(|x32 - y32| - s * 2^-22, 0)                        <= |x - y|            (exact value)
 //   thr = fl32up(f) * (|x32| * (1 + 2^-22) + 2^-124) + 1 ulp      >= fl64(f * |x|)      (reference threshold)
 //   nlb >= thr  =>  the reference's test `num < f*|x|` is false  =>  both add exactly 1
+//   (the kernel tests the slightly stronger, s-free condition |fl32(x32 - y32)| >= thr2, see the pack kernel,
+//    so that a 3-instruction counting pass can decide "definitely out" on its own)
 //   otherwise the reference adds either q = num/den (< 1 for f <= 1 ... any f: we take min(.,1)) or 1, and
 //   qlb = nlb * rcp(fma(s, 1 + 2^-21 + 2^-22, 0.01 * (1 + 2^-21)))  <= fl64(num / den)   (< 1 always)
 //   term = (nlb >= thr) ? 1 : qlb                                 <= the reference's term
@@ -24,13 +26,13 @@
 // pack kernels and the caller falls back to the exact kernel.
 //
 // Layout: lane = reference (64 per chunk, values resident in VGPRs for the whole chunk), target row =
-// wave-uniform (its (x32, thr) pairs arrive through the scalar cache); each wave owns T targets and their
-// candidate lists (fp32 key + u32 index) in LDS.
+// wave-uniform (its packed operands are LDS broadcasts); each wave owns T targets and their candidate lists
+// (fp32 key + u32 index) in LDS.  See cbf_filter_kernel for the count / compact / bound structure.
+#include <cstdlib>
 #include "knn_common.h"
 
 namespace nabo {
 
-constexpr int CBF_T = 8;     // targets per wave
 
 // targets: xq[row][k] = (x32, thr); references: ycf[chunk][k][64] = y32
 // *flag is set when a value does not fit fp32 comfortably (|v| > 1e37 or non-finite): the bound's
@@ -52,7 +54,10 @@ __global__ void cbf_pack_targets_kernel(const double *__restrict__ X, int64_t m,
     float f32 = (float)f;
     if ((double)f32 < f) f32 = __uint_as_float(__float_as_uint(f32) + 1);
     const float thr = f32 * (fabsf(x32) * (1.0f + 2.384185791015625e-07f) + 4.70197740328915e-38f);
-    xq[e] = make_float2(x32, __uint_as_float(__float_as_uint(thr) + 1u));
+    // thr2: |fl32(x32 - y32)| >= thr2 implies nlb >= thr WITHOUT looking at s = |x32|+|y32| (header):
+    // s <= (2|x32| + |d|)(1 + 2^-23), so nlb >= |d|(1 - 2.6e-7) - 5.2e-7 |x32|; the factors below are generous
+    const float thr2 = (__uint_as_float(__float_as_uint(thr) + 1u) + 6e-07f * fabsf(x32)) * 1.000001f;
+    xq[e] = make_float2(x32, __uint_as_float(__float_as_uint(thr2) + 1u));
 }
 
 __global__ void cbf_pack_refs_kernel(const double *__restrict__ Y, int64_t n, int g, int gp, float *__restrict__ ycf,
@@ -66,6 +71,99 @@ __global__ void cbf_pack_refs_kernel(const double *__restrict__ Y, int64_t n, in
         if (!(fabsf(v) <= 1e37f)) atomicOr(flag, 1u);
         ycf[(chunk * gp + k) * 64 + lane] = v;
     }
+}
+
+// ---- f16 operands of the counting pass ---------------------------------------------------------------
+// The counting pass only has to PROVE "this dimension is out of window" for as many dimensions as it can; what
+// it cannot prove merely counts as 0.  That tolerates half precision, which buys packed arithmetic (two
+// dimensions per instruction) and four reference chunks per register set.  Every dimension k is scaled by a
+// power of two s_k (exact) chosen from the references so that max_j |s_k y_jk| lies in (2^13, 2^14]:
+//   y' = fl16(s_k y),  x' = fl16(s_k x)          relative error u = 2^-11, absolute 2^-25 below the normal range
+//   d' = fl16(x' - y'),  the kernel counts the dimension when |d'| > thr'.
+// With delta = x' - y' (exact): |d'| <= |delta| (1+u);  s|x-y| >= |delta| - u s (|x|+|y|) - 2 eta and
+// |y| <= |x| + |x-y| give  s |x-y| (1+u) >= |delta| - 2 u s |x| - 2 eta.  So with  T+ = fl64(f |x|) (1 + 2^-52)
+// (the reference's own threshold, padded for the rounding of its fl64 |x-y|),
+//   thr' = roundup16( (1+u) ( s T+ (1+u) + 2 u s |x| + 2 eta ) + eta )
+// guarantees  |d'| >= thr'  =>  |x-y| >= T+  =>  the reference's `num < f*|x|` is false: the dimension adds 1.
+// x' or thr' beyond the f16 range become +inf and the dimension is never counted.
+typedef _Float16 cbf_h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t cbf_f16_up(double v)          // smallest f16 >= v (v >= 0), as bits
+{
+    if (!(v < 65504.0)) return 0x7C00u;
+    _Float16 h = (_Float16)v;                                     // round to nearest
+    uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, h);
+    if ((double)h < v) ++b;                                       // next representable (0x7BFF + 1 = inf)
+    return b;
+}
+
+// per-dimension max |y| (bits of a non-negative float order like unsigned integers)
+__global__ void cbf_colmax_kernel(const double *__restrict__ Y, int64_t n, int g, unsigned int *__restrict__ colmax)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * g) return;
+    const float v = fabsf((float)Y[e]);
+    if (v > 0.0f) atomicMax(&colmax[e % g], __float_as_uint(v < 3e38f ? v : 3e38f));
+}
+
+// refs: ych[chunk][p][64] = half2(y'_{2p}, y'_{2p+1}); targets: xh[row][p] = (half2 x', half2 thr')
+__global__ void cbf_pack_refs16_kernel(const double *__restrict__ Y, int64_t n, int g, int gp,
+                                       const double *__restrict__ scale, uint32_t *__restrict__ ych)
+{
+    const int64_t chunk = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t j = chunk * 64 + lane;
+    for (int p = threadIdx.x >> 6; p < gp / 2; p += (blockDim.x >> 6)) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * p + h;
+            double v = (j < n && k < g) ? Y[j * g + k] * scale[k] : 0.0;
+            if (!(fabs(v) < 65000.0)) v = v > 0 ? 65000.0 : (v < 0 ? -65000.0 : 0.0);   // cannot happen for finite input
+            w |= (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v) << (16 * h);
+        }
+        ych[(chunk * (gp / 2) + p) * 64 + lane] = w;
+    }
+}
+
+__global__ void cbf_pack_targets16_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
+                                          const double *__restrict__ scale, uint2 *__restrict__ xh)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * (gp / 2)) return;
+    const int64_t row = e / (gp / 2);
+    const int p = (int)(e - row * (gp / 2));
+    const double u = 4.8828125e-4, eta = 2.98023223876953125e-8;                   // 2^-11, 2^-25
+    uint32_t xw = 0, tw = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int k = 2 * p + h;
+        uint32_t xb = 0, tb = 0x7C00u;                                             // padding: x' = 0, thr' = +inf
+        if (k < g) {
+            const double x = X[row * g + k], sc = scale[k];
+            const double sx = x * sc;
+            if (fabs(sx) < 65000.0) {
+                xb = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)sx);
+                const double tp = (f * fabs(x)) * (1.0 + 2.3e-16);                   // T+
+                const double thr = (1.0 + u) * (sc * tp * (1.0 + u) + 2.0 * u * fabs(sx) + 2.0 * eta) + eta;
+                tb = cbf_f16_up(thr * (1.0 + 1e-12));
+            }                                                                       // else: x' = 0 with thr' = inf (never counted)
+        }
+        xw |= xb << (16 * h);
+        tw |= tb << (16 * h);
+    }
+    xh[e] = make_uint2(xw, tw);
+}
+
+// row-major fp32 copy of the references ([n][gp], zero padded) for the bound pass: a lane that evaluates one
+// (target, reference) pair reads both rows with 16-byte loads instead of one 4-byte gather per dimension
+__global__ void cbf_pack_refs_rows_kernel(const double *__restrict__ Y, int64_t n, int g, int gp, float *__restrict__ yrow)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * gp) return;
+    const int64_t j = e / gp;
+    const int k = (int)(e - j * gp);
+    yrow[e] = k < g ? (float)Y[j * g + k] : 0.0f;
 }
 
 template <int EPL>
@@ -89,100 +187,210 @@ __device__ __forceinline__ float cbf_compact(float *kb, uint32_t *ib, int count,
     return __shfl(key[(L - 1) >> 6], (L - 1) & 63, 64);
 }
 
-// grid.x = ceil(m / (4*T)), grid.y = S splits of `chunks_per_split` 64-reference chunks.
-// GP >= g: padded dimensionality (register array for one chunk of references; the wave's T target rows
-// sit in LDS for the whole kernel and are read back as broadcasts).
-template <int GP, int EPL>
-__global__ __launch_bounds__(256) void cbf_filter_kernel(const float2 *__restrict__ xq, int64_t m,
-                                                         const float *__restrict__ ycf, int64_t n, int g,
-                                                         const uint8_t *__restrict__ mask, int64_t n_chunks,
-                                                         int64_t chunks_per_split, float slack, float plateau,
-                                                         uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau)
+// grid.x = ceil(m / T), grid.y = S splits of `chunks_per_split` 64-reference chunks; one wave per workgroup.
+// Each WAVE owns T target rows and their candidate lists (LDS, wave-private: no barriers anywhere) and
+// streams the split's references past them: NCH chunks of 64 references (lane = reference) are resident in
+// VGPRs per step as packed f16 pairs.  The targets' packed (x', thr') pairs sit in the wave's LDS and are read
+// back as broadcasts (one ds_read_b64 per two dimensions and NCH chunks).
+//
+// Two passes:
+//   1. COUNT, packed f16, 2 VALU per pair and dimension (v_pk_add_f16, v_and, v_pk_add_f16 clamp, v_dot2c per
+//      TWO dimensions): acc = sum_k clamp(|x'-y'| - thr', 0, 1) <= number of dimensions PROVEN out of window
+//      (see the pack kernels).  Each of those adds exactly 1 to the reference's distance and the others add
+//      >= 0, so distance >= acc; a pair whose acc already reaches the row's threshold is dropped here (all but
+//      ~1e-3 of the pairs once the lists have warmed up).
+//   2. BOUND (the fp32 ~15-slot divide-and-accumulate expression) only for the survivors, which are compacted
+//      through a wave-private work list so that all 64 lanes of a batch carry a live pair: lane p takes pair
+//      (t_p, j_p) and gathers x and y from the packed fp32 arrays (16-byte loads from the row-major fp32 copies; rare).
+template <int GP, int EPL, int T, int NCH>
+__global__ __launch_bounds__(64, 2)
+void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ xh, int64_t m,
+                       const float *__restrict__ yrow, const uint32_t *__restrict__ ych, int64_t n, int g,
+                       const uint8_t *__restrict__ mask, int64_t n_chunks, int64_t chunks_per_split, float slack,
+                       float plateau, uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau, int dbg)
 {
-    constexpr int CAP = 64 * EPL, L = 32 * EPL, T = CBF_T;
+    constexpr int L = 32 * EPL, CAP = L + 16 * EPL;     // kept + pending entries per list
+    constexpr int GH = GP / 2;           // packed dimension pairs
+    constexpr int GHS = GH + 1;          // LDS row stride (uint2): spreads the T rows over the banks
+    constexpr int WLN = 512;             // work-list ring (entries); >= 63 + 64 * NCH
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // per wave: xs [T][GP] float2 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | cnt [T] i32
-    constexpr size_t WAVE_BYTES = (size_t)T * GP * 8 + (size_t)T * CAP * 8 + T * 8;
-    unsigned char *wb = smem_raw + (size_t)wave * WAVE_BYTES;
-    float2 *xs = reinterpret_cast<float2 *>(wb);
-    float *keys = reinterpret_cast<float *>(xs + T * GP);
+    // one wave per workgroup (nothing is shared between waves; small workgroups pack the CU's LDS better):
+    //   xs [T][GHS] uint2 (f16 count operands) | xf [T][GPS] float2 (fp32 bound operands) |
+    //   keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | cnt [T] i32 | wl_j [WLN] u32 | wl_t [WLN] u8
+    constexpr int GPS = GP + 1;
+    unsigned char *wb = smem_raw;
+    uint2 *xs = reinterpret_cast<uint2 *>(wb);
+    float2 *xf = reinterpret_cast<float2 *>(xs + T * GHS);
+    float *keys = reinterpret_cast<float *>(xf + T * GPS);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
     float *tau = reinterpret_cast<float *>(idxs + T * CAP);
     int *cnt = reinterpret_cast<int *>(tau + T);
+    uint32_t *wl = reinterpret_cast<uint32_t *>(cnt + T);
+    unsigned char *wl_t = reinterpret_cast<unsigned char *>(wl + WLN);
 
     const int S = gridDim.y;
     const int split = blockIdx.y;
-    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * T;
-    if (lane < T) { tau[lane] = __builtin_inff(); cnt[lane] = 0; }
+    const int64_t row0 = (int64_t)blockIdx.x * T;
+    if (row0 >= m) return;                                   // (no barriers in this kernel)
+    for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); cnt[e] = 0; }
+    for (int e = lane; e < T * GH; e += 64) {
+        const int64_t row = row0 + e / GH;
+        xs[(e / GH) * GHS + e % GH] = row < m ? xh[row * GH + e % GH] : make_uint2(0u, 0x7C007C00u);
+    }
     for (int e = lane; e < T * GP; e += 64) {
         const int64_t row = row0 + e / GP;
-        xs[e] = row < m ? xq[row * GP + e % GP] : make_float2(0.0f, __builtin_inff());
+        xf[(e / GP) * GPS + e % GP] = row < m ? xq[row * GP + e % GP] : make_float2(0.0f, __builtin_inff());
     }
     // (wave-private LDS: DS operations of one wave execute in order, no barrier needed)
     const float below_plateau = __uint_as_float(__float_as_uint(plateau) - 1u);     // plateau > 0
+    int t_cnt = T;                                            // live target rows of this wave
+    if (row0 + T > m) t_cnt = (int)(m - row0);
 
-    const int64_t c_begin = split * chunks_per_split;
-    int64_t c_end = c_begin + chunks_per_split;
-    if (c_end > n_chunks) c_end = n_chunks;
-    for (int64_t chunk = c_begin; chunk < c_end; ++chunk) {
-        const int64_t j = chunk * 64 + lane;
-        const bool valid = (j < n) && !(mask && mask[j]);
-        float yv[GP];
+    int wl_head = 0, wl_n = 0;                               // wave-uniform ring state
+
+    // Pass 2 for `nb` (<= 64) work-list entries starting at wl_head: lane p evaluates the bound of pair
+    // (t_p, j_p); x from the wave's fp32 LDS rows, y from the row-major fp32 references (one burst of 16-byte loads).
+    auto drain = [&](int nb) {
+        const bool act = lane < nb;
+        const int slot = (wl_head + lane) & (WLN - 1);
+        const uint32_t j = act ? wl[slot] : 0u;
+        const uint32_t e = act ? (uint32_t)wl_t[slot] : 0u;
+        wl_head = (wl_head + nb) & (WLN - 1);
+        wl_n -= nb;
+        if ((dbg & 4) && lane == 0) {                       // experiments: survivors / batches of the whole launch
+            unsigned int *ctr = reinterpret_cast<unsigned int *>(cand_tau + m * gridDim.y);
+            atomicAdd(ctr, (unsigned int)nb);
+            atomicAdd(ctr + 1, 1u);
+        }
+        const int t_p = (int)(e & 0xFFu);
+        const float2 *xp = xf + t_p * GPS;                                               // LDS, lane-varying row
+        const float4 *yp = reinterpret_cast<const float4 *>(yrow + (int64_t)j * GP);     // 4 dimensions per 16 bytes
+        float lb = 0.0f;
+        int no_p = 0;
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {                     // two bursts of GP/8 sixteen-byte loads (register budget)
+            float4 yy[GP / 8];
 #pragma unroll
-        for (int k = 0; k < GP; ++k) yv[k] = ycf[(chunk * GP + k) * 64 + lane];
-        for (int t = 0; t < T; ++t) {
-            const int64_t row = row0 + t;
-            if (row >= m) break;
-            const float2 *xr = xs + t * GP;               // same address in every lane: LDS broadcast
-            float lb = 0.0f;
-            int n_out = 0;
+            for (int q = 0; q < GP / 8; ++q) yy[q] = yp[hf * (GP / 8) + q];
+            const float2 *xph = xp + hf * (GP / 2);
 #pragma unroll
-            for (int k = 0; k < GP; ++k) {
-                const float2 xt = xr[k];
-                const float s = fabsf(xt.x) + fabsf(yv[k]);
-                const float nlb = fmaxf(__builtin_fmaf(s, -2.5e-07f, fabsf(xt.x - yv[k])), 0.0f);   // 2.5e-7 > 2^-22
+            for (int k = 0; k < GP / 2; ++k) {
+                const float2 xt = xph[k];
+                const float4 y4 = yy[k >> 2];
+                const float y = (k & 3) == 0 ? y4.x : (k & 3) == 1 ? y4.y : (k & 3) == 2 ? y4.z : y4.w;
+                const float s = fabsf(xt.x) + fabsf(y);
+                const float ad = fabsf(xt.x - y);
+                const float nlb = fmaxf(__builtin_fmaf(s, -2.5e-07f, ad), 0.0f);   // 2.5e-7 > 2^-22
                 // den >= (|x|+|y|+0.01) * (1 + 2^-21): the surplus pays for v_rcp_f32 (1 ulp) and the multiply;
                 // nlb <= s < den, so q < 1 without a clamp
                 const float den = __builtin_fmaf(s, 1.00000072f, 0.01000002f);
                 const float q = nlb * __builtin_amdgcn_rcpf(den);
-                const bool out = nlb >= xt.y;
-                n_out += out ? 1 : 0;
+                const bool out = ad >= xt.y;
+                no_p += out ? 1 : 0;
                 lb += out ? 1.0f : q;
             }
-            const float key = (n_out == g) ? plateau : fminf(lb - slack, below_plateau);
-            bool pend = valid && (key < tau[t]);
+        }
+        const float key = (no_p == g) ? plateau : fminf(lb - slack, below_plateau);
+        const bool hit = act && (key < tau[t_p]);
+        if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+        for (int t2 = 0; t2 < t_cnt; ++t2) {
+            bool pend = hit && (t_p == t2);
             uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
             while (pm != 0) {
-                const int c = cnt[t];
+                const int c = cnt[t2];
                 const int room = CAP - c;
                 if (room == 0) {
                     float kr[EPL];
                     uint32_t vr[EPL];
-                    const float nt = cbf_compact<EPL>(keys + t * CAP, idxs + t * CAP, c, kr, vr);
-                    if (lane == 0) { tau[t] = nt; cnt[t] = L; }
+                    const float nt = cbf_compact<EPL>(keys + t2 * CAP, idxs + t2 * CAP, c, kr, vr);
+                    if (lane == 0) { tau[t2] = nt; cnt[t2] = L; }
                     pend = pend && (key < nt);
                 } else {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                     const bool take = pend && rank < room;
                     if (take) {
-                        keys[t * CAP + c + rank] = key;
-                        idxs[t * CAP + c + rank] = (uint32_t)j;
+                        keys[t2 * CAP + c + rank] = key;
+                        idxs[t2 * CAP + c + rank] = j;
                     }
                     const int np = __popcll(pm);
-                    if (lane == 0) cnt[t] = c + (np < room ? np : room);
+                    if (lane == 0) cnt[t2] = c + (np < room ? np : room);
                     pend = pend && !take;
                 }
                 pm = __builtin_amdgcn_ballot_w64(pend);
             }
         }
+    };
+
+    const int64_t c_begin = split * chunks_per_split;
+    int64_t c_end = c_begin + chunks_per_split;
+    if (c_end > n_chunks) c_end = n_chunks;
+    const cbf_h2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
+    const float gf = (float)g;
+    for (int64_t chunk0 = c_begin; chunk0 < c_end; chunk0 += NCH) {
+        cbf_h2 yv[NCH][GH];
+        bool valid[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int64_t chunk = chunk0 + c;
+            const int64_t j = chunk * 64 + lane;
+            valid[c] = (chunk < c_end) && (j < n) && !(mask && mask[j]);
+#pragma unroll
+            for (int p = 0; p < GH; ++p)
+                yv[c][p] = __builtin_bit_cast(cbf_h2, (chunk < c_end) ? ych[(chunk * GH + p) * 64 + lane] : 0u);
+        }
+
+        for (int t = 0; t < t_cnt; ++t) {
+            const uint2 *xr = xs + t * GHS;               // same address in every lane: LDS broadcast
+            float acc[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[c] = 0.0f;
+#pragma unroll
+            for (int p = 0; p < GH; ++p) {
+                const uint2 xt = xr[p];
+                const cbf_h2 xv = __builtin_bit_cast(cbf_h2, xt.x);
+                const cbf_h2 th = __builtin_bit_cast(cbf_h2, xt.y);
+                cbf_h2 d[NCH], ind[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) d[c] = xv - yv[c][p];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+                    d[c] = __builtin_bit_cast(cbf_h2, __builtin_bit_cast(uint32_t, d[c]) & 0x7FFF7FFFu);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    ind[c] = d[c] - th;                                                       // +inf - +inf = NaN -> 0
+                    ind[c] = __builtin_elementwise_min(__builtin_elementwise_max(ind[c], (cbf_h2){0, 0}), one2);
+                }
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_fdot2(ind[c], one2, acc[c], false);
+            }
+            const float tau_t = tau[t];
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                // acc <= proven-out dimensions (fp32 sum of g terms in [0,1]: rounding < 1e-3).  acc == g exactly
+                // only when every dimension counted fully: then the distance is exactly g (plateau key).
+                const float pre = (acc[c] == gf) ? plateau : fminf(acc[c] - 1e-3f - slack, below_plateau);
+                const bool surv = valid[c] && (pre < tau_t) && !(dbg & 1);
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(surv);
+                if (bm != 0) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                    if (surv) {
+                        const int slot = (wl_head + wl_n + rank) & (WLN - 1);
+                        wl[slot] = (uint32_t)((chunk0 + c) * 64 + lane);
+                        wl_t[slot] = (unsigned char)t;
+                    }
+                    wl_n += __popcll(bm);
+                }
+            }
+            while (wl_n >= 64) drain(64);
+        }
     }
+    while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);
     // flush: the L smallest (key, index) per target; tau = L-th key if anything was ever dropped
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < t_cnt; ++t) {
         const int64_t row = row0 + t;
-        if (row >= m) break;
         float kr[EPL];
         uint32_t vr[EPL];
         const int c = cnt[t];
@@ -233,31 +441,77 @@ void cbf_constants(int g, float *slack, float *plateau)
     *plateau = (float)g - s;
 }
 
+// lists written per (target row, split): the caller sizes cand_idx / cand_tau and tells refine
+int cbf_lists_per_split() { return 1; }
+
+constexpr int cbf_t_rows(int epl) { return epl == 1 ? 16 : 8; }     // target rows per wave
+
 template <int GP, int EPL>
-static hipError_t cbf_launch_one(const float *xq, int64_t m, const float *ycf, int64_t n, int g, const uint8_t *mask,
-                                 int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st)
+static hipError_t cbf_launch_one(const float *xq, const void *xh, int64_t m, const float *ycf, const void *ych, int64_t n,
+                                 int g, const uint8_t *mask, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st)
 {
+    constexpr int T = cbf_t_rows(EPL);
+    constexpr int NCH = GP <= 64 ? 4 : GP <= 96 ? 2 : 1;      // reference chunks resident in VGPRs (GP/2 registers each)
+    constexpr int L = 32 * EPL, CAP = L + 16 * EPL;
     const int64_t n_chunks = (n + 63) / 64;
     const int64_t cps = (n_chunks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = 4 * ((size_t)CBF_T * GP * 8 + (size_t)CBF_T * (64 * EPL) * 8 + CBF_T * 8);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&cbf_filter_kernel<GP, EPL>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = (size_t)T * (GP / 2 + 1) * 8 + (size_t)T * (GP + 1) * 8 + (size_t)T * CAP * 8 + (size_t)T * 8 + 512 * 5;
+    auto kern = &cbf_filter_kernel<GP, EPL, T, NCH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)((m + 4 * CBF_T - 1) / (4 * CBF_T)), S), block(256);
-    hipLaunchKernelGGL((cbf_filter_kernel<GP, EPL>), grid, block, lds, st, reinterpret_cast<const float2 *>(xq), m, ycf, n,
-                       g, mask, n_chunks, cps, slack, plateau, cand_idx, cand_tau);
+    dim3 grid((unsigned)((m + T - 1) / T), S), block(64);
+    const char *dbg = getenv("NABO_DEBUG_ABLATE");          // timing experiments only (results are garbage)
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const float2 *>(xq),
+                       reinterpret_cast<const uint2 *>(xh), m, ycf, reinterpret_cast<const uint32_t *>(ych), n, g, mask,
+                       n_chunks, cps, slack, plateau, cand_idx, cand_tau, dbg ? atoi(dbg) : 0);
     return hipGetLastError();
 }
 
-hipError_t cbf_filter_launch(int gp, int epl, const float *xq, int64_t m, const float *ycf, int64_t n, int g,
-                             const uint8_t *mask, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st)
+// target rows per workgroup (the caller's split heuristic needs it)
+int cbf_rows_per_wg(int epl) { return epl == 1 ? cbf_t_rows(1) : cbf_t_rows(2); }
+
+hipError_t cbf_colmax_launch(const double *Y, int64_t n, int g, unsigned int *colmax, hipStream_t st)
+{
+    const int64_t tot = n * g;
+    hipLaunchKernelGGL(cbf_colmax_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Y, n, g, colmax);
+    return hipGetLastError();
+}
+
+hipError_t cbf_pack_refs_rows_launch(const double *Y, int64_t n, int g, int gp, float *yrow, hipStream_t st)
+{
+    const int64_t tot = n * gp;
+    hipLaunchKernelGGL(cbf_pack_refs_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Y, n, g, gp, yrow);
+    return hipGetLastError();
+}
+
+hipError_t cbf_pack_refs16_launch(const double *Y, int64_t n, int g, int gp, const double *scale, void *ych, hipStream_t st)
+{
+    const int64_t chunks = (n + 63) / 64;
+    hipLaunchKernelGGL(cbf_pack_refs16_kernel, dim3((unsigned)chunks), dim3(256), 0, st, Y, n, g, gp, scale,
+                       reinterpret_cast<uint32_t *>(ych));
+    return hipGetLastError();
+}
+
+hipError_t cbf_pack_targets16_launch(const double *X, int64_t m, int g, int gp, double f, const double *scale, void *xh,
+                                     hipStream_t st)
+{
+    const int64_t tot = m * (gp / 2);
+    hipLaunchKernelGGL(cbf_pack_targets16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, m, g, gp, f,
+                       scale, reinterpret_cast<uint2 *>(xh));
+    return hipGetLastError();
+}
+
+hipError_t cbf_filter_launch(int gp, int epl, const float *xq, const void *xh, int64_t m, const float *ycf,
+                             const void *ych, int64_t n, int g, const uint8_t *mask, int S, uint32_t *cand_idx,
+                             float *cand_tau, hipStream_t st)
 {
 #define NABO_CBF(GPV)                                                                                          \
     case GPV:                                                                                                  \
-        return epl == 1 ? cbf_launch_one<GPV, 1>(xq, m, ycf, n, g, mask, S, cand_idx, cand_tau, st)            \
-                        : cbf_launch_one<GPV, 2>(xq, m, ycf, n, g, mask, S, cand_idx, cand_tau, st);
+        return epl == 1 ? cbf_launch_one<GPV, 1>(xq, xh, m, ycf, ych, n, g, mask, S, cand_idx, cand_tau, st)  \
+                        : cbf_launch_one<GPV, 2>(xq, xh, m, ycf, ych, n, g, mask, S, cand_idx, cand_tau, st);
     switch (gp) {
         NABO_CBF(8)
         NABO_CBF(16)

@@ -3,9 +3,10 @@ with the oracle's CPU timing beside it.  Prints one JSON line (same field meanin
 
     python tools/bench_canberra.py [targets refs dims k]      default 100000 100000 50 15
 
-Roofline: VALU bound (compare / add / divide per dimension; nothing for MFMA).  The dominant kernel is the fp32
-lower-bound filter (canberra_f32.hip, ~11 fp32 VALU instructions + one v_rcp_f32 per pair and dimension); the
-float64 expression is evaluated only for the <= 32 candidates per target.  Algorithmic work per (pair, dimension)
+Roofline: VALU bound (compare / add / divide per dimension; nothing for MFMA).  The dominant kernel is the
+lower-bound filter (canberra_f32.hip): a packed-f16 counting pass of 2 VALU instructions per pair and dimension
+proves "out of window" for most dimensions and drops all but ~1e-3 of the pairs; the fp32 bound (~15 slots per
+dimension) runs on the survivors and the float64 expression only on the <= 32 candidates per target.  Algorithmic work per (pair, dimension)
 = the reference's 9 operations (nabo/_mapping.py:37-44: abs, sub, abs, mul, cmp, abs, add, add, div/add); peak =
 78.6e12 fp32 VALU instructions/s (MI355X: 157.3 TFLOP/s fp32 vector, an FMA counting 2).  With
 NABO_CANBERRA_MODE=exact the float64 kernel of canberra.hip runs instead (peak 39.3e12 float64 instructions/s).
@@ -51,7 +52,7 @@ print(json.dumps({
     "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, modified Canberra" % (n // 1000, m // 1000, d, k)},
     "roofline": {"bound": "valu-f64" if exact else "valu-f32", "achieved": alg_ops / t_k / 1e12, "peak": peak,
                  "unit": "T ops/s", "frac": alg_ops / t_k / (peak * 1e12),
-                 "kernel": "canberra_topk_kernel (float64)" if exact else "cbf_filter_kernel (fp32 lower bound)",
+                 "kernel": "canberra_topk_kernel (float64)" if exact else "cbf_filter_kernel (f16 count + fp32 lower bound)",
                  "kernel_ms": st["ms_topk"]},
     "phases_ms": {kk_: st[kk_] for kk_ in ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
     "uncertified_rows_resolved_exactly": st["fallback_rows"],
