@@ -359,6 +359,17 @@ def test_canberra_filter_path_stress(gpu_lib):
     cases.append(("far apart", rng.standard_normal((80, 24)) * 0.01, rng.standard_normal((3000, 24)) * 100, 0.25))
     Xz = X.copy(); Xz[:, ::3] = 0.0
     cases.append(("zeros in x", Xz, Y, 0.25))
+    # the packed-f16 counting pass: per-dimension power-of-two scales, half-precision window edges, f16 range
+    col = 10.0 ** (np.arange(24) - 12.0)
+    cases.append(("column scales 1e-12..1e11", X * col, Y * col, 0.25))
+    Yo = Y.copy(); Yo[np.arange(24) * 7, np.arange(24)] *= 1e6          # one huge outlier per column: the rest of the
+    cases.append(("column outliers", X, Yo, 0.25))                      # column lands in the f16 denormal range
+    cases.append(("targets far outside the reference range", X * 3e4, Y, 0.25))     # x' overflows f16: never counted
+    Yh = Y.copy()
+    Yh[:, :12] = X[rng.integers(0, 400, 6000), :12] * (1 + 0.25 * rng.choice([-1, 1], (6000, 12)) * (1 + rng.uniform(-2e-3, 2e-3, (6000, 12))))
+    cases.append(("edges at f16 resolution", X, Yh, 0.25))
+    cases.append(("negated references", X, -Y, 0.25))
+    cases.append(("f = 1", X, Y, 1.0))
     for name, Xc, Yc, f in cases:
         gi, gd = gpu_lib.knn(Xc, Yc, 15, metric=1, dist_factor=f)
         oi, od = oracle.knn(Xc, Yc, 15, 1, f, nthreads=8)
