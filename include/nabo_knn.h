@@ -130,6 +130,21 @@ int nabo_merge_topk(int32_t device, const int64_t *parts_idx, const double *part
 int nabo_snn_counts(int32_t device, const int64_t *t_idx, int64_t m,
                     const int64_t *r_idx, int64_t n, int32_t k, int32_t *out_snn);
 
+/* ---- permutation null for mapping scores (EXTENSION: BASELINE.json configs[4]; the reference has the
+ * score, Graph.get_mapping_score nabo/_graph.py:555-697, but no permutation test) -------------------------
+ * Bipartite target->reference edges in CSR by reference node: row_ptr [n_ref+1], edge_t [E] (pooled target
+ * cell of the edge), edge_w [E]; group [n_t] flags the sample of interest (n_A cells).  HOST pointers.
+ *   out_obs[r]  = multiplier * sum_{e in row r, group[t_e]} w_e / n_A            (the reference's score)
+ *   permutation p: key(t,p) = top key_bits of splitmix64(seed + (p+1)*0x9E3779B97F4A7C15 + t*0xD1B54A32D192ED03),
+ *                  label_p[t] = key <= (n_A-th smallest key); out_sizes[p] = #labelled (n_A unless keys tie)
+ *   out_nge[r]  = #{p : multiplier * sum_{e in row r, label_p[t_e]} w_e / out_sizes[p]  >=  out_obs[r]}
+ *   out_mean/out_sd[r] = mean and population sd of the permuted scores.  Edge sums are float64, in row order.
+ * key_bits in {8,16,..,64} (64 in production; small values force ties, for tests); n_perm <= 4096. */
+int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const int64_t *edge_t,
+                    const double *edge_w, int64_t n_t, const uint8_t *group, int32_t n_perm, uint64_t seed,
+                    int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge, double *out_mean,
+                    double *out_sd, int64_t *out_sizes /* [n_perm] or NULL */);
+
 /* ---- plain device-memory helpers so a ctypes host needs no other GPU binding ------------ */
 int nabo_dev_malloc(int32_t device, void **ptr, size_t bytes);
 int nabo_dev_free(int32_t device, void *ptr);

@@ -7,6 +7,8 @@ weights (> min_weight) of its edges to nodes of ONE target sample, times
 sub-graph and loops over Python dicts; here it is one segmented sum over the target's edge list
 as stored in the mapping file (`<uid>_graph`, nabo/_mapping.py:252-273).
 """
+import ctypes as C
+
 import numpy as np
 
 
@@ -52,3 +54,86 @@ def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0
     sc = mapping_score_from_edges(len(ref_cells), ridx, w, n_nodes, min_weight, min_score, weighted, score_multiplier)
     names = ref_cells if remove_suffix else [c + "_" + ref_name for c in ref_cells]
     return dict(zip(names, sc.tolist()))
+
+
+# ---- permutation null (EXTENSION: BASELINE.json configs[4]; the reference has no permutation test) ------------
+def mapping_score_null(edge_t, edge_ref_idx, edge_weight, group, n_ref, n_perm=1000, seed=0, score_multiplier=1000,
+                       key_bits=64, device=0):
+    """Label-permutation null of the mapping score on the GPU (nabo_score_null, include/nabo_knn.h).
+
+    edge_t[e] / edge_ref_idx[e] / edge_weight[e]: target->reference edges of POOLED target cells (e.g. two
+    mapped samples); group[t] != 0 marks the cells of the sample of interest.  Every permutation relabels the
+    pooled cells (same group size) and recomputes the score; returns a dict of float64 / int64 arrays [n_ref]:
+    obs (== the reference's mapping score of the sample of interest), n_ge (#permutations with score >= obs),
+    pvalue = (1 + n_ge) / (1 + n_perm), null_mean, null_sd, and sizes [n_perm] (realised group sizes)."""
+    from . import _lib
+    edge_t = np.ascontiguousarray(edge_t, dtype=np.int64)
+    edge_r = np.ascontiguousarray(edge_ref_idx, dtype=np.int64)
+    w = np.ascontiguousarray(edge_weight, dtype=np.float64)
+    group = np.ascontiguousarray(np.asarray(group) != 0, dtype=np.uint8)
+    if not (edge_t.shape == edge_r.shape == w.shape) or edge_t.ndim != 1:
+        raise ValueError("ERROR: edge arrays must be 1-D and of equal length")
+    if edge_r.size and (edge_r.min() < 0 or edge_r.max() >= n_ref):
+        raise ValueError("ERROR: edge_ref_idx out of range")
+    order = np.argsort(edge_r, kind="stable")                 # CSR by reference node, edge order kept inside a row
+    row_ptr = np.zeros(n_ref + 1, dtype=np.int64)
+    np.cumsum(np.bincount(edge_r, minlength=n_ref), out=row_ptr[1:])
+    et, ew = np.ascontiguousarray(edge_t[order]), np.ascontiguousarray(w[order])
+    obs = np.empty(n_ref); mean = np.empty(n_ref); sd = np.empty(n_ref)
+    nge = np.empty(n_ref, dtype=np.int64)
+    sizes = np.empty(int(n_perm), dtype=np.int64)
+    L = _lib.lib()
+    L.nabo_score_null.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int32, C.c_uint64, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    _lib.check(L.nabo_score_null(int(device), int(n_ref), row_ptr.ctypes.data, et.ctypes.data, ew.ctypes.data,
+                                 int(group.shape[0]), group.ctypes.data, int(n_perm), int(seed) & (2 ** 64 - 1),
+                                 int(key_bits), float(score_multiplier), obs.ctypes.data, nge.ctypes.data,
+                                 mean.ctypes.data, sd.ctypes.data, sizes.ctypes.data))
+    return {"obs": obs, "n_ge": nge, "pvalue": (1.0 + nge) / (1.0 + n_perm), "null_mean": mean, "null_sd": sd,
+            "sizes": sizes}
+
+
+def _read_target_edges(h5, ref_name, target, pos):
+    uid = None
+    for i in h5["name_stash/target_names"][:]:
+        if i[0].decode("UTF-8") == target:
+            uid = i[1].decode("UTF-8")
+    if uid is None:
+        raise ValueError("ERROR: %s not present in graph" % target)
+    grp = h5[uid + "_graph"]
+    t, r, w = [], [], []
+    n_nodes = 0
+    for node in grp:
+        for row in grp[node]:
+            t.append(n_nodes)
+            r.append(pos[row[0].decode("UTF-8")])
+            w.append(float(row[1].decode("UTF-8")))
+        n_nodes += 1
+    return n_nodes, np.array(t, dtype=np.int64), np.array(r, dtype=np.int64), np.array(w)
+
+
+def get_mapping_score_null(mapping_h5_fn, ref_name, target, background, n_perm=1000, seed=0, score_multiplier=1000,
+                           remove_suffix=False, device=0):
+    """Permutation null for `target`'s mapping scores against the pooled cells of `target` + `background`
+    (another mapped sample, or a list of them), read from the mapping file.  Returns {reference node name:
+    (score, pvalue, null_mean, null_sd)}."""
+    import h5py
+    if isinstance(background, str):
+        background = [background]
+    with h5py.File(mapping_h5_fn, "r") as h5:
+        if h5["name_stash/ref_name"][0].decode("UTF-8") != ref_name:
+            raise KeyError("ERROR: The reference is not named %s in the mapping file" % ref_name)
+        ref_cells = [x.decode("UTF-8") for x in h5["ref_cells/ref_cells"][:]]
+        pos = {c + "_" + ref_name: i for i, c in enumerate(ref_cells)}
+        parts = [_read_target_edges(h5, ref_name, s, pos) for s in [target] + list(background)]
+    off, ts, rs, ws, grp = 0, [], [], [], []
+    for i, (n_nodes, t, r, w) in enumerate(parts):
+        ts.append(t + off); rs.append(r); ws.append(w)
+        grp.append(np.full(n_nodes, 1 if i == 0 else 0, dtype=np.uint8))
+        off += n_nodes
+    res = mapping_score_null(np.concatenate(ts), np.concatenate(rs), np.concatenate(ws), np.concatenate(grp),
+                             len(ref_cells), n_perm, seed, score_multiplier, device=device)
+    names = ref_cells if remove_suffix else [c + "_" + ref_name for c in ref_cells]
+    return {n: (float(res["obs"][i]), float(res["pvalue"][i]), float(res["null_mean"][i]), float(res["null_sd"][i]))
+            for i, n in enumerate(names)}

@@ -81,6 +81,13 @@ hipError_t cbf_pack_targets16_launch(const double *X, int64_t m, int g, int gp, 
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
 hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
                                int64_t *out_idx, double *out_dist, hipStream_t st);
+hipError_t null_hist_launch(int64_t n_t, int P, uint64_t seed, int key_bits, const uint64_t *prefix, int done_bits,
+                            unsigned int *hist, hipStream_t st);
+hipError_t null_label_launch(int64_t n_t, int P, int W, uint64_t seed, int key_bits, const uint64_t *thr,
+                             const uint8_t *group, uint32_t *bits, hipStream_t st);
+hipError_t null_score_launch(int64_t n_ref, const int64_t *row_ptr, const int64_t *edge_t, const double *edge_w, int P,
+                             int W, const uint32_t *bits, const int64_t *n_lab, int64_t n_a, double mult,
+                             double *out_obs, int64_t *out_nge, double *out_mean, double *out_sd, hipStream_t st);
 hipError_t snn_counts_launch(const int64_t *t_idx, int64_t m, const int64_t *r_idx, int64_t n, int k, int32_t *out,
                              hipStream_t st);
 }  // namespace nabo
@@ -845,6 +852,112 @@ int nabo_snn_counts(int32_t device, const int64_t *t_idx, int64_t m, const int64
     if (rc) return rc;
     HIP_TRY(nabo::snn_counts_launch(t_idx, m, r_idx, n, k, out_snn, nullptr));
     HIP_TRY(hipStreamSynchronize(nullptr));
+    return NABO_OK;
+}
+
+int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const int64_t *edge_t,
+                    const double *edge_w, int64_t n_t, const uint8_t *group, int32_t n_perm, uint64_t seed,
+                    int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge, double *out_mean,
+                    double *out_sd, int64_t *out_sizes)
+{
+    if (!row_ptr || !group || !out_obs || !out_nge || !out_mean || !out_sd) return fail(NABO_E_INVALID, "NULL argument");
+    if (n_ref < 1 || n_t < 1) return fail(NABO_E_INVALID, "empty operand");
+    if (n_perm < 1 || n_perm > 4096) return fail(NABO_E_UNSUPPORTED, "n_perm=%d: 1..4096 supported", n_perm);
+    if (key_bits < 8 || key_bits > 64 || key_bits % 8) return fail(NABO_E_INVALID, "key_bits must be 8, 16, .., 64");
+    if (n_ref >= 0x7FFFFFFFll) return fail(NABO_E_UNSUPPORTED, "n_ref too large for one launch");
+    const int64_t E = row_ptr[n_ref];
+    if (row_ptr[0] != 0 || E < 0) return fail(NABO_E_INVALID, "row_ptr must start at 0");
+    if (E > 0 && (!edge_t || !edge_w)) return fail(NABO_E_INVALID, "NULL edge arrays");
+    for (int64_t r = 0; r < n_ref; ++r)
+        if (row_ptr[r + 1] < row_ptr[r]) return fail(NABO_E_INVALID, "row_ptr must be non-decreasing");
+    for (int64_t e = 0; e < E; ++e)
+        if (edge_t[e] < 0 || edge_t[e] >= n_t) return fail(NABO_E_INVALID, "edge_t[%lld] out of range", (long long)e);
+    int64_t n_a = 0;
+    for (int64_t t = 0; t < n_t; ++t) n_a += group[t] ? 1 : 0;
+    if (n_a < 1) return fail(NABO_E_INVALID, "the group of interest is empty");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const int P = n_perm, W = (P + 1 + 31) / 32;
+    hipStream_t st = nullptr;
+    DevBuf d_rp, d_et, d_ew, d_grp, d_pre, d_hist, d_bits, d_nl, d_obs, d_nge, d_mean, d_sd;
+    auto release = [&]() {
+        DevBuf *all[] = {&d_rp, &d_et, &d_ew, &d_grp, &d_pre, &d_hist, &d_bits, &d_nl, &d_obs, &d_nge, &d_mean, &d_sd};
+        for (DevBuf *b : all) b->release();
+    };
+#define NS_TRY(expr)                                                                     \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            release();                                                                   \
+            return fail(e__ == hipErrorOutOfMemory ? NABO_E_NOMEM : NABO_E_HIP, "%s failed: %s", #expr, \
+                        hipGetErrorString(e__));                                         \
+        }                                                                                \
+    } while (0)
+#define NS_RES(buf, bytes)                         \
+    do {                                           \
+        if ((rc = (buf).reserve(bytes))) {         \
+            release();                             \
+            return rc;                             \
+        }                                          \
+    } while (0)
+    NS_RES(d_rp, (size_t)(n_ref + 1) * 8);
+    NS_RES(d_et, (size_t)(E ? E : 1) * 8);
+    NS_RES(d_ew, (size_t)(E ? E : 1) * 8);
+    NS_RES(d_grp, (size_t)n_t);
+    NS_RES(d_pre, (size_t)P * 8);
+    NS_RES(d_hist, (size_t)P * 256 * 4);
+    NS_RES(d_bits, (size_t)n_t * W * 4);
+    NS_RES(d_nl, (size_t)P * 8);
+    NS_RES(d_obs, (size_t)n_ref * 8);
+    NS_RES(d_nge, (size_t)n_ref * 8);
+    NS_RES(d_mean, (size_t)n_ref * 8);
+    NS_RES(d_sd, (size_t)n_ref * 8);
+    NS_TRY(hipMemcpyAsync(d_rp.p, row_ptr, (size_t)(n_ref + 1) * 8, hipMemcpyHostToDevice, st));
+    if (E) {
+        NS_TRY(hipMemcpyAsync(d_et.p, edge_t, (size_t)E * 8, hipMemcpyHostToDevice, st));
+        NS_TRY(hipMemcpyAsync(d_ew.p, edge_w, (size_t)E * 8, hipMemcpyHostToDevice, st));
+    }
+    NS_TRY(hipMemcpyAsync(d_grp.p, group, (size_t)n_t, hipMemcpyHostToDevice, st));
+    // radix select of the n_A-th smallest key of every permutation, 8 bits per pass
+    std::vector<uint64_t> prefix((size_t)P, 0), below((size_t)P, 0), rank((size_t)P, (uint64_t)n_a);
+    std::vector<int64_t> sizes((size_t)P, 0);
+    std::vector<unsigned int> hist((size_t)P * 256);
+    for (int done = 0; done < key_bits; done += 8) {
+        NS_TRY(hipMemcpyAsync(d_pre.p, prefix.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));
+        NS_TRY(hipMemsetAsync(d_hist.p, 0, (size_t)P * 256 * 4, st));
+        NS_TRY(nabo::null_hist_launch(n_t, P, seed, key_bits, d_pre.as<uint64_t>(), done, d_hist.as<unsigned int>(), st));
+        NS_TRY(hipMemcpyAsync(hist.data(), d_hist.p, (size_t)P * 256 * 4, hipMemcpyDeviceToHost, st));
+        NS_TRY(hipStreamSynchronize(st));
+        for (int p = 0; p < P; ++p) {
+            const unsigned int *h = &hist[(size_t)p * 256];
+            uint64_t cum = 0;
+            int b = 0;
+            for (; b < 256; ++b) {
+                if (cum + h[b] >= rank[p]) break;
+                cum += h[b];
+            }
+            if (b == 256) { release(); return fail(NABO_E_HIP, "internal: radix select lost rank (permutation %d)", p); }
+            prefix[p] = (prefix[p] << 8) | (uint64_t)b;
+            below[p] += cum;
+            rank[p] -= cum;
+            if (done + 8 >= key_bits) sizes[p] = (int64_t)(below[p] + h[b]);      // keys <= T_p (ties at T_p included)
+        }
+    }
+    NS_TRY(hipMemcpyAsync(d_pre.p, prefix.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));        // thresholds T_p
+    NS_TRY(hipMemcpyAsync(d_nl.p, sizes.data(), (size_t)P * 8, hipMemcpyHostToDevice, st));
+    NS_TRY(nabo::null_label_launch(n_t, P, W, seed, key_bits, d_pre.as<uint64_t>(), d_grp.as<uint8_t>(), d_bits.as<uint32_t>(), st));
+    NS_TRY(nabo::null_score_launch(n_ref, d_rp.as<int64_t>(), d_et.as<int64_t>(), d_ew.as<double>(), P, W,
+                                   d_bits.as<uint32_t>(), d_nl.as<int64_t>(), n_a, multiplier, d_obs.as<double>(),
+                                   d_nge.as<int64_t>(), d_mean.as<double>(), d_sd.as<double>(), st));
+    NS_TRY(hipMemcpyAsync(out_obs, d_obs.p, (size_t)n_ref * 8, hipMemcpyDeviceToHost, st));
+    NS_TRY(hipMemcpyAsync(out_nge, d_nge.p, (size_t)n_ref * 8, hipMemcpyDeviceToHost, st));
+    NS_TRY(hipMemcpyAsync(out_mean, d_mean.p, (size_t)n_ref * 8, hipMemcpyDeviceToHost, st));
+    NS_TRY(hipMemcpyAsync(out_sd, d_sd.p, (size_t)n_ref * 8, hipMemcpyDeviceToHost, st));
+    NS_TRY(hipStreamSynchronize(st));
+    if (out_sizes) memcpy(out_sizes, sizes.data(), (size_t)P * 8);
+    release();
+#undef NS_TRY
+#undef NS_RES
     return NABO_OK;
 }
 

@@ -94,3 +94,45 @@ def snn_edges(t_idx, r_idx, k):
     ne = lib().oracle_snn_counts(t_idx, m, r_idx, n, k, ot, oj, os_)
     w = np.array([snn_weight(int(s), k) for s in os_[:ne]], dtype=np.float64)
     return ot[:ne].copy(), oj[:ne].copy(), w
+
+
+# ---- permutation null of the mapping score (EXTENSION; definition in include/nabo_knn.h / score_null.hip) --------
+def _null_keys(seed, p, n_t, key_bits):
+    t = np.arange(n_t, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = (np.full(n_t, seed & (2 ** 64 - 1), dtype=np.uint64) +
+             np.full(n_t, ((p + 1) * 0x9E3779B97F4A7C15) & (2 ** 64 - 1), dtype=np.uint64) +
+             t * np.uint64(0xD1B54A32D192ED03))
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return z >> np.uint64(64 - key_bits)
+
+
+def score_null(edge_t, edge_ref_idx, edge_weight, group, n_ref, n_perm, seed=0, score_multiplier=1000, key_bits=64):
+    """CPU statement of nabo_score_null: plain loops, float64 sums in CSR (stable by reference node) order."""
+    edge_t = np.asarray(edge_t, dtype=np.int64)
+    edge_r = np.asarray(edge_ref_idx, dtype=np.int64)
+    w = np.asarray(edge_weight, dtype=np.float64)
+    group = np.asarray(group) != 0
+    n_t = group.shape[0]
+    n_a = int(group.sum())
+    lab = np.empty((n_perm + 1, n_t), dtype=bool)
+    sizes = np.empty(n_perm, dtype=np.int64)
+    for p in range(n_perm):
+        k = _null_keys(seed, p, n_t, key_bits)
+        thr = np.partition(k, n_a - 1)[n_a - 1]
+        lab[p] = k <= thr
+        sizes[p] = int(lab[p].sum())
+    lab[n_perm] = group
+    order = np.argsort(edge_r, kind="stable")
+    acc = np.zeros((n_ref, n_perm + 1))
+    for e in order:
+        acc[edge_r[e]] = acc[edge_r[e]] + np.where(lab[:, edge_t[e]], w[e], 0.0)
+    obs = (score_multiplier * acc[:, n_perm]) / float(n_a)
+    sp = (score_multiplier * acc[:, :n_perm]) / sizes[None, :].astype(np.float64)
+    n_ge = (sp >= obs[:, None]).sum(axis=1).astype(np.int64)
+    return {"obs": obs, "n_ge": n_ge, "null_mean": sp.mean(axis=1), "null_sd": sp.std(axis=1), "sizes": sizes,
+            "scores": sp}

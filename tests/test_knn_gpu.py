@@ -451,3 +451,48 @@ def test_cosine_config5_shape_sampled(gpu_lib):
     oi, od = oracle.knn(Y[rows], Y, k, 2, drop_first=True, nthreads=8)
     _check(gi[rows], gd[rows], oi, od)
     assert st["fallback_rows"] < 200
+
+
+# ---- permutation null of the mapping score: EXTENSION (no reference counterpart; own oracle) --------------------
+def _null_case(n_ref, n_t, k, seed):
+    rng = np.random.default_rng(seed)
+    edge_t = np.repeat(np.arange(n_t), k)
+    edge_r = rng.integers(0, n_ref, n_t * k)
+    edge_r[:5 * k] = 3                                    # a heavily hit reference node
+    w = rng.choice(np.round(np.arange(1, 11) / (20.0 - np.arange(1, 11)), 2), n_t * k)
+    group = (rng.random(n_t) < 0.3).astype(np.uint8)
+    group[:5] = 1
+    return edge_t, edge_r, w, group
+
+
+@pytest.mark.parametrize("n_ref,n_t,k,P,bits", [(40, 200, 5, 64, 64), (300, 1500, 7, 257, 64), (50, 400, 4, 1000, 8),
+                                                (17, 90, 3, 31, 16)])
+def test_mapping_score_permutation_null_vs_oracle(gpu_lib, n_ref, n_t, k, P, bits):
+    import nabo_amd
+    from oracle import oracle as orc
+    edge_t, edge_r, w, group = _null_case(n_ref, n_t, k, 7 + n_ref)
+    res = nabo_amd.mapping_score_null(edge_t, edge_r, w, group, n_ref, n_perm=P, seed=12345, key_bits=bits)
+    ref = orc.score_null(edge_t, edge_r, w, group, n_ref, P, seed=12345, key_bits=bits)
+    assert np.array_equal(res["sizes"], ref["sizes"])                     # thresholds / ties: integer-exact
+    if bits == 8:
+        assert (ref["sizes"] > int(group.sum())).any()                    # 8-bit keys tie at the threshold
+    assert np.array_equal(res["obs"], ref["obs"])                         # same float64 operations, same order
+    assert np.array_equal(res["n_ge"], ref["n_ge"])
+    assert np.allclose(res["null_mean"], ref["null_mean"], rtol=1e-12, atol=1e-12)    # reduction order differs
+    assert np.allclose(res["null_sd"], ref["null_sd"], rtol=1e-9, atol=1e-9)
+    # the observed score is the reference's mapping score of the sample of interest (nabo/_graph.py:644-653)
+    keep = group[edge_t] != 0
+    sc = nabo_amd.mapping_score_from_edges(n_ref, edge_r[keep], w[keep], int(group.sum()))
+    assert np.allclose(res["obs"], sc, rtol=1e-13, atol=0)
+    assert res["pvalue"].min() >= 1.0 / (P + 1) and res["pvalue"].max() <= 1.0
+
+
+def test_mapping_score_null_rejects_bad_input(gpu_lib):
+    import nabo_amd
+    edge_t, edge_r, w, group = _null_case(10, 30, 2, 1)
+    with pytest.raises(ValueError):
+        nabo_amd.mapping_score_null(edge_t, edge_r, w, np.zeros(30), 10, n_perm=8)          # empty group
+    with pytest.raises(ValueError):
+        nabo_amd.mapping_score_null(edge_t, edge_r + 100, w, group, 10, n_perm=8)           # ref index out of range
+    with pytest.raises(ValueError):
+        nabo_amd.mapping_score_null(edge_t, edge_r, w, group, 10, n_perm=5000)               # > 4096 permutations
