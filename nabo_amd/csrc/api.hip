@@ -50,7 +50,7 @@ hipError_t normalise_rows_launch(const double *X, int64_t m, int g, double *out,
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
                              int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
-                             double *out_dist, hipStream_t st);
+                             double *out_dist, double *D, unsigned int d_rows, hipStream_t st);
 hipError_t masked_tail_launch(const double *X, int64_t m, const double *Y, int g, int metric, double f,
                               const uint32_t *masked_list, int n_masked_list, int n_valid, int k, int drop,
                               int64_t base, int64_t *out_idx, double *out_dist, hipStream_t st);
@@ -199,7 +199,7 @@ struct nabo_index {
     bool cb_f32 = false;          // filter usable for these references (fits fp32, g <= 128)
 
     // query workspace
-    DevBuf xfail, tmpi, tmpd;
+    DevBuf xfail, tmpi, tmpd, exact_d;
     DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_idx2, cand_tau2, cand_d, fails, failcnt, oidx, odist, nfound;
     int n_cu = 256;
 
@@ -312,7 +312,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -624,9 +624,17 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
-                                        n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
-                                        d_oidx, d_odist, st));
+        if (n_fail > 0) {
+            // workspace for the exact distances of the flagged rows: up to ~1 GiB, at least one row
+            uint64_t d_rows = (1ull << 30) / ((uint64_t)ix->n * sizeof(double));
+            if (d_rows < 1) d_rows = 1;
+            if (d_rows > n_fail) d_rows = n_fail;
+            if (d_rows > 65535) d_rows = 65535;
+            if ((rc = ix->exact_d.reserve((size_t)d_rows * ix->n * sizeof(double)))) return rc;
+            HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
+                                            n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
+                                            d_oidx, d_odist, ix->exact_d.as<double>(), (unsigned int)d_rows, st));
+        }
         HIP_TRY(hipEventRecord(ix->ev[4], st));
         n_wg = gx_main * S + gx_tail * S2;
     } else {

@@ -11,7 +11,7 @@
 // chain + fp32 input rounding), a row is certified when
 //       tau_min + ||x~||^2 - E  >  d_(k')^2          (k' = k + drop_first, exact value)
 // i.e. nothing outside the candidate set can enter or tie with the first k'.  Rows that fail
-// (duplicates, pathological gaps) are re-solved by exact_rows_kernel, which brute-forces the
+// (duplicates, pathological gaps) are re-solved by the exact kernels below, which brute-force the
 // whole reference set in float64 on the GPU.  There is no CPU path.
 #include "knn_common.h"
 
@@ -297,15 +297,31 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
     if (lane == 0) out_bound[row] = bound;
 }
 
-// Exact brute force for flagged rows: one 256-thread block per row, k' selection passes over
-// all references (each pass picks the smallest (d, j) strictly after the previous pick).
-__global__ __launch_bounds__(256) void exact_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
-                                                         int64_t n, int g, int metric, double f,
-                                                         const uint8_t *__restrict__ mask,
-                                                         const uint32_t *__restrict__ rows,
-                                                         int k, int drop, int64_t base,
-                                                         const uint32_t *__restrict__ masked_list, int n_masked_list,
-                                                         int64_t *__restrict__ out_idx, double *__restrict__ out_dist)
+// Exact brute force for flagged rows, two phases so that a handful of rows does not serialise on one CU each:
+//   1. exact_dist_rows_kernel: D[b][j] = exact float64 distance of flagged row b to EVERY reference (NaN for
+//      masked ones), grid = (references / 256, rows of the batch) -- the whole chip works on every row;
+//   2. exact_select_rows_kernel: one 256-thread block per row, k' selection passes over D[b] (each pass picks
+//      the smallest (d, j) strictly after the previous pick -- the canonical order, ties included).
+__global__ __launch_bounds__(256) void exact_dist_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
+                                                              int64_t n, int g, int metric, double f,
+                                                              const uint8_t *__restrict__ mask,
+                                                              const uint32_t *__restrict__ rows, double *__restrict__ D)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int64_t row = rows[blockIdx.y];
+    double d = __builtin_nan("");
+    if (!(mask && mask[j])) d = exact_dist(metric, X + row * g, Y + j * g, g, f);
+    D[(int64_t)blockIdx.y * n + j] = d;
+}
+
+__global__ __launch_bounds__(256) void exact_select_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
+                                                                int64_t n, int g, int metric, double f,
+                                                                const double *__restrict__ D,
+                                                                const uint32_t *__restrict__ rows,
+                                                                int k, int drop, int64_t base,
+                                                                const uint32_t *__restrict__ masked_list, int n_masked_list,
+                                                                int64_t *__restrict__ out_idx, double *__restrict__ out_dist)
 {
     __shared__ double s_d[256];
     __shared__ uint32_t s_j[256];
@@ -313,6 +329,7 @@ __global__ __launch_bounds__(256) void exact_rows_kernel(const double *__restric
     __shared__ uint32_t prev_j;
     __shared__ int have_prev;
     const int64_t row = rows[blockIdx.x];
+    const double *Dr = D + (int64_t)blockIdx.x * n;
     const double *x = X + row * g;
     const int kk = k + drop;
     if (threadIdx.x == 0) { have_prev = 0; prev_d = 0.0; prev_j = 0; }
@@ -325,8 +342,8 @@ __global__ __launch_bounds__(256) void exact_rows_kernel(const double *__restric
         const double pd = prev_d;
         const uint32_t pj = prev_j;
         for (int64_t j = threadIdx.x; j < n; j += 256) {
-            if (mask && mask[j]) continue;
-            const double d = exact_dist(metric, x, Y + j * g, g, f);
+            const double d = Dr[j];
+            if (d != d) continue;                                           // masked reference
             if (hp && !kv_less<double>(pd, pj, d, (uint32_t)j)) continue;   // not after previous pick
             if (kv_less<double>(d, (uint32_t)j, bd, bj)) { bd = d; bj = (uint32_t)j; }
         }
@@ -480,14 +497,21 @@ hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const do
     return hipGetLastError();
 }
 
+// D: workspace for d_rows x n float64 distances; the flagged rows are processed d_rows at a time.
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
                              int64_t base, const uint32_t *masked_list, int n_masked_list, int64_t *out_idx,
-                             double *out_dist, hipStream_t st)
+                             double *out_dist, double *D, unsigned int d_rows, hipStream_t st)
 {
     if (nrows == 0) return hipSuccess;
-    hipLaunchKernelGGL(exact_rows_kernel, dim3(nrows), dim3(256), 0, st, X, Y, n, g, metric, f, mask, rows, k, drop,
-                       base, masked_list, n_masked_list, out_idx, out_dist);
+    if (!D || d_rows == 0) return hipErrorInvalidValue;
+    for (unsigned int r0 = 0; r0 < nrows; r0 += d_rows) {
+        const unsigned int nb = nrows - r0 < d_rows ? nrows - r0 : d_rows;
+        hipLaunchKernelGGL(exact_dist_rows_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, st, X, Y, n, g,
+                           metric, f, mask, rows + r0, D);
+        hipLaunchKernelGGL(exact_select_rows_kernel, dim3(nb), dim3(256), 0, st, X, Y, n, g, metric, f, D, rows + r0, k,
+                           drop, base, masked_list, n_masked_list, out_idx, out_dist);
+    }
     return hipGetLastError();
 }
 
