@@ -581,7 +581,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         }
         // rounding-error coefficient of the filter score, relative to (||x|| + max||y||)^2
         const double err_coef = use_h
-                                    ? 1.05 * ((48.0 * ix->ks16 + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20))
+                                    ? 1.05 * ((48.0 * ix->ks16 + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
                                     : 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
         const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0;
         const double ymax_sqrt = use_h ? ix->ymax_sqrt_h : ix->ymax_sqrt;

@@ -27,13 +27,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // Packed f16 tile (32 cells), KS16 = ceil(g/16) K-steps:
 //   part p (0 = hi, 1 = lo), step s: frag[p][s][lane l][j] = v_p[cell l & 31][16 s + 8 (l >> 5) + j], j < 8
-//   (reference tiles only) norm[h][r] as in knn_common.h, in SCALED units.
-__host__ __device__ constexpr int htile_bytes(int ks16, bool is_ref) { return 2 * ks16 * 1024 + (is_ref ? 128 : 0); }
+// The ||y||^2 term rides in the contraction: component slot g (the first padding slot; KS16 is chosen so that
+// one exists) holds  ||y~||^2 * 2^-15 (hi + lo, SCALED units; +inf for masked / padding cells) in reference
+// tiles and the constant 2^15 in target tiles, so the MFMA chain starts from C = 0 (an inline constant: no
+// norm registers, no C-in copies) and still ends with  s = ||y||^2 - 2 x.y.
+__host__ __device__ constexpr int htile_bytes(int ks16, bool is_ref) { (void)is_ref; return 2 * ks16 * 1024; }
 
 template <int KS16>
 struct HTile {
     f16x8 hi[KS16], lo[KS16];
-    f32x16 n;
 };
 
 template <int KS16>
@@ -45,7 +47,6 @@ __device__ __forceinline__ void load_htile(HTile<KS16> &y, const unsigned char *
         y.hi[s] = p[s * 64 + lane];
         y.lo[s] = p[(KS16 + s) * 64 + lane];
     }
-    y.n = *reinterpret_cast<const f32x16 *>(base + 2 * KS16 * 1024 + (lane >> 5) * 64);
 }
 
 // 3*KS16 MFMAs: lo_y*hi_x, hi_y*lo_x, hi_y*hi_x (small terms first).
@@ -58,16 +59,14 @@ template <int KS16, bool ROLL>
 __device__ __forceinline__ f32x16 hchain(HTile<KS16> &y, HTile<KS16> &yn, const f16x8 (&xhi)[KS16],
                                          const f16x8 (&xlo)[KS16], const unsigned char *__restrict__ next2, int lane)
 {
-    f32x16 acc = y.n;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
     for (int s = 0; s < KS16; ++s) {
         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(y.lo[s], xhi[s], acc, 0, 0, 0);
         if (ROLL) {
             __builtin_amdgcn_sched_barrier(0);
-            if (s == 0) {                       // C-in has been read by the first MFMA
-                y.n = yn.n;
-                yn.n = *reinterpret_cast<const f32x16 *>(next2 + 2 * KS16 * 1024 + (lane >> 5) * 64);
-            }
             y.lo[s] = yn.lo[s];
             yn.lo[s] = reinterpret_cast<const f16x8 *>(next2)[(KS16 + s) * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
@@ -187,8 +186,8 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
     const bool live = cell < ncell;
     unsigned char *o = out + tile * (int64_t)htile_bytes(ks16, IS_REF);
     double ss = 0.0;
+    f16x8 vh[4], vl[4];                                      // ks16 <= 4
     for (int s = 0; s < ks16; ++s) {
-        f16x8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * s + 8 * hh + j;
@@ -198,23 +197,33 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
             const _Float16 l = (_Float16)(f - (float)h);
             const double rep = (double)(float)h + (double)(float)l;
             ss += rep * rep;
-            vh[j] = IS_REF ? h : (_Float16)(-2.0f * (float)h);
-            vl[j] = IS_REF ? l : (_Float16)(-2.0f * (float)l);
+            vh[s][j] = IS_REF ? h : (_Float16)(-2.0f * (float)h);
+            vl[s][j] = IS_REF ? l : (_Float16)(-2.0f * (float)l);
         }
-        reinterpret_cast<f16x8 *>(o)[s * 64 + lane] = vh;
-        reinterpret_cast<f16x8 *>(o)[(ks16 + s) * 64 + lane] = vl;
     }
     ss += __shfl_xor(ss, 32, 64);
+    // the norm slot: component index g (s = g/16, half = (g%16)/8, j = g%8)
+    float slot_hi, slot_lo = 0.0f;
     if (IS_REF) {
         float nf = __builtin_inff();
         if (live && !(mask && mask[cell])) {
-            nf = (float)ss;                                  // scaled units: this is the C-in of the MFMA
+            nf = (float)ss * 3.0517578125e-05f;              // ||y~||^2 (scaled units) * 2^-15, <= 2^15
             if (hh == 0) atomicMax(norm_max_bits, __float_as_uint((float)(ss / (scale * scale))));
         }
-        if (hh == 0)
-            reinterpret_cast<float *>(o + 2 * ks16 * 1024)[((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3)] = nf;
+        const _Float16 h = (_Float16)nf;
+        slot_hi = (float)h;
+        if (nf < __builtin_inff()) slot_lo = (float)(_Float16)(nf - (float)h);
     } else {
+        slot_hi = live ? 32768.0f : 0.0f;                     // 2^15, NOT scaled by -2: the product is +||y||^2
         if (hh == 0 && live) norm64[cell] = ss / (scale * scale);
+    }
+    for (int s = 0; s < ks16; ++s) {
+        if (g / 16 == s && ((g % 16) >> 3) == hh) {
+            vh[s][g & 7] = (_Float16)slot_hi;
+            vl[s][g & 7] = (_Float16)slot_lo;
+        }
+        reinterpret_cast<f16x8 *>(o)[s * 64 + lane] = vh[s];
+        reinterpret_cast<f16x8 *>(o)[(ks16 + s) * 64 + lane] = vl[s];
     }
 }
 
@@ -283,11 +292,11 @@ void l2h_topk_geometry(int ks16, int *rows_per_wg, int *wg_per_cu, int *lkeep_ma
 
 int l2h_pick_ks16(int g)
 {
-    const int need = (g + 15) / 16;
+    const int need = (g + 1 + 15) / 16;       // one padding slot carries the norm term
     const int inst[] = {1, 2, 4};
     for (int v : inst)
         if (need <= v) return v;
-    return -1;          // g > 64: use the fp32 kernel
+    return -1;          // g >= 64: use the fp32 kernel
 }
 
 hipError_t l2h_topk_launch(int ks16, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
