@@ -96,6 +96,15 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend)
+        # build the communicators before anything is timed (RCCL creates them lazily, per collective kind)
+        cdev = ("cuda:%d" % dev) if backend == "nccl" else "cpu"
+        w_ = dist.get_world_size()
+        a2a_s, a2a_r = torch.zeros(w_ * 4, dtype=torch.float64, device=cdev), torch.zeros(w_ * 4, dtype=torch.float64, device=cdev)
+        dist.all_to_all_single(a2a_r, a2a_s)
+        ag = torch.zeros(w_ * 4, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(ag, torch.zeros(4, dtype=torch.int64, device=cdev))
+        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=cdev), op=dist.ReduceOp.MAX)
+        dist.barrier()
         tX = torch.from_numpy(X).to("cuda:%d" % dev)
         tY = torch.from_numpy(np.ascontiguousarray(Y)).to("cuda:%d" % dev)
         torch.cuda.synchronize()
