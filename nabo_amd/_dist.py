@@ -107,7 +107,9 @@ class ShardedKnn:
         import torch
         kk = k + (1 if drop_first else 0)
         N = self.world
-        if self.local_cand is not None and N > 1 and -(-kk // N) <= 32:
+        import os
+        force = os.environ.get("NABO_DIST_FORCE_CERT") == "1"          # experiments: protocol overhead at N = 1
+        if self.local_cand is not None and (N > 1 or force) and -(-kk // N) <= 32:
             return self._query_certified(X, m, k, drop_first)
         idx, dst = self.local_knn(X, kk)
         if N == 1:
