@@ -496,3 +496,39 @@ def test_mapping_score_null_rejects_bad_input(gpu_lib):
         nabo_amd.mapping_score_null(edge_t, edge_r + 100, w, group, 10, n_perm=8)           # ref index out of range
     with pytest.raises(ValueError):
         nabo_amd.mapping_score_null(edge_t, edge_r, w, group, 10, n_perm=5000)               # > 4096 permutations
+
+
+# ---- randomized sweep: many small shapes, every metric, masks, duplicates, drop_first ---------------------------
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_random_small_shapes_sweep(gpu_lib, metric):
+    rng = np.random.default_rng(1000 + metric)
+    for case in range(60):
+        n = int(rng.choice([1, 2, 3, 5, 17, 31, 32, 33, 63, 64, 65, 100, 257, 700, 1500]))
+        m = int(rng.choice([1, 2, 7, 31, 32, 33, 64, 129, 300]))
+        g = int(rng.choice([1, 2, 3, 8, 15, 16, 17, 30, 49, 50, 64, 65, 100, 128]))
+        drop = bool(rng.integers(0, 2)) and n >= 2
+        kmax = min(n - (1 if drop else 0), 55)
+        if kmax < 1:
+            continue
+        k = int(rng.integers(1, kmax + 1))
+        Y = pca_like(n, g, seed=int(rng.integers(1, 1 << 30)))
+        if drop and m <= n:
+            X = Y[:m].copy()
+        else:
+            X = pca_like(m, g, seed=int(rng.integers(1, 1 << 30)))
+            drop = False
+        mask = None
+        flavour = int(rng.integers(0, 5))
+        if flavour == 1 and n > 4:                       # ignored references (some rows run out of valid ones)
+            mask = (rng.random(n) < rng.choice([0.1, 0.5, 0.9])).astype(np.uint8)
+            if mask.all():
+                mask[0] = 0
+        elif flavour == 2 and n > 8:                     # exact duplicates among the references
+            Y[rng.integers(0, n, n // 2)] = Y[rng.integers(0, n)]
+        elif flavour == 3:                               # coarse grid: many exact ties
+            Y = np.round(Y)
+            X = np.round(X)
+        gi, gd = gpu_lib.knn(X, Y, k, metric=metric, dist_factor=0.25, ref_mask=mask, drop_first=drop)
+        oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, drop_first=drop, nthreads=8)
+        ok = np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True)
+        assert ok, "case %d: m=%d n=%d g=%d k=%d drop=%s flavour=%d metric=%d" % (case, m, n, g, k, drop, flavour, metric)
