@@ -23,7 +23,7 @@ import string
 import numpy as np
 
 from . import _knn
-from ._lib import EUCLIDEAN, MOD_CANBERRA
+from ._lib import EUCLIDEAN, MOD_CANBERRA, COSINE
 
 __all__ = ["Mapping", "write_dense_pca"]
 
@@ -188,11 +188,11 @@ class Mapping:
     :param ref_pca_fn: HDF5 file with the reference PCA data (one dataset per cell)
     :param ref_pca_grp_name: Group inside ref_pca_fn holding the data
     :param overwrite: start from scratch, deleting everything saved in mapping_h5_fn
-    Extensions (keyword only, defaults = reference behaviour): device, layout.
+    Extensions (keyword only, defaults = reference behaviour): device, layout, target_metric.
     """
 
     def __init__(self, mapping_h5_fn, ref_name, ref_pca_fn, ref_pca_grp_name, overwrite=False, *,
-                 device=0, layout="per_cell"):
+                 device=0, layout="per_cell", target_metric=None):
         self._h5Fn = mapping_h5_fn
         if ref_name.find("__") != -1:
             raise ValueError("ERROR: Underscores are not allowed in the value for `ref_name` parameter")
@@ -203,6 +203,11 @@ class Mapping:
             raise ValueError("ERROR: Input HDF5 and output HDF5 file cannot be same")
         if layout not in ("per_cell", "columnar"):
             raise ValueError("ERROR: layout must be 'per_cell' or 'columnar'")
+        if target_metric not in (None, "mod_canberra", "euclidean", "cosine"):
+            raise ValueError("ERROR: target_metric must be None, 'mod_canberra', 'euclidean' or 'cosine'")
+        # None / 'mod_canberra' = the reference's target<->reference metric (nabo/_mapping.py:122-124)
+        self._targetMetric = {None: MOD_CANBERRA, "mod_canberra": MOD_CANBERRA, "euclidean": EUCLIDEAN,
+                              "cosine": COSINE}[target_metric]
         self._device = device
         self._layout = layout
         self._check_h5(self._refPcaFn, self._refPcaGrp)
@@ -351,7 +356,7 @@ class Mapping:
         k_store = min(self._k if self._k is not None else 1, n_ref - drop)
         if k_store < 1:
             raise ValueError("ERROR: not enough reference cells")
-        idx, dist = _knn.knn(X, ref, k_store, metric=EUCLIDEAN if intra_ref else MOD_CANBERRA,
+        idx, dist = _knn.knn(X, ref, k_store, metric=EUCLIDEAN if intra_ref else self._targetMetric,
                              dist_factor=float(self._distFactor), ref_mask=mask, drop_first=bool(drop),
                              device=self._device)
         with _h5py().File(self._h5Fn, mode="a") as h5:

@@ -157,6 +157,24 @@ def run_case(tag):
             m4.make_ref_graph()
         _, edges4, _ = read_graph_like_reference(map3, "WT", "reference")
         out["dense_input_same_graph"] = (edges4 == edges) and (list(m4.refCells) == list(m.refCells))
+        # opt-in target metric (extension): the stored lists are the oracle's Euclidean order rows
+        import oracle
+        tn0, names0, data0, ign0 = targets[0]
+        map4 = os.path.join(td, "mapping_euc.h5")
+        with redirect_stdout(buf):
+            m5 = nabo_amd.Mapping(map4, "WT", ref_fn, "data", overwrite=True, target_metric="euclidean", layout="columnar")
+            m5.set_parameters(uc, k, f, chunk)
+            m5.make_ref_graph()
+            m5.map_target(tn0, os.path.join(td, "t_%s.h5" % tn0), "data")
+        with h5py.File(map4, "r") as h5:
+            tuid = [i[1].decode() for i in h5["name_stash/target_names"][:] if i[0].decode() == tn0][0]
+            t_idx = h5[tuid + "_sortedDist/__knn_idx"][:]
+            t_cells = [x.decode() for x in h5[tuid + "_sortedDist/__knn_cells"][:]]
+        order_t = np.argsort(np.array([str(x) for x in names0]))         # HDF5 name order of the target cells
+        Xo = np.asarray(data0)[order_t][:, :uc]
+        Yo = np.stack([np.asarray(ref)[list(map(str, rn)).index(c)][:uc] for c in m.refCells])
+        oi, _ = oracle.knn(Xo, Yo, k, 0, nthreads=4)
+        out["target_metric_euclidean"] = bool(t_cells == [str(names0[i]) for i in order_t] and np.array_equal(t_idx, oi))
     return out
 
 
