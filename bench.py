@@ -180,15 +180,16 @@ def main():
         t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events, kernel's own stream
         flops = 2.0 * m * (hi - lo) * d                                       # algorithmic: the -2XY^T term
         achieved = flops / t_kernel / 1e12
-        traffic = None
+        traffic, traffic_note = None, None
         try:
             tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
             wl = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, world)
             if wl in tj and not os.environ.get("NABO_L2_MODE"):
-                traffic = {"gb_per_step": (2.0 * tj[wl]["fetch_kb"] + tj[wl]["write_kb"]) * 1024 / 1e9,
-                           "source": tj[wl]["source"]}
+                # bytes per step (= the two launches of the dominant kernel), gfx950 FETCH_SIZE correction applied
+                traffic = (2.0 * tj[wl]["fetch_kb"] + tj[wl]["write_kb"]) * 1024
+                traffic_note = "bytes per step from " + tj[wl]["source"]
         except Exception:
-            traffic = None
+            traffic, traffic_note = None, None
         line = {
             "metric": "cell-pair distances/s (k-NN build, 1Mx1M d=50 k=15)" if (m, n, d, k) == (1000000, 1000000, 50, 15)
                       else "cell-pair distances/s (k-NN build)",
@@ -203,7 +204,8 @@ def main():
                        "arithmetic": "fp32 MFMA score filter, float64 re-evaluation: indices and distances equal the "
                                      "reference's float64 path"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes": 4.0 * d * (m + (hi - lo)) + 12.0 * k * m,      # fp32 operands + (i32, f64) results
                          "kernel": "l2_topk_kernel (v_mfma_f32_32x32x2_f32)", "kernel_ms": t_kernel * 1e3},
             "phases_ms": {key: float(np.mean([s[key] for s in stats])) for key in
                           ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
