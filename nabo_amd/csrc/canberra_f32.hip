@@ -78,7 +78,8 @@ __global__ void cbf_pack_refs_kernel(const double *__restrict__ Y, int64_t n, in
 // it cannot prove merely counts as 0.  That tolerates half precision, which buys packed arithmetic (two
 // dimensions per instruction) and four reference chunks per register set.  Every dimension k is scaled by a
 // power of two s_k (exact) chosen from the references so that max_j |s_k y_jk| lies in (2^13, 2^14]:
-//   y' = fl16(s_k y),  x' = fl16(s_k x)          relative error u = 2^-11, absolute 2^-25 below the normal range
+//   y' = fl16(s_k y),  x' = fl16(s_k x)          relative error u = 2^-11 (1.001 u is used: the conversion may
+//                                                round twice), absolute 2^-25 below the normal range
 //   d' = fl16(x' - y'),  the kernel counts the dimension when |d'| > thr'.
 // With delta = x' - y' (exact): |d'| <= |delta| (1+u);  s|x-y| >= |delta| - u s (|x|+|y|) - 2 eta and
 // |y| <= |x| + |x-y| give  s |x-y| (1+u) >= |delta| - 2 u s |x| - 2 eta.  So with  T+ = fl64(f |x|) (1 + 2^-52)
@@ -133,7 +134,8 @@ __global__ void cbf_pack_targets16_kernel(const double *__restrict__ X, int64_t 
     if (e >= m * (gp / 2)) return;
     const int64_t row = e / (gp / 2);
     const int p = (int)(e - row * (gp / 2));
-    const double u = 4.8828125e-4, eta = 2.98023223876953125e-8;                   // 2^-11, 2^-25
+    // 2^-11 (+0.1 %: a double -> f16 conversion may round twice, through fp32) and 2^-25
+    const double u = 4.8828125e-4 * 1.001, eta = 2.98023223876953125e-8;
     uint32_t xw = 0, tw = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
