@@ -236,6 +236,42 @@ def run_validate():
                                             np.array_equal(A, Z[np.argsort(names)][:, :5]))
         out["too_many_comps_per_cell"] = raises(ValueError, MM._read_group_matrix, ref_fn, "data", None, 7)
         out["too_many_comps_dense"] = raises(ValueError, MM._read_group_matrix, dense_fn, "data", None, 7)
+        # the vectorised graph writer against a plain dict-of-dicts statement of nabo/_mapping.py:252-273
+        rg = np.random.default_rng(4)
+
+        def expect(t_cells, target_name, is_ref, et, ej, ew, extra):
+            ref_nodes = [c + "_WT" for c in m.refCells]
+            t_nodes = [c + "_" + target_name for c in t_cells]
+            adj = [dict() for _ in t_cells]
+            if is_ref:
+                pos = {c: i for i, c in enumerate(t_cells)}
+                rpos = [pos[c] for c in m.refCells]
+                for t, j, w in zip(et, ej, ew):
+                    adj[t][ref_nodes[j]] = w
+                    adj[rpos[j]][t_nodes[t]] = w
+                for a, b, w in extra:
+                    adj[rpos[a]][ref_nodes[b]] = w
+                    adj[rpos[b]][ref_nodes[a]] = w
+            else:
+                for t, j, w in zip(et, ej, ew):
+                    adj[t][ref_nodes[j]] = w
+            return {n: [(k.encode(), repr(float(v)).encode()) for k, v in d.items()] for n, d in zip(t_nodes, adj)}
+
+        ok_dump = True
+        for is_ref in (False, True):
+            t_cells = list(reversed(m.refCells)) if is_ref else ["t%02d" % i for i in range(9)]
+            nt = len(t_cells)
+            et = rg.integers(0, nt - 1, 40); ej = rg.integers(0, 12, 40); ew = rg.choice([0.05, 0.11, 1.0, 0.33], 40)
+            extra = [(1, 2, 0.03), (7, 9, 0.03)] if is_ref else []
+            tn = "WT" if is_ref else "T1"
+            m._dump_graph("dump_test", t_cells, tn, is_ref, et, ej, ew, extra)
+            want = expect(t_cells, tn, is_ref, et, ej, ew, extra)
+            with h5py.File(map_fn, "r") as h5:
+                got = {n: [tuple(r) for r in h5["dump_test"][n][:].tolist()] if h5["dump_test"][n].shape != (0,) else []
+                       for n in h5["dump_test"]}
+                dts = {h5["dump_test"][n].dtype.str for n in h5["dump_test"] if h5["dump_test"][n].shape != (0,)}
+            ok_dump = ok_dump and got == want and dts <= {"|S32"}
+        out["dump_graph_matches_dict_statement"] = bool(ok_dump)
         with h5py.File(os.path.join(td, "rows.h5"), "w") as h5:
             gg = h5.create_group("g")
             I = np.arange(36, dtype=np.int64).reshape(12, 3)
