@@ -258,6 +258,55 @@ def test_config2_100k_sampled_rows(gpu_lib):
     assert st["fallback_rows"] < n // 100
 
 
+def test_config3_full_size_1M_properties(gpu_lib):
+    """BASELINE configs[2] at FULL size (1M x 1M, d=50, k=15, the bench workload) through the resident-index
+    entry points: size-independent properties on all rows, a row sample re-solved by the oracle, and the
+    reference-vs-itself form (positional self-drop) on a slice."""
+    n = 1000000
+    Y = pca_like(n, 50, seed=1003)
+    X = pca_like(n, 50, seed=2003)
+    ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, 15)
+    st = ix.last_stats()
+    assert st["fallback_rows"] < 1000
+    assert (np.diff(gd, axis=1) >= 0).all()                       # sorted rows
+    assert gi.min() >= 0 and gi.max() < n
+    s = np.sort(gi, axis=1)
+    assert (np.diff(s, axis=1) > 0).all()                         # no repeated neighbour in any row
+    rows = np.random.default_rng(5).choice(n, 48, replace=False)
+    oi, od = oracle.knn(X[rows], Y, 15, 0, nthreads=8)
+    _check(gi[rows], gd[rows], oi, od)
+    # every returned distance is the reference formula at the returned index (checksum over a sample of rows)
+    rs = rows[:16]
+    d_chk = np.stack([oracle.pairwise(X[r:r + 1], Y[gi[r]], 0)[0] for r in rs])
+    assert np.array_equal(d_chk, gd[rs])
+    # ref <-> ref with the positional [1:] drop: a cell never lists itself unless it has an exact twin
+    gi2, gd2 = ix.query(Y[:20000], 15, drop_first=True)
+    ix.close()
+    assert not (gi2 == np.arange(20000)[:, None]).any()
+    assert (gd2[:, 0] > 0).all()
+    o2i, o2d = oracle.knn(Y[rows[:8] % 20000], Y, 15, 0, drop_first=True, nthreads=8)
+    _check(gi2[rows[:8] % 20000], gd2[rows[:8] % 20000], o2i, o2d)
+
+
+def test_canberra_full_size_1M_sampled(gpu_lib):
+    """The reference's target<->reference metric at 1M x 1M (d=50, k=15): sorted rows, valid indices, and a
+    row sample equal to the oracle bit for bit."""
+    n = 1000000
+    Y = pca_like(n, 50, seed=1003)
+    X = pca_like(n, 50, seed=2003)
+    ix = gpu_lib.KnnIndex(n, 50, metric=1, dist_factor=0.25).set_ref(Y)
+    gi, gd = ix.query(X, 15)
+    st = ix.last_stats()
+    ix.close()
+    assert (np.diff(gd, axis=1) >= 0).all()
+    assert gi.min() >= 0 and gi.max() < n
+    rows = np.random.default_rng(6).choice(n, 48, replace=False)
+    oi, od = oracle.knn(X[rows], Y, 15, 1, 0.25, nthreads=8)
+    _check(gi[rows], gd[rows], oi, od)
+    assert st["fallback_rows"] < 1000
+
+
 def test_far_from_origin_and_badly_scaled_inputs(gpu_lib):
     """Centring + the certification must keep results exact when the cloud sits far from the origin
     and when components differ by many orders of magnitude."""
