@@ -88,6 +88,11 @@ int nabo_index_destroy(nabo_index *ix);
 int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device,
                        const uint8_t *ref_mask);
 
+/* Replace the ignore mask of the resident references (n_ref bytes, HOST pointer, NULL = none) without
+ * touching them: the graph-repair step queries "nearest reference among an allowed set" for one component
+ * after another (nabo/_mapping.py:203-249). */
+int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask);
+
 /* k-NN of m target rows against the resident references.
  * x_on_device / out_on_device select host or device pointers for X and for
  * out_idx[m,k] (int64) / out_dist[m,k] (float64).  Work is enqueued on the index's own

@@ -79,6 +79,12 @@ class KnnIndex:
             _lib.check(_lib.lib().nabo_index_set_ref(self._h, Y.ctypes.data, 0, mp))
         return self
 
+    def set_mask(self, ref_mask=None):
+        """New ignore mask for the references already resident (no re-upload)."""
+        mk, mp = _mask(ref_mask, self.n_ref)
+        _lib.check(_lib.lib().nabo_index_set_mask(self._h, mp))
+        return self
+
     def query(self, X, k, drop_first=False):
         X = _f64(X, "X")
         if X.shape[1] != self.g:

@@ -363,28 +363,53 @@ class Mapping:
             self._store_knn(h5, dist_grp, sorted_dist_grp, cells, idx, dist)
 
     # ---- SNN graph (nabo/_mapping.py:446-493 -> :151-273) ----------------------------------
-    def _fix_disconnected(self, n, edges_a, edges_b, weight):
-        """One repair round (nabo/_mapping.py:203-249): every component that has a strictly larger
-        one gets an edge from its member closest (Euclidean) to any cell of those larger components.
-        The reference walks full order rows; here it is a masked 1-NN query on the GPU.
-        Returns (new edges, number of components before the round)."""
-        lab = _component_labels(n, edges_a, edges_b)
-        comps, sizes = np.unique(lab, return_counts=True)
+    def _repair_round(self, lab, weight, index):
+        """One repair round (nabo/_mapping.py:203-249) on component labels `lab`: every component that has a
+        strictly larger one gets an edge from its member closest (Euclidean) to any cell of those larger
+        components.  The reference walks full order rows; here it is a masked 1-NN query against the resident
+        reference index (only the mask changes between components).  Returns the new edges."""
+        comps, inv, sizes = np.unique(lab, return_inverse=True, return_counts=True)
         if len(comps) == 1:
-            return [], 1
+            return []
         ref = self._ref_matrix()
+        size_of_node = sizes[inv]
+        order = np.argsort(inv, kind="stable")                     # members of every component, ascending index
+        starts = np.concatenate([[0], np.cumsum(sizes)])
         new = []
-        for c, sz in zip(comps, sizes):
-            larger = comps[sizes > sz]
-            if len(larger) == 0:
+        smax = sizes.max()
+        for ci in range(len(comps)):
+            sz = sizes[ci]
+            if sz == smax:                                          # no strictly larger component
                 continue
-            members = np.nonzero(lab == c)[0]
-            mask = (~np.isin(lab, larger)).astype(np.uint8)
-            idx, dist = _knn.knn(ref[members], ref, 1, metric=EUCLIDEAN, ref_mask=mask, drop_first=False,
-                                 device=self._device)
+            members = order[starts[ci]:starts[ci + 1]]
+            mask = (size_of_node <= sz).astype(np.uint8)            # allowed = cells of strictly larger components
+            index.set_mask(mask)
+            idx, dist = index.query(ref[members], 1)
             best = int(np.lexsort((idx[:, 0], members, dist[:, 0]))[0])
             new.append((int(members[best]), int(idx[best, 0]), weight))
-        return new, len(comps)
+        return new
+
+    @staticmethod
+    def _merge_labels(lab, new_edges):
+        """Component labels (= smallest member index) after adding a few edges: union-find over the labels."""
+        if not new_edges:
+            return lab
+        parent = {}
+
+        def find(c):
+            while parent.setdefault(c, c) != c:
+                parent[c] = parent[parent[c]]
+                c = parent[c]
+            return c
+
+        for a, b, _ in new_edges:
+            ra, rb = find(int(lab[a])), find(int(lab[b]))
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+        lut = np.arange(lab.shape[0], dtype=np.int64)
+        for c in list(parent):
+            lut[c] = find(c)
+        return lut[lab]
 
     def calc_snn(self, target_sorted_dist_grp, target_name, graph_grp, fix_graph_attempts=5, fix_weight=None):
         """Shared-nearest-neighbour graph from the stored neighbour lists; written in the layout
@@ -412,21 +437,26 @@ class Mapping:
         if is_ref:
             n = len(self.refCells)
             tpos = np.array([order[c] for c in t_cells]) if t_cells != list(self.refCells) else np.arange(n)
-            ea, eb = list(tpos[et]), list(ej)
             if fix_weight is None:
                 fix_weight = 0.5 / ((2 * (k - 1)) - 0.5)
-            new, n_comp = self._fix_disconnected(n, ea, eb, fix_weight)
+            # components once from all SNN edges; repair rounds then only merge labels (a round adds few edges)
+            lab = _component_labels(n, tpos[et], ej)
+            n_comp = len(np.unique(lab))
             if n_comp > 1:
                 print("INFO: Reference graph is disconnected. Trying to fix..")
-                for _ in range(fix_graph_attempts):
-                    for a, b, w in new:
-                        ea.append(a)
-                        eb.append(b)
-                        extra.append((a, b, w))
-                    new, n_comp = self._fix_disconnected(n, ea, eb, fix_weight)
-                    if n_comp == 1:
-                        print("INFO: Reference graph is no longer disconnected.")
-                        break
+                index = _knn.KnnIndex(n, self._useComps, metric=EUCLIDEAN, device=self._device).set_ref(self._ref_matrix())
+                try:
+                    new = self._repair_round(lab, fix_weight, index)
+                    for _ in range(fix_graph_attempts):             # same schedule as nabo/_mapping.py:476-490
+                        extra.extend(new)
+                        lab = self._merge_labels(lab, new)
+                        n_comp = len(np.unique(lab))
+                        if n_comp == 1:
+                            print("INFO: Reference graph is no longer disconnected.")
+                            break
+                        new = self._repair_round(lab, fix_weight, index)
+                finally:
+                    index.close()
             if n_comp > 1:
                 print("WARNING: Output graph is disconnected.")
         self._dump_graph(graph_grp, t_cells, target_name, is_ref, et, ej, ew, extra)

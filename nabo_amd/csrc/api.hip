@@ -250,6 +250,34 @@ static int ensure_packed(nabo_index *ix, bool want_h)
     return NABO_OK;
 }
 
+// mask + ascending list of the first masked indices (order-row tail, nabo/_mapping.py:135-144)
+static int apply_mask(nabo_index *ix, const uint8_t *ref_mask)
+{
+    hipStream_t st = ix->stream;
+    int rc;
+    ix->dmask = nullptr;
+    ix->n_masked = 0;
+    ix->n_masked_list = 0;
+    if (ref_mask) {
+        std::vector<uint32_t> lst;
+        for (int64_t j = 0; j < ix->n; ++j)
+            if (ref_mask[j]) {
+                ++ix->n_masked;
+                if ((int)lst.size() < NABO_MAX_K) lst.push_back((uint32_t)j);
+            }
+        if (ix->n_masked > 0) {
+            if ((rc = ix->maskbuf.reserve((size_t)ix->n))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->maskbuf.p, ref_mask, (size_t)ix->n, hipMemcpyHostToDevice, st));
+            ix->dmask = ix->maskbuf.as<uint8_t>();
+            if ((rc = ix->mlistbuf.reserve(lst.size() * sizeof(uint32_t)))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->mlistbuf.p, lst.data(), lst.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));      // lst goes out of scope
+            ix->n_masked_list = (int)lst.size();
+        }
+    }
+    return NABO_OK;
+}
+
 extern "C" {
 
 const char *nabo_version(void) { return "nabo_knn 0.1 (gfx950)"; }
@@ -337,27 +365,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         HIP_TRY(hipMemcpyAsync(ix->ybuf.p, Y, ybytes, hipMemcpyHostToDevice, st));
         ix->dY = ix->ybuf.as<double>();
     }
-    // mask + ascending list of the first masked indices (order-row tail, nabo/_mapping.py:135-144)
-    ix->dmask = nullptr;
-    ix->n_masked = 0;
-    ix->n_masked_list = 0;
-    if (ref_mask) {
-        std::vector<uint32_t> lst;
-        for (int64_t j = 0; j < ix->n; ++j)
-            if (ref_mask[j]) {
-                ++ix->n_masked;
-                if ((int)lst.size() < NABO_MAX_K) lst.push_back((uint32_t)j);
-            }
-        if (ix->n_masked > 0) {
-            if ((rc = ix->maskbuf.reserve((size_t)ix->n))) return rc;
-            HIP_TRY(hipMemcpyAsync(ix->maskbuf.p, ref_mask, (size_t)ix->n, hipMemcpyHostToDevice, st));
-            ix->dmask = ix->maskbuf.as<uint8_t>();
-            if ((rc = ix->mlistbuf.reserve(lst.size() * sizeof(uint32_t)))) return rc;
-            HIP_TRY(hipMemcpyAsync(ix->mlistbuf.p, lst.data(), lst.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));      // lst goes out of scope
-            ix->n_masked_list = (int)lst.size();
-        }
-    }
+    if ((rc = apply_mask(ix, ref_mask))) return rc;
     if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 16;      // room for split padding (+inf-norm tiles)
@@ -420,6 +428,20 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         HIP_TRY(hipStreamSynchronize(st));
     }
     ix->have_ref = true;
+    return NABO_OK;
+}
+
+int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
+{
+    if (!ix) return fail(NABO_E_INVALID, "NULL index");
+    if (!ix->have_ref) return fail(NABO_E_INVALID, "nabo_index_set_ref has not been called");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if ((rc = apply_mask(ix, ref_mask))) return rc;
+    if (ix->metric != NABO_METRIC_MOD_CANBERRA) {       // masked cells carry ||y||^2 = +inf in the packed tiles
+        ix->packed_f32 = ix->packed_f16 = false;
+        if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
+    }
     return NABO_OK;
 }
 

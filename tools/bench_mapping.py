@@ -43,7 +43,7 @@ t_gen = time.perf_counter() - t0
 
 for name in ("_read_group_matrix",):
     timed(_mapping, name)
-for name in ("calc_dist", "calc_snn", "_dump_graph", "_store_knn", "_fix_disconnected"):
+for name in ("calc_dist", "calc_snn", "_dump_graph", "_store_knn", "_repair_round"):
     timed(_mapping.Mapping, name)
 timed(_mapping, "snn_edges")
 
