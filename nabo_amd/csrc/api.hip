@@ -400,7 +400,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
             HIP_TRY(hipStreamSynchronize(st));
             ix->cb_f32 = (flag == 0);
             if (ix->cb_f32) {
-                // per-dimension power-of-two scales for the f16 counting pass: max |s_k y_k| in (2^13, 2^14]
+                // per-dimension power-of-two scales for the f16 counting pass: max |s_k y_k| in (2^7, 2^8]
                 std::vector<unsigned int> cm((size_t)ix->g, 0u);
                 std::vector<double> sc((size_t)ix->g, 1.0);
                 if ((rc = ix->cbscale.reserve((size_t)ix->g * sizeof(double)))) return rc;
@@ -412,7 +412,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                     float mx;
                     memcpy(&mx, &cm[k], sizeof(mx));
                     if (mx > 0.0f && std::isfinite(mx)) {
-                        int e = 14 - (int)std::ceil(std::log2((double)mx) + 1e-9);
+                        int e = 8 - (int)std::ceil(std::log2((double)mx) + 1e-9);
                         if (e > 120) e = 120;
                         if (e < -120) e = -120;
                         sc[k] = std::ldexp(1.0, e);

@@ -77,10 +77,13 @@ __global__ void cbf_pack_refs_kernel(const double *__restrict__ Y, int64_t n, in
 // The counting pass only has to PROVE "this dimension is out of window" for as many dimensions as it can; what
 // it cannot prove merely counts as 0.  That tolerates half precision, which buys packed arithmetic (two
 // dimensions per instruction) and four reference chunks per register set.  Every dimension k is scaled by a
-// power of two s_k (exact) chosen from the references so that max_j |s_k y_jk| lies in (2^13, 2^14]:
+// power of two s_k (exact) chosen from the references so that max_j |s_k y_jk| lies in (2^7, 2^8]:
 //   y' = fl16(s_k y),  x' = fl16(s_k x)          relative error u = 2^-11 (1.001 u is used: the conversion may
 //                                                round twice), absolute 2^-25 below the normal range
-//   d' = fl16(x' - y'),  the kernel counts the dimension when |d'| > thr'.
+//   d' = fl16(x' - y'),  the kernel counts the dimension when  fma(d', d', -t2) > 0,  t2 = roundup16(thr'^2)
+//   (one rounding of the exact d'^2 - t2, so "> 0" means d'^2 > t2 >= thr'^2, i.e. |d'| > thr'; if d'^2 overflows
+//   f16 while t2 is finite then |d'| > 255.9 >= thr' as well; an overflowing t2 -- |x'| beyond ~4x the column's
+//   reference maximum -- makes the dimension uncountable, never miscounted).
 // With delta = x' - y' (exact): |d'| <= |delta| (1+u);  s|x-y| >= |delta| - u s (|x|+|y|) - 2 eta and
 // |y| <= |x| + |x-y| give  s |x-y| (1+u) >= |delta| - 2 u s |x| - 2 eta.  So with  T+ = fl64(f |x|) (1 + 2^-52)
 // (the reference's own threshold, padded for the rounding of its fl64 |x-y|),
@@ -148,7 +151,7 @@ __global__ void cbf_pack_targets16_kernel(const double *__restrict__ X, int64_t 
                 xb = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)sx);
                 const double tp = (f * fabs(x)) * (1.0 + 2.3e-16);                   // T+
                 const double thr = (1.0 + u) * (sc * tp * (1.0 + u) + 2.0 * u * fabs(sx) + 2.0 * eta) + eta;
-                tb = cbf_f16_up(thr * (1.0 + 1e-12));
+                tb = cbf_f16_up(thr * thr * (1.0 + 1e-12));                         // the kernel compares d'^2 with thr'^2
             }                                                                       // else: x' = 0 with thr' = inf (never counted)
         }
         xw |= xb << (16 * h);
@@ -196,8 +199,8 @@ __device__ __forceinline__ float cbf_compact(float *kb, uint32_t *ib, int count,
 // back as broadcasts (one ds_read_b64 per two dimensions and NCH chunks).
 //
 // Two passes:
-//   1. COUNT, packed f16, 2 VALU per pair and dimension (v_pk_add_f16, v_and, v_pk_add_f16 clamp, v_dot2c per
-//      TWO dimensions): acc = sum_k clamp(|x'-y'| - thr', 0, 1) <= number of dimensions PROVEN out of window
+//   1. COUNT, packed f16, 1.5 VALU per pair and dimension (v_pk_add_f16, v_pk_fma_f16 clamp, v_dot2c per TWO
+//      dimensions): acc = sum_k clamp((x'-y')^2 - thr'^2, 0, 1) <= number of dimensions PROVEN out of window
 //      (see the pack kernels).  Each of those adds exactly 1 to the reference's distance and the others add
 //      >= 0, so distance >= acc; a pair whose acc already reaches the row's threshold is dropped here (all but
 //      ~1e-3 of the pairs once the lists have warmed up).
@@ -357,13 +360,10 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) d[c] = xv - yv[c][p];
 #pragma unroll
-                for (int c = 0; c < NCH; ++c)
-                    d[c] = __builtin_bit_cast(cbf_h2, __builtin_bit_cast(uint32_t, d[c]) & 0x7FFF7FFFu);
-#pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    ind[c] = d[c] - th;                                                       // +inf - +inf = NaN -> 0
+                    ind[c] = __builtin_elementwise_fma(d[c], d[c], -th);                      // d'^2 - thr'^2, ONE rounding
                     ind[c] = __builtin_elementwise_min(__builtin_elementwise_max(ind[c], (cbf_h2){0, 0}), one2);
-                }
+                }                                                                             // (+inf - +inf = NaN -> 0)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_fdot2(ind[c], one2, acc[c], false);
             }

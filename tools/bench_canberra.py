@@ -4,7 +4,7 @@ with the oracle's CPU timing beside it.  Prints one JSON line (same field meanin
     python tools/bench_canberra.py [targets refs dims k]      default 100000 100000 50 15
 
 Roofline: VALU bound (compare / add / divide per dimension; nothing for MFMA).  The dominant kernel is the
-lower-bound filter (canberra_f32.hip): a packed-f16 counting pass of 2 VALU instructions per pair and dimension
+lower-bound filter (canberra_f32.hip): a packed-f16 counting pass of 1.5 VALU instructions per pair and dimension
 proves "out of window" for most dimensions and drops all but ~1e-3 of the pairs; the fp32 bound (~15 slots per
 dimension) runs on the survivors and the float64 expression only on the <= 32 candidates per target.  Algorithmic work per (pair, dimension)
 = the reference's 9 operations (nabo/_mapping.py:37-44: abs, sub, abs, mul, cmp, abs, add, add, div/add); peak =
