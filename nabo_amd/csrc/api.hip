@@ -700,34 +700,71 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 }
             }
             if (Sf > s_max) Sf = s_max;
+            // "tail round": with many rows the last, partially filled round of workgroups gets its own (larger)
+            // split factor so that it takes a fraction of a round -- same idea as in the Euclidean launch above
+            const int rpw = nabo::cbf_rows_per_wg(epl);
+            int64_t gx_main = gxf, gx_tail = 0;
+            int S2 = 1;
+            if (env_int("NABO_SPLITS", 0) <= 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && gxf > slots && gxf % slots != 0 &&
+                s_max >= 2) {
+                const int64_t tail = gxf % slots;
+                double best_t = 1e30;
+                int best_s = 1;
+                for (int s2 = 1; s2 <= s_max; ++s2) {
+                    const double c = (double)((tail * s2 + slots - 1) / slots) / s2 * (1.0 + 0.08 * (s2 - 1));
+                    if (c < best_t - 1e-9) { best_t = c; best_s = s2; }
+                }
+                const double cost_uniform = (double)((gxf * Sf + slots - 1) / slots) / Sf * (1.0 + 0.08 * (Sf - 1));
+                const double cost_tail = (double)(gxf / slots) + best_t;
+                if (best_s > 1 && cost_tail < cost_uniform - 1e-9) {
+                    gx_tail = tail; gx_main = gxf - tail; S2 = best_s; Sf = 1;
+                }
+            }
             S = Sf;
-            const int SL = Sf * lists;
+            const int SL = Sf * lists, SL2 = S2 * lists;
+            const int64_t rows_main = gx_tail > 0 ? gx_main * rpw : m;          // rows of the main launch
+            const int64_t rows_tail = m - rows_main;
             if ((rc = ix->xpk.reserve((size_t)m * ix->cb_gp * 2 * sizeof(float)))) return rc;
             if ((rc = ix->xh.reserve((size_t)m * ix->cb_gp * 4))) return rc;
-            if ((rc = ix->cand_idx.reserve((size_t)m * SL * L * sizeof(uint32_t)))) return rc;
-            if ((rc = ix->cand_tau.reserve((size_t)m * SL * sizeof(float) + 16))) return rc;
+            if ((rc = ix->cand_idx.reserve((size_t)rows_main * SL * L * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->cand_tau.reserve((size_t)rows_main * SL * sizeof(float) + 16))) return rc;
+            if (rows_tail > 0) {
+                if ((rc = ix->cand_idx2.reserve((size_t)rows_tail * SL2 * L * sizeof(uint32_t)))) return rc;
+                if ((rc = ix->cand_tau2.reserve((size_t)rows_tail * SL2 * sizeof(float) + 16))) return rc;
+            }
             if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
             const bool dbg_counts = (env_int("NABO_DEBUG_ABLATE", 0) & 4) != 0;
-            if (dbg_counts) HIP_TRY(hipMemsetAsync(ix->cand_tau.as<float>() + (size_t)m * SL, 0, 8, st));
+            if (dbg_counts) HIP_TRY(hipMemsetAsync(ix->cand_tau.as<float>() + (size_t)rows_main * SL, 0, 8, st));
             HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
             unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();
             HIP_TRY(nabo::cbf_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->xpk.as<float>(), d_flag, st));
             HIP_TRY(nabo::cbf_pack_targets16_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbscale.as<double>(), ix->xh.p, st));
             HIP_TRY(hipEventRecord(ix->ev[1], st));
-            HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), ix->xh.p, m, ix->yrow.as<float>(), ix->ych.p,
-                                            ix->n, g, ix->dmask, Sf, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), st));
+            HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), ix->xh.p, rows_main, ix->yrow.as<float>(),
+                                            ix->ych.p, ix->n, g, ix->dmask, Sf, ix->cand_idx.as<uint32_t>(),
+                                            ix->cand_tau.as<float>(), st));
+            if (rows_tail > 0)
+                HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>() + (size_t)rows_main * ix->cb_gp * 2,
+                                                ix->xh.as<unsigned char>() + (size_t)rows_main * ix->cb_gp * 4, rows_tail,
+                                                ix->yrow.as<float>(), ix->ych.p, ix->n, g, ix->dmask, S2,
+                                                ix->cand_idx2.as<uint32_t>(), ix->cand_tau2.as<float>(), st));
             HIP_TRY(hipEventRecord(ix->ev[2], st));
             if (dbg_counts) {
                 unsigned int c2[2] = {0, 0};
-                HIP_TRY(hipMemcpyAsync(c2, ix->cand_tau.as<float>() + (size_t)m * SL, 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(c2, ix->cand_tau.as<float>() + (size_t)rows_main * SL, 8, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                fprintf(stderr, "[nabo debug] canberra filter: splits=%d survivors=%u (%.1f per row) batches=%u\n", Sf, c2[0],
-                        (double)c2[0] / (double)m, c2[1]);
+                fprintf(stderr, "[nabo debug] canberra filter (main launch): splits=%d survivors=%u (%.1f per row) batches=%u\n",
+                        Sf, c2[0], (double)c2[0] / (double)rows_main, c2[1]);
             }
-            HIP_TRY(nabo::refine_launch(dX, 0, m, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), SL, L,
-                                        nullptr, 0.0, 0.0, 1.0, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
+            HIP_TRY(nabo::refine_launch(dX, 0, rows_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), SL,
+                                        L, nullptr, 0.0, 0.0, 1.0, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(), d_failcnt, st, 1,
                                         ix->f, plateau));
+            if (rows_tail > 0)
+                HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
+                                            ix->cand_tau2.as<float>(), SL2, L, nullptr, 0.0, 0.0, 1.0, k, drop, ix->base,
+                                            n_valid, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
+                                            ix->fails.as<uint32_t>(), d_failcnt, st, 1, ix->f, plateau));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             unsigned int hf[2] = {0, 0};
             HIP_TRY(hipMemcpyAsync(hf, ix->cbflag.p, sizeof(hf), hipMemcpyDeviceToHost, st));

@@ -289,6 +289,25 @@ def test_config3_full_size_1M_properties(gpu_lib):
     _check(gi2[rows[:8] % 20000], gd2[rows[:8] % 20000], o2i, o2d)
 
 
+def test_canberra_tail_round_rows_are_exact(gpu_lib):
+    """Many target rows: the last, partially filled round of workgroups is launched with its own reference
+    split (api.hip); rows of both launches must equal the oracle."""
+    n, g, k = 20000, 30, 11
+    m = 2048 * 16 + 700                       # one full round of one-wave workgroups + a tail
+    Y = pca_like(n, g, seed=95)
+    X = pca_like(m, g, seed=96)
+    gi, gd = gpu_lib.knn(X, Y, k, metric=1, dist_factor=0.25)
+    rows = np.concatenate([np.arange(0, 40), np.arange(2048 * 16 - 20, 2048 * 16 + 20), np.arange(m - 40, m)])
+    oi, od = oracle.knn(X[rows], Y, k, 1, 0.25, nthreads=8)
+    _check(gi[rows], gd[rows], oi, od)
+    os.environ["NABO_TAIL_SPLIT"] = "0"
+    try:
+        hi, hd = gpu_lib.knn(X, Y, k, metric=1, dist_factor=0.25)
+    finally:
+        del os.environ["NABO_TAIL_SPLIT"]
+    assert np.array_equal(gi, hi) and np.array_equal(gd, hd)
+
+
 def test_canberra_full_size_1M_sampled(gpu_lib):
     """The reference's target<->reference metric at 1M x 1M (d=50, k=15): sorted rows, valid indices, and a
     row sample equal to the oracle bit for bit."""
