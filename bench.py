@@ -122,7 +122,7 @@ def main():
 
     if use_dist:
         lk, mg, lc = gpu_callables(index, dev)
-        if os.environ.get("NABO_DIST_LOCAL_CERT") == "1" or a.metric != "euclidean":   # A/B; candidates are Euclidean-only
+        if os.environ.get("NABO_DIST_LOCAL_CERT") == "1":      # A/B: every shard certifies its own top-k'
             lc = None
         sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev), local_cand=lc)
 

@@ -105,8 +105,9 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
  * n_cand (<= 32) entries of the shard's order rows WITHOUT a local verdict -- out_idx [m,n_cand] (global
  * indices, -1 = absent), out_dist [m,n_cand] (exact float64, +inf = absent) -- and out_bound [m]: a lower
  * bound on the exact SQUARED distance of every reference of this shard that is not in the emitted list
- * (+inf: nothing else exists; -inf: unknown, the caller must fall back to nabo_index_query).  Euclidean
- * only, device pointers for the three outputs.  A merged k'-th distance d with d^2 < min over shards of
+ * (+inf: nothing else exists; -inf: unknown, the caller must fall back to nabo_index_query).  Euclidean and
+ * cosine (there the bound is the SQUARE of a lower bound on the cosine distance, so the same test applies);
+ * device pointers for the three outputs.  A merged k'-th distance d with d^2 < min over shards of
  * out_bound is the exact global k'-th distance. */
 int nabo_index_query_candidates(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m,
                                 int32_t n_cand, int64_t *out_idx, double *out_dist, double *out_bound);

@@ -45,7 +45,7 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
-                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st);
+                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0);
 hipError_t normalise_rows_launch(const double *X, int64_t m, int g, double *out, hipStream_t st);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
@@ -459,8 +459,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
     if (k < 1) return fail(NABO_E_INVALID, "k=%d must be >= 1", k);
     if (kk > ix->n && !cand_mode)
         return fail(NABO_E_INVALID, "k + drop_first = %d exceeds the %lld references", kk, (long long)ix->n);
-    if (cand_mode && (ix->metric != NABO_METRIC_EUCLIDEAN || !out_bound || !out_on_device || k > 32))
-        return fail(NABO_E_INVALID, "candidate mode: Euclidean metric, device outputs, <= 32 candidates");
+    if (cand_mode && (ix->metric == NABO_METRIC_MOD_CANBERRA || !out_bound || !out_on_device || k > 32))
+        return fail(NABO_E_INVALID, "candidate mode: Euclidean or cosine metric, device outputs, <= 32 candidates");
     if (kk > NABO_MAX_K) return fail(NABO_E_UNSUPPORTED, "k + drop_first = %d exceeds NABO_MAX_K=%d", kk, NABO_MAX_K);
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -611,11 +611,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (cand_mode) {
             HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(),
                                              S, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
-                                             n_valid, d_oidx, d_odist, out_bound, st));
+                                             n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0));
             if (gx_tail > 0)
                 HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                                  ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
-                                                 ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st));
+                                                 ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st,
+                                                 cosine ? 2 : 0));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             HIP_TRY(hipEventRecord(ix->ev[4], st));
             HIP_TRY(hipEventRecord(ix->ev[5], st));

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
 // the emitted candidates: min over splits of (tau * scale + ||x~||^2 - E), and additionally the squared
 // distance of the first candidate that did not fit into `kout`.  +inf when nothing was dropped, -inf when
 // the filter saw non-finite scores (forces the exact second phase).
-template <int NCL>
+template <int NCL, int MET>
 __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                           const double *__restrict__ Y, int g,
                                                           const uint32_t *__restrict__ cand_idx,
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
             const uint32_t j = cand_idx[lrow * ncand + e];
             if (j != 0xFFFFFFFFu) {
                 val[r] = j;
-                key[r] = euclid_exact(x, Y + (int64_t)j * g, g);
+                key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, 0.0);
             }
         }
     }
@@ -270,11 +270,18 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
     for (int s = lane; s < S; s += 64) tmin = fminf(tmin, cand_tau[lrow * S + s]);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+    // `bound` is always compared as  d^2 (1 + 1e-12) < bound  by the caller.  Cosine (MET = 2): every reference
+    // not emitted has cosine distance >= B/2 - 2e-13 (refine_kernel's certificate), so the bound is the square of
+    // that value (cosine distances are >= -1e-15, squaring keeps the order once the value is positive).
     double bound = __builtin_inf();
     if (tmin != __builtin_inff()) {
         const double sx = sqrt(xnorm[row]);
         const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
         bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);
+        if (MET == 2) {
+            const double c = 0.5 * bound - 2e-13;
+            bound = c > 0.0 ? c * c * (1.0 - 1e-12) : -__builtin_inf();
+        }
     } else if ((int64_t)nreal < n_valid_total) {
         bound = -__builtin_inf();          // nothing "dropped" yet references are missing: non-finite scores
     }
@@ -480,14 +487,22 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
-                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st)
+                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
 #define NABO_RC(N)                                                                                                  \
-    hipLaunchKernelGGL((refine_cand_kernel<N>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, L, xnorm, \
-                       err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx, out_dist, out_bound)
+    do {                                                                                                            \
+        if (metric == 2)                                                                                            \
+            hipLaunchKernelGGL((refine_cand_kernel<N, 2>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
+                               L, xnorm, err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx, out_dist, \
+                               out_bound);                                                                          \
+        else                                                                                                        \
+            hipLaunchKernelGGL((refine_cand_kernel<N, 0>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
+                               L, xnorm, err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx, out_dist, \
+                               out_bound);                                                                          \
+    } while (0)
     if (ncl <= 1) NABO_RC(1);
     else if (ncl <= 2) NABO_RC(2);
     else if (ncl <= 4) NABO_RC(4);

@@ -117,7 +117,8 @@ def test_merge_numpy_matches_oracle_order():
 
 
 @pytest.mark.gpu
-def test_bench_sharded_path_two_ranks_on_one_gpu():
+@pytest.mark.parametrize("extra", [[], ["--metric", "cosine", "--dims", "30", "--neighbors", "40"]])
+def test_bench_sharded_path_two_ranks_on_one_gpu(extra):
     """bench.py's N>1 code (shard bounds, KnnIndex per shard with a global index base, exchange, GPU merge,
     gather) rehearsed with 2 ranks sharing ONE GPU: collectives staged through gloo (RCCL cannot put two
     ranks on one device).  Each rank checks its result bit-for-bit against an unsharded index."""
@@ -125,7 +126,7 @@ def test_bench_sharded_path_two_ranks_on_one_gpu():
     env = dict(os.environ, NABO_BENCH_BACKEND="gloo", NABO_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--targets", "20001", "--refs", "50000"]
+           "--gpus", "2", "--steps", "1", "--warmup", "1", "--targets", "20001", "--refs", "50000"] + extra
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
                        timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stdout[-3000:]

@@ -193,7 +193,8 @@ def test_resident_index_shard_base_and_merge(gpu_lib):
     _check(gi, gd, oi, od)
 
 
-def test_shard_candidates_and_their_bound(gpu_lib):
+@pytest.mark.parametrize("metric", [0, 2])
+def test_shard_candidates_and_their_bound(gpu_lib, metric):
     """nabo_index_query_candidates: the emitted list is the exact head of the shard's order row and the
     bound is a true lower bound on the squared distance of everything not emitted (global certification)."""
     from nabo_amd import _knn
@@ -202,8 +203,8 @@ def test_shard_candidates_and_their_bound(gpu_lib):
     X = pca_like(m, g, seed=44)
     mask = np.zeros(n, dtype=np.uint8)
     mask[::7] = 1
-    full_i, full_d = oracle.knn(X, Y, 40, 0, ref_mask=mask, nthreads=8)
-    ix = gpu_lib.KnnIndex(n, g, metric=0, ref_index_base=1000).set_ref(Y, ref_mask=mask)
+    full_i, full_d = oracle.knn(X, Y, 40, metric, ref_mask=mask, nthreads=8)
+    ix = gpu_lib.KnnIndex(n, g, metric=metric, ref_index_base=1000).set_ref(Y, ref_mask=mask)
     dx = _knn.DeviceBuffer(X.nbytes).upload(X)
     for nc in (1, 9, 16, 32):
         di, dd, db = _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * 8)
