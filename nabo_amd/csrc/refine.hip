@@ -306,20 +306,74 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
 
 // Exact brute force for flagged rows, two phases so that a handful of rows does not serialise on one CU each:
 //   1. exact_dist_rows_kernel: D[b][j] = exact float64 distance of flagged row b to EVERY reference (NaN for
-//      masked ones), grid = (references / 256, rows of the batch) -- the whole chip works on every row;
+//      masked ones), grid = (references / 256, rows of the batch / 8) -- the whole chip works on every row;
 //   2. exact_select_rows_kernel: one 256-thread block per row, k' selection passes over D[b] (each pass picks
 //      the smallest (d, j) strictly after the previous pick -- the canonical order, ties included).
+// RB flagged rows per thread: a thread owns one reference j, reads Y[j][k] once per component and advances the
+// RB rows' accumulators in the reference's own order (k ascending, rounded multiply then rounded add), so the
+// strided reference reads are shared by RB rows.
+constexpr int EXACT_RB = 8;
+
 __global__ __launch_bounds__(256) void exact_dist_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
                                                               int64_t n, int g, int metric, double f,
                                                               const uint8_t *__restrict__ mask,
-                                                              const uint32_t *__restrict__ rows, double *__restrict__ D)
+                                                              const uint32_t *__restrict__ rows, int nrows,
+                                                              double *__restrict__ D)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
-    const int64_t row = rows[blockIdx.y];
-    double d = __builtin_nan("");
-    if (!(mask && mask[j])) d = exact_dist(metric, X + row * g, Y + j * g, g, f);
-    D[(int64_t)blockIdx.y * n + j] = d;
+    const int b0 = blockIdx.y * EXACT_RB;
+    const double *xr[EXACT_RB];
+#pragma unroll
+    for (int r = 0; r < EXACT_RB; ++r) xr[r] = X + (int64_t)rows[b0 + r < nrows ? b0 + r : nrows - 1] * g;
+    const bool masked = mask && mask[j];
+    const double *y = Y + j * g;
+    double a0[EXACT_RB], a1[EXACT_RB], a2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < EXACT_RB; ++r) { a0[r] = 0.0; a1[r] = 0.0; }
+    if (!masked) {
+        for (int k = 0; k < g; ++k) {
+            const double yv = y[k];
+            if (metric == 0) {
+#pragma unroll
+                for (int r = 0; r < EXACT_RB; ++r) {
+                    const double t = __dsub_rn(xr[r][k], yv);
+                    a0[r] = __dadd_rn(a0[r], __dmul_rn(t, t));
+                }
+            } else if (metric == 1) {
+#pragma unroll
+                for (int r = 0; r < EXACT_RB; ++r) {
+                    const double xv = xr[r][k];
+                    const double absx = fabs(xv);
+                    const double num = fabs(__dsub_rn(xv, yv));
+                    if (num < __dmul_rn(f, absx))
+                        a0[r] = __dadd_rn(a0[r], __ddiv_rn(num, __dadd_rn(__dadd_rn(absx, fabs(yv)), 0.01)));
+                    else
+                        a0[r] = __dadd_rn(a0[r], 1.0);
+                }
+            } else {
+                a2 = __dadd_rn(a2, __dmul_rn(yv, yv));
+#pragma unroll
+                for (int r = 0; r < EXACT_RB; ++r) {
+                    const double xv = xr[r][k];
+                    a0[r] = __dadd_rn(a0[r], __dmul_rn(xv, yv));
+                    a1[r] = __dadd_rn(a1[r], __dmul_rn(xv, xv));
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < EXACT_RB; ++r) {
+        if (b0 + r >= nrows) break;
+        double d = __builtin_nan("");                                       // masked reference
+        if (!masked) {
+            if (metric == 0) d = __dsqrt_rn(a0[r]);
+            else if (metric == 1) d = a0[r];
+            else d = (a1[r] == 0.0 || a2 == 0.0) ? 1.0
+                                                 : __dsub_rn(1.0, __ddiv_rn(a0[r], __dmul_rn(__dsqrt_rn(a1[r]), __dsqrt_rn(a2))));
+        }
+        D[(int64_t)(b0 + r) * n + j] = d;
+    }
 }
 
 __global__ __launch_bounds__(256) void exact_select_rows_kernel(const double *__restrict__ X, const double *__restrict__ Y,
@@ -522,8 +576,8 @@ hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g,
     if (!D || d_rows == 0) return hipErrorInvalidValue;
     for (unsigned int r0 = 0; r0 < nrows; r0 += d_rows) {
         const unsigned int nb = nrows - r0 < d_rows ? nrows - r0 : d_rows;
-        hipLaunchKernelGGL(exact_dist_rows_kernel, dim3((unsigned)((n + 255) / 256), nb), dim3(256), 0, st, X, Y, n, g,
-                           metric, f, mask, rows + r0, D);
+        hipLaunchKernelGGL(exact_dist_rows_kernel, dim3((unsigned)((n + 255) / 256), (nb + EXACT_RB - 1) / EXACT_RB), dim3(256),
+                           0, st, X, Y, n, g, metric, f, mask, rows + r0, (int)nb, D);
         hipLaunchKernelGGL(exact_select_rows_kernel, dim3(nb), dim3(256), 0, st, X, Y, n, g, metric, f, D, rows + r0, k,
                            drop, base, masked_list, n_masked_list, out_idx, out_dist);
     }
