@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh clone has no libnabo_knn.so (built artefacts are not committed): cross-compile it once (hipcc
+    needs no GPU; ~2 min).  Normally __graft_entry__.build() / `python -m nabo_amd._build` has already done it."""
+    from nabo_amd import _build, _lib
+    if not os.path.exists(_lib.SO_PATH):
+        _build.build()
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
