@@ -55,3 +55,33 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(root, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "libnabo_oracle" not in txt, f
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    exe = os.path.join(str(tmp_path), "abi_check")
+    cmd = ["gcc", "-std=c99", "-Wall", "-I" + os.path.join(REPO, "include"), os.path.join(REPO, "tests", "abi_c", "abi_check.c"),
+           "-L" + os.path.join(REPO, "nabo_amd"), "-lnabo_knn", "-Wl,-rpath," + os.path.join(REPO, "nabo_amd"),
+           "-Wl,-rpath-link,/opt/rocm/lib", "-lm", "-o", exe]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0, r.stdout
+    return exe
+
+
+def test_header_is_plain_c_and_every_entry_point_links(tmp_path):
+    """include/nabo_knn.h through gcc -std=c99 (the boundary a cgo / JNI / ctypes binding sees), linked against
+    the library; the program only takes the addresses and prints the version."""
+    import subprocess
+    _lib.lib()
+    exe = _build_c_consumer(tmp_path)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0 and "20 entry points" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_consumer_gets_reference_results(tmp_path):
+    import subprocess
+    _lib.lib()
+    exe = _build_c_consumer(tmp_path)
+    r = subprocess.run([exe, "run"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert r.returncode == 0 and "C ABI ok" in r.stdout, r.stdout
