@@ -199,7 +199,11 @@ struct nabo_index {
     bool cb_f32 = false;          // filter usable for these references (fits fp32, g <= 128)
 
     // query workspace
-    DevBuf xfail, tmpi, tmpd, exact_d;
+    DevBuf xfail, tmpi, tmpd, exact_d, fails2;
+    float ms_keep[3] = {0, 0, 0};
+    double ms_inner = 0.0;         // total of the most recent query_impl (read by the outer call of a retry)
+    bool ms_keep_valid = false;
+    bool wide_retry = false;       // inside the second-chance pass (64-entry lists for the rows the first pass could not certify)
     DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_idx2, cand_tau2, cand_d, fails, failcnt, oidx, odist, nfound;
     int n_cu = 256;
 
@@ -340,7 +344,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d, &ix->fails2,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -485,7 +489,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         d_oidx = ix->oidx.as<int64_t>();
         d_odist = ix->odist.as<double>();
     }
-    const int epl = (kk <= 24 || cand_mode) ? 1 : 2;
+    const int epl = ((kk <= 24 && !ix->wide_retry) || cand_mode) ? 1 : 2;
     const int L = 32 * epl;
     unsigned int n_fail = 0;
     int S = 1;
@@ -518,6 +522,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // kept-list length: k' + 8 slack (the certification needs a gap above the k'-th distance)
         int lkeep = kk + 8;
         if (lkeep < 16) lkeep = 16;
+        if (ix->wide_retry) lkeep = lkeep_max;              // as many kept entries as the 64-entry lists allow
         if (cand_mode) lkeep = kk < 4 ? 4 : kk;
         if (lkeep > lkeep_max) lkeep = lkeep_max;
         { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }   // experiments
@@ -647,7 +652,33 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (n_fail > 0) {
+        float ms_first[3] = {0, 0, 0};
+        bool retried = false;
+        if (n_fail >= 16 && epl == 1 && !ix->wide_retry && env_int("NABO_WIDE_RETRY", 1) != 0) {
+            // Second chance: rows the 32-entry lists could not certify (ties / near-ties reaching past the kept
+            // entries) go through the same filter once more with 64-entry lists before anything is brute-forced.
+            // The flagged rows are gathered into a dense batch; this very function solves it (wide_retry) and
+            // sends what is STILL uncertified to the exact kernels; the answers are scattered back.
+            for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms_first[i], ix->ev[i], ix->ev[i + 1]));
+            const int64_t nf = n_fail;
+            if ((rc = ix->fails2.reserve((size_t)nf * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->xfail.reserve((size_t)nf * g * sizeof(double)))) return rc;
+            if ((rc = ix->tmpi.reserve((size_t)nf * k * sizeof(int64_t)))) return rc;
+            if ((rc = ix->tmpd.reserve((size_t)nf * k * sizeof(double)))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->fails2.p, ix->fails.p, (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(nabo::gather_rows_launch(dX, ix->fails2.as<uint32_t>(), nf, g, ix->xfail.as<double>(), st));
+            HIP_TRY(hipStreamSynchronize(st));
+            ix->wide_retry = true;
+            rc = query_impl(ix, ix->xfail.as<double>(), 1, nf, k, drop_first, ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), 1,
+                            false, nullptr);
+            ix->wide_retry = false;
+            if (rc) return rc;
+            n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
+            HIP_TRY(nabo::scatter_rows_launch(ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), ix->fails2.as<uint32_t>(), nf, k,
+                                              d_oidx, d_odist, st));
+            HIP_TRY(hipEventRecord(ix->ev[3], st));          // (ev[0..5] were reused by the inner call)
+            retried = true;
+        } else if (n_fail > 0) {
             // workspace for the exact distances of the flagged rows: up to ~1 GiB, at least one row
             uint64_t d_rows = (1ull << 30) / ((uint64_t)ix->n * sizeof(double));
             if (d_rows < 1) d_rows = 1;
@@ -660,6 +691,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         }
         HIP_TRY(hipEventRecord(ix->ev[4], st));
         n_wg = gx_main * S + gx_tail * S2;
+        if (retried) { ix->ms_keep[0] = ms_first[0]; ix->ms_keep[1] = ms_first[1]; ix->ms_keep[2] = ms_first[2]; ix->ms_keep_valid = true; }
     } else {
         const int64_t n_chunks = (ix->n + 63) / 64;
         const int64_t gx = (m + 63) / 64;
@@ -829,6 +861,18 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
     }
     HIP_TRY(hipEventElapsedTime(&t, ix->ev[0], ix->ev[5]));
     ix->ms[4] = t;
+    if (ix->ms_keep_valid) {            // a second-chance pass reused the events: phases 0-2 were saved before it ran
+        ix->ms_keep_valid = false;
+        HIP_TRY(hipEventElapsedTime(&t, ix->ev[3], ix->ev[5]));
+        const double inner_total = ix->ms[4];      // (events 0..2 now belong to the inner call)
+        (void)inner_total;
+        ix->ms[0] = ix->ms_keep[0];
+        ix->ms[1] = ix->ms_keep[1];
+        ix->ms[2] = ix->ms_keep[2];
+        ix->ms[3] = ix->ms_inner + t;              // inner pass (its own total) + scatter / copy-out
+        ix->ms[4] = ix->ms[0] + ix->ms[1] + ix->ms[2] + ix->ms[3];
+    }
+    ix->ms_inner = ix->ms[4];
     ix->counters[0] = n_fail;
     ix->counters[1] = S;
     ix->counters[2] = L;

@@ -601,3 +601,33 @@ def test_random_small_shapes_sweep(gpu_lib, metric):
         oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, drop_first=drop, nthreads=8)
         ok = np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True)
         assert ok, "case %d: m=%d n=%d g=%d k=%d drop=%s flavour=%d metric=%d" % (case, m, n, g, k, drop, flavour, metric)
+
+
+def test_tie_heavy_rows_take_the_wide_second_chance(gpu_lib):
+    """References on the 4-D integer lattice: around a site the distance shells hold 8, 24, 32 ... points, so the
+    15th AND the 24th neighbour sit in the same shell (no certificate from 32-entry lists) while the 64th lies
+    in the next one.  Such rows are re-filtered with 64-entry lists before anything is brute-forced; the answer
+    is the oracle's either way.  (One reference split, so that the lists are not S times longer.)"""
+    rng = np.random.default_rng(8)
+    side = 9
+    Y = np.stack(np.meshgrid(*[np.arange(side)] * 4, indexing="ij"), -1).reshape(-1, 4).astype(np.float64)   # 6561 points
+    interior = np.nonzero(((Y >= 2) & (Y <= side - 3)).all(axis=1))[0]
+    X = Y[rng.choice(interior, 600, replace=False)] + 0.0                                                     # on lattice sites
+    k = 15
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    os.environ["NABO_SPLITS"] = "1"
+    try:
+        ix = gpu_lib.KnnIndex(len(Y), 4, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, k)
+        with_retry = ix.last_stats()["fallback_rows"]
+        os.environ["NABO_WIDE_RETRY"] = "0"
+        hi, hd = ix.query(X, k)
+        without = ix.last_stats()["fallback_rows"]
+        ix.close()
+    finally:
+        os.environ.pop("NABO_SPLITS", None)
+        os.environ.pop("NABO_WIDE_RETRY", None)
+    _check(gi, gd, oi, od)
+    _check(hi, hd, oi, od)
+    assert without >= 16                 # the situation really arises on this input
+    assert with_retry < without          # ... and the second chance certifies part of it without brute force
