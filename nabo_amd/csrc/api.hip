@@ -14,16 +14,16 @@
 namespace nabo {
 // kernels (pack.hip, l2_topk.hip, refine.hip, canberra.hip)
 hipError_t centre_launch(const double *Y, int64_t n, int g, double *centre, hipStream_t st);
-hipError_t pack_ref_launch(const double *Y, int64_t n, int g, const double *centre, int ksteps, int64_t ntiles_total,
+hipError_t pack_ref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int ksteps, int64_t ntiles_total,
                            const uint8_t *mask, float *out, unsigned int *norm_max_bits, hipStream_t st);
-hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *centre, int ksteps,
+hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *centre, double scale, int ksteps,
                              int64_t ntiles_total, float *out, double *xnorm, hipStream_t st);
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st);
 void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu);
 // f16x3 variant (l2h_topk.hip)
-hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned int *out_bits, hipStream_t st);
+hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st);
 hipError_t pack_href_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int ks16,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
                             hipStream_t st);
@@ -188,6 +188,7 @@ struct nabo_index {
     int mode = 0;
     int ks16 = 0;
     double hscale = 1.0;
+    double fscale = 1.0;           // power-of-two input scale of the fp32 path: max |y~| * fscale in (1/2, 1]
     int ksteps = 0;
     DevBuf centre, ypk, yhpk, normmax;
     bool packed_f32 = false, packed_f16 = false;
@@ -217,23 +218,28 @@ static int ensure_packed(nabo_index *ix, bool want_h)
     if (want_h ? ix->packed_f16 : ix->packed_f32) return NABO_OK;
     hipStream_t st = ix->stream;
     int rc;
-    if ((rc = ix->normmax.reserve(2 * sizeof(unsigned int)))) return rc;
-    HIP_TRY(hipMemsetAsync(ix->normmax.p, 0, 2 * sizeof(unsigned int), st));
-    unsigned int bits[2] = {0, 0};
+    // normmax: [0] = max ||y~||^2 (float bits, SCALED units), [2..3] = max |y~ component| (double bits)
+    if ((rc = ix->normmax.reserve(4 * sizeof(unsigned int)))) return rc;
+    HIP_TRY(hipMemsetAsync(ix->normmax.p, 0, 4 * sizeof(unsigned int), st));
+    unsigned int bits[4] = {0, 0, 0, 0};
+    // power-of-two input scale from the largest centred component: the filter then works in a fixed numeric range
+    // whatever the unit of the data (1e-30 or 1e+19 per component would under- / overflow fp32 squares otherwise)
+    HIP_TRY(nabo::maxabs_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(),
+                                reinterpret_cast<unsigned long long *>(ix->normmax.as<unsigned int>() + 2), st));
+    HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    double amax;
+    memcpy(&amax, &bits[2], sizeof(amax));
+    int e2 = 0;                                              // 2^e2 * amax in (1/2, 1]
+    if (amax > 0 && std::isfinite(amax)) e2 = -(int)std::ceil(std::log2(amax));
+    if (e2 > 480) e2 = 480;                                  // scale^2 must stay finite in float64
+    if (e2 < -480) e2 = -480;
+    double scale;
     if (want_h) {
         const size_t tile_bytes = (size_t)2 * ix->ks16 * 1024 + 128;
         if ((rc = ix->yhpk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
-        // power-of-two scale: |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
-        HIP_TRY(nabo::maxabs_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->normmax.as<unsigned int>() + 1, st));
-        HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        float amax;
-        memcpy(&amax, &bits[1], sizeof(amax));
-        int e = 0;
-        if (amax > 0 && std::isfinite(amax)) e = 12 - (int)std::ceil(std::log2((double)amax));
-        if (e > 60) e = 60;
-        if (e < -60) e = -60;
-        ix->hscale = std::ldexp(1.0, e);
+        // |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
+        ix->hscale = scale = std::ldexp(1.0, e2 + 12);
         HIP_TRY(nabo::pack_href_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->ks16,
                                        ix->ref_tiles_alloc, ix->dmask, ix->yhpk.as<unsigned char>(),
                                        ix->normmax.as<unsigned int>(), st));
@@ -241,14 +247,15 @@ static int ensure_packed(nabo_index *ix, bool want_h)
         const int Q = (ix->ksteps + 3) / 4;
         const size_t tile_bytes = ((size_t)Q * 256 + 32) * sizeof(float);
         if ((rc = ix->ypk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
-        HIP_TRY(nabo::pack_ref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->ksteps, ix->ref_tiles_alloc,
-                                      ix->dmask, ix->ypk.as<float>(), ix->normmax.as<unsigned int>(), st));
+        ix->fscale = scale = std::ldexp(1.0, e2);
+        HIP_TRY(nabo::pack_ref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->fscale, ix->ksteps,
+                                      ix->ref_tiles_alloc, ix->dmask, ix->ypk.as<float>(), ix->normmax.as<unsigned int>(), st));
     }
     HIP_TRY(hipMemcpyAsync(bits, ix->normmax.p, sizeof(bits), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     float fmax;
     memcpy(&fmax, &bits[0], sizeof(fmax));
-    const double v = std::sqrt((double)fmax) * (1.0 + 1e-6);
+    const double v = std::sqrt((double)fmax) / scale * (1.0 + 1e-6);      // unscaled units
     if (want_h) { ix->ymax_sqrt_h = v; ix->packed_f16 = true; }
     else { ix->ymax_sqrt = v; ix->packed_f32 = true; }
     return NABO_OK;
@@ -573,7 +580,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(nabo::pack_hquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->ks16, rows_pad / 32,
                                              ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), st));
         else
-            HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->ksteps, rows_pad / 32,
+            HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->fscale, ix->ksteps, rows_pad / 32,
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
         HIP_TRY(hipEventRecord(ix->ev[1], st));
         if (use_h) {
@@ -610,7 +617,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         const double err_coef = use_h
                                     ? 1.05 * ((48.0 * ix->ks16 + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
                                     : 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
-        const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0;
+        const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0 / (ix->fscale * ix->fscale);
         const double ymax_sqrt = use_h ? ix->ymax_sqrt_h : ix->ymax_sqrt;
         const int64_t m_main = rows_main < m ? rows_main : m;
         if (cand_mode) {

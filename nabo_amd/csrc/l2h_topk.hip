@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
         float nf = __builtin_inff();
         if (live && !(mask && mask[cell])) {
             nf = (float)ss * 3.0517578125e-05f;              // ||y~||^2 (scaled units) * 2^-15, <= 2^15
-            if (hh == 0) atomicMax(norm_max_bits, __float_as_uint((float)(ss / (scale * scale))));
+            if (hh == 0) atomicMax(norm_max_bits, __float_as_uint((float)ss));        // SCALED units (host unscales)
         }
         const _Float16 h = (_Float16)nf;
         slot_hi = (float)h;
@@ -227,20 +227,25 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
     }
 }
 
-// max |V - centre| over all components (bits of a non-negative float)
+// max |V - centre| over all components, in float64 (bits of a non-negative double order like unsigned 64-bit ints)
 __global__ void maxabs_kernel(const double *__restrict__ V, int64_t n, int g, const double *__restrict__ centre,
-                              unsigned int *__restrict__ out_bits)
+                              unsigned long long *__restrict__ out_bits)
 {
-    float m = 0.0f;
+    double m = 0.0;
     const int64_t tot = n * g;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf((float)(V[i] - centre[i % g])));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
+        const double a = fabs(V[i] - centre[i % g]);
+        if (a > m) m = a;                                   // NaN never wins
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m * 1.0001f));
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(m, o, 64);
+        m = other > m ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
 }
 
-hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned int *out_bits, hipStream_t st)
+hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st)
 {
     hipLaunchKernelGGL(maxabs_kernel, dim3(2048), dim3(256), 0, st, V, n, g, centre, out_bits);
     return hipGetLastError();

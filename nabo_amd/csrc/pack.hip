@@ -32,10 +32,13 @@ __global__ void centre_kernel(const double *__restrict__ Y, int64_t n, int g, in
 
 // One wave per 32-cell tile.  IS_REF: also emits the norm block (+inf for masked / padded
 // cells so they can never pass the filter) and the running max of ||y||^2 (bits of a
-// non-negative float order like unsigned ints).  Targets are scaled by -2 (exact).
+// non-negative float order like unsigned ints; SCALED units, the host unscales in double).  Every value is
+// multiplied by `scale`, a power of two chosen from the references so that max |y~| lies in (1/2, 1]: exact, and
+// it keeps squares and scores inside the fp32 range whatever the unit of the input.  Targets additionally carry
+// the factor -2 (exact).
 template <bool IS_REF>
 __global__ __launch_bounds__(64) void pack_tiles_kernel(const double *__restrict__ V, int64_t ncell, int g,
-                                                        const double *__restrict__ centre, int ksteps,
+                                                        const double *__restrict__ centre, double scale, int ksteps,
                                                         int64_t ntiles_total,
                                                         const uint8_t *__restrict__ mask,
                                                         float *__restrict__ out, double *__restrict__ norm64,
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(const double *__restrict
             const int k = 2 * (4 * q + e) + hh;
             float f = 0.0f;
             if (live && k < g) {
-                f = (float)(V[cell * g + k] - centre[k]);
+                f = (float)((V[cell * g + k] - centre[k]) * scale);      // scale: a power of two (exact)
                 ss += (double)f * (double)f;
             }
             v[e] = IS_REF ? f : -2.0f * f;
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(const double *__restrict
         }
         if (hh == 0) o[Q * 256 + ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3)] = nf;
     } else {
-        if (hh == 0 && live) norm64[cell] = ss;
+        if (hh == 0 && live) norm64[cell] = ss / (scale * scale);        // UNSCALED units
     }
 }
 
@@ -87,19 +90,19 @@ hipError_t centre_launch(const double *Y, int64_t n, int g, double *centre, hipS
     return hipGetLastError();
 }
 
-hipError_t pack_ref_launch(const double *Y, int64_t n, int g, const double *centre, int ksteps,
+hipError_t pack_ref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int ksteps,
                            int64_t ntiles_total, const uint8_t *mask, float *out,
                            unsigned int *norm_max_bits, hipStream_t st)
 {
-    hipLaunchKernelGGL((pack_tiles_kernel<true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre,
+    hipLaunchKernelGGL((pack_tiles_kernel<true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre, scale,
                        ksteps, ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
     return hipGetLastError();
 }
 
-hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *centre, int ksteps,
+hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *centre, double scale, int ksteps,
                              int64_t ntiles_total, float *out, double *xnorm, hipStream_t st)
 {
-    hipLaunchKernelGGL((pack_tiles_kernel<false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre,
+    hipLaunchKernelGGL((pack_tiles_kernel<false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre, scale,
                        ksteps, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
     return hipGetLastError();
 }

@@ -131,8 +131,8 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 // MET = 1: modified-Canberra candidates from the fp32 LOWER-BOUND filter (canberra_f32.hip):
 //               every non-candidate has exact distance >= tau, so the row is certified when
 //               tau > d_(k') strictly, or when tau is the all-dimensions-out-of-window plateau (then
-//               every non-candidate is at distance exactly g and carries a larger index than the kept
-//               plateau entries of its split).
+//               every non-candidate is at distance exactly g and carries a larger index than the last
+//               entry of its list) AND the k'-th entry is either closer than g or precedes all of those.
 // MET = 2: cosine candidates from the Euclidean filter run on unit-length rows x^, y^ (float64, then
 //               packed like any other input).  The Euclidean certificate bounds ||x^-y^||^2 of every
 //               non-candidate from below by B; ||x^-y^||^2 = 2(1-cos) up to the float64 rounding of the
@@ -193,9 +193,39 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
 #pragma unroll
         for (int r = 0; r < NCL; ++r)
             if ((e >> 6) == r) dk = __shfl(key[r], e & 63, 64);
-        if (MET == 1) {
-            if (tmin != __builtin_inff()) certified = ((double)tmin > dk) || (tmin == cb_plateau);
-        } else if (tmin != __builtin_inff()) {
+        if (tmin == __builtin_inff()) {
+            // no list ever overflowed, i.e. the filter claims it dropped nothing: then EVERY unmasked reference
+            // must be among the candidates.  (References whose fp32 score is NaN -- a target that dwarfs the
+            // references by more than the fp32 range -- never pass `score < tau` and vanish without a trace.)
+            certified = (int64_t)nreal >= n_valid_total;
+        } else if (MET == 1) {
+            {
+                certified = (double)tmin > dk;
+                if (!certified && tmin == cb_plateau) {
+                    // Every reference some list dropped sits at distance exactly g and carries a larger index than
+                    // the LAST entry of that list (the lists arrive sorted by (key, index); with tau == plateau
+                    // that last entry is the largest kept plateau index).  A CANDIDATE at distance g may have had a
+                    // key below the plateau (a dimension exactly on the window edge is not "provably out") and any
+                    // index, so the k'-th entry is final only if it is closer than g or precedes every dropped one.
+                    uint32_t ie = 0;
+#pragma unroll
+                    for (int r = 0; r < NCL; ++r)
+                        if ((e >> 6) == r) ie = (uint32_t)__shfl((int)val[r], e & 63, 64);
+                    uint32_t pmin = 0xFFFFFFFFu;
+                    for (int s2 = lane; s2 < S; s2 += 64)
+                        if (cand_tau[lrow * S + s2] == cb_plateau) {
+                            const uint32_t pl = cand_idx[lrow * ncand + (int64_t)s2 * L + (L - 1)];
+                            pmin = pl < pmin ? pl : pmin;
+                        }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const uint32_t other = (uint32_t)__shfl_xor((int)pmin, o, 64);
+                        pmin = other < pmin ? other : pmin;
+                    }
+                    certified = (dk < (double)g) || (ie <= pmin);
+                }
+            }
+        } else {
             const double sx = sqrt(xnorm[row]);
             const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
             const double bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);   // tau in score units

@@ -339,18 +339,30 @@ def test_far_from_origin_and_badly_scaled_inputs(gpu_lib):
         _check(gi, gd, oi, od)
 
 
-def test_overflowing_fp32_scores_fall_back_to_the_exact_path(gpu_lib):
-    """Magnitudes whose squares overflow fp32: the filter sees inf/NaN, the guard must notice and the
-    float64 fallback must still answer exactly."""
-    Y = pca_like(600, 8, seed=63) * 1e25
-    X = pca_like(20, 8, seed=64) * 1e25
-    ix = gpu_lib.KnnIndex(600, 8, metric=0).set_ref(Y)
-    gi, gd = ix.query(X, 5)
+def test_any_unit_of_the_input_is_fine_and_fp32_overflow_is_noticed(gpu_lib):
+    """The filter works on data scaled by a power of two taken from the references, so magnitudes whose squares
+    would overflow or underflow fp32 (1e+25, 1e-30 per component; found as a wrong answer at 1e+19 by
+    tools/stress_sweep.py before the scaling existed) go through the fast path; TARGETS that dwarf the
+    references by more than the fp32 range still overflow, the guard notices and the float64 kernels answer."""
+    Yb = pca_like(600, 8, seed=63)
+    Xb = pca_like(20, 8, seed=64)
+    for sc in (1e25, 1e19, 1e-30, 1e-150):
+        ix = gpu_lib.KnnIndex(600, 8, metric=0).set_ref(Yb * sc)
+        gi, gd = ix.query(Xb * sc, 5)
+        st = ix.last_stats()
+        ix.close()
+        oi, od = oracle.knn(Xb * sc, Yb * sc, 5, 0)
+        _check(gi, gd, oi, od)
+        assert st["fallback_rows"] == 0, sc
+    Xh = Xb.copy()
+    Xh[:7] *= 1e45                                            # scaled targets exceed fp32: inf / NaN scores
+    ix = gpu_lib.KnnIndex(600, 8, metric=0).set_ref(Yb)
+    gi, gd = ix.query(Xh, 5)
     st = ix.last_stats()
     ix.close()
-    oi, od = oracle.knn(X, Y, 5, 0)
+    oi, od = oracle.knn(Xh, Yb, 5, 0)
     _check(gi, gd, oi, od)
-    assert st["fallback_rows"] == 20
+    assert st["fallback_rows"] >= 7
 
 
 def test_zero_target_rows_is_a_no_op(gpu_lib):
@@ -631,3 +643,18 @@ def test_tie_heavy_rows_take_the_wide_second_chance(gpu_lib):
     _check(hi, hd, oi, od)
     assert without >= 16                 # the situation really arises on this input
     assert with_retry < without          # ... and the second chance certifies part of it without brute force
+
+
+def test_canberra_plateau_with_window_edge_candidates(gpu_lib):
+    """Regression (found by tools/stress_sweep.py): references whose every dimension lies EXACTLY on the window
+    edge are at distance g like the all-out ones, but the filter cannot prove them out, so they enter the
+    candidate list with a key below the plateau whatever their index.  The plateau certificate must not accept
+    a row whose k'-th entry could be preceded by a dropped (all-out, lower-index) reference."""
+    n, k = 200, 15
+    Y = np.stack([100.0 + np.arange(n), -50.0 - np.arange(n)], 1).astype(np.float64)      # all-out for the target
+    Y[150:175] = [3.0, 3.0]                                                                # |x-y| == 0.25*|x| in both dims
+    X = np.array([[4.0, 4.0], [4.0, 4.0], [8.0, -8.0]])
+    gi, gd = gpu_lib.knn(X, Y, k, metric=1, dist_factor=0.25)
+    oi, od = oracle.knn(X, Y, k, 1, 0.25)
+    assert (od[0] == 2.0).all() and list(oi[0]) == list(range(15))
+    _check(gi, gd, oi, od)
