@@ -1,0 +1,125 @@
+"""Randomised parity sweep, part 2: the f16x3 filter, the shard-candidate protocol (global certification emulated
+on one GPU with numpy collectives), mask swaps on a resident index, SNN counts and the permutation null.
+    python tools/stress_sweep2.py [n_cases] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import nabo_amd  # noqa: E402
+import oracle  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from nabo_amd import _knn  # noqa: E402
+from nabo_amd._dist import ShardedKnn, merge_numpy, shard_bounds  # noqa: E402
+from nabo_amd._synth import pca_like  # noqa: E402
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+t0 = time.time()
+
+
+def fail(msg):
+    print("MISMATCH " + msg)
+    sys.exit(1)
+
+
+def data(n, m, g, flavour):
+    Y = pca_like(n, g, seed=int(rng.integers(1, 1 << 30)))
+    X = pca_like(m, g, seed=int(rng.integers(1, 1 << 30)))
+    if flavour == 1:
+        Y[rng.integers(0, n, max(1, n // 3))] = Y[rng.integers(0, n)]
+    elif flavour == 2:
+        Y, X = np.round(Y), np.round(X)
+    elif flavour == 3:
+        sc = 10.0 ** rng.integers(-15, 15)
+        Y, X = Y * sc, X * sc
+    elif flavour == 4:
+        Y = Y[np.argsort(Y[:, 0])]                  # spatially sorted: neighbours concentrate in one shard
+    return X, Y
+
+
+counts = {"f16x3": 0, "sharded": 0, "set_mask": 0, "snn": 0, "null": 0}
+for case in range(n_cases):
+    kind = ["f16x3", "sharded", "set_mask", "snn", "null"][int(rng.integers(0, 5))]
+    if kind == "f16x3":
+        n = int(rng.choice([40, 300, 3000, 20000])); m = int(rng.choice([1, 33, 400, 1500])); g = int(rng.integers(1, 64))
+        k = int(rng.integers(1, min(n, 24) + 1)); fl = int(rng.integers(0, 4))
+        X, Y = data(n, m, g, fl)
+        os.environ["NABO_L2_MODE"] = "f16x3"
+        try:
+            gi, gd = nabo_amd.knn(X, Y, k, metric=0)
+        finally:
+            del os.environ["NABO_L2_MODE"]
+        oi, od = oracle.knn(X, Y, k, 0, nthreads=16)
+        if not (np.array_equal(gi, oi) and np.array_equal(gd, od)):
+            fail("f16x3 case %d n=%d m=%d g=%d k=%d flavour=%d" % (case, n, m, g, k, fl))
+    elif kind == "sharded":
+        N = int(rng.integers(2, 9)); n = int(rng.choice([200, 3000, 20000])); m = int(rng.choice([5, 64, 301])); g = int(rng.integers(2, 60))
+        metric = int(rng.choice([0, 2])); drop = bool(rng.integers(0, 2)) and m <= n
+        k = int(rng.integers(1, min(n // N, 30) + 1)); fl = int(rng.integers(0, 5))
+        X, Y = data(n, m, g, fl)
+        if drop:
+            X = Y[:m].copy()
+        kk = k + (1 if drop else 0)
+        Ls = ShardedKnn.candidates_per_shard(kk, N)
+        dx = _knn.DeviceBuffer(X.nbytes).upload(X)
+        pi, pd, pb = [], [], []
+        for r in range(N):
+            lo, hi = shard_bounds(n, N, r)
+            ix = nabo_amd.KnnIndex(hi - lo, g, metric=metric, ref_index_base=lo).set_ref(Y[lo:hi])
+            di, dd, db = _knn.DeviceBuffer(m * Ls * 8), _knn.DeviceBuffer(m * Ls * 8), _knn.DeviceBuffer(m * 8)
+            ix.query_candidates_device(dx.ptr, m, Ls, di.ptr, dd.ptr, db.ptr)
+            pi.append(di.download((m, Ls), np.int64)); pd.append(dd.download((m, Ls), np.float64)); pb.append(db.download((m,), np.float64))
+            ix.close()
+        mi, md = merge_numpy(np.stack(pi), np.stack(pd), kk, False)
+        dk = md[:, kk - 1]
+        ok = (mi[:, kk - 1] >= 0) & (dk * dk * (1 + 1e-12) < np.min(np.stack(pb), axis=0))
+        oi, od = oracle.knn(X, Y, kk, metric, nthreads=16)
+        if not (np.array_equal(mi[ok], oi[ok]) and np.array_equal(md[ok], od[ok])):
+            fail("sharded-certified case %d N=%d n=%d m=%d g=%d k=%d metric=%d flavour=%d" % (case, N, n, m, g, kk, metric, fl))
+        if fl not in (1, 2, 4) and ok.mean() < 0.5:
+            fail("sharded: only %.0f %% of the rows certified (case %d N=%d n=%d k=%d)" % (100 * ok.mean(), case, N, n, kk))
+    elif kind == "set_mask":
+        n = int(rng.choice([100, 2000, 9000])); m = int(rng.choice([3, 70, 400])); g = int(rng.integers(1, 80))
+        metric = int(rng.integers(0, 3)); k = int(rng.integers(1, 12))
+        X, Y = data(n, m, g, int(rng.integers(0, 3)))
+        ix = nabo_amd.KnnIndex(n, g, metric=metric).set_ref(Y)
+        for rep in range(3):
+            mask = (rng.random(n) < rng.choice([0.0, 0.3, 0.97])).astype(np.uint8)
+            if mask.all():
+                mask[0] = 0
+            ix.set_mask(mask if mask.any() else None)
+            gi, gd = ix.query(X, k)
+            oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, nthreads=16)
+            if not (np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True)):
+                fail("set_mask case %d rep %d n=%d m=%d g=%d k=%d metric=%d" % (case, rep, n, m, g, k, metric))
+        ix.close()
+    elif kind == "snn":
+        n = int(rng.choice([50, 700, 5000])); k = int(rng.integers(3, 20)); m = int(rng.choice([10, 300, 2000]))   # k = 2: the reference divides by zero
+        r_idx = np.stack([rng.choice(n, k, replace=False) for _ in range(n)]) if n > k else None
+        if r_idx is None:
+            continue
+        t_idx = np.stack([rng.choice(n, k, replace=False) for _ in range(m)])
+        cnt = nabo_amd.snn_counts(t_idx, r_idx, k)
+        t, j, w = oracle.snn_edges(t_idx, r_idx, k)
+        tt, ss = np.nonzero(cnt > 0)
+        if not (np.array_equal(tt, t) and np.array_equal(t_idx[tt, ss], j)):
+            fail("snn case %d n=%d m=%d k=%d" % (case, n, m, k))
+    else:
+        n_ref = int(rng.choice([5, 60, 700])); n_t = int(rng.choice([20, 300, 2500])); kq = int(rng.integers(1, 9))
+        P = int(rng.choice([1, 31, 32, 33, 255, 256, 257, 1000])); bits = int(rng.choice([8, 16, 64]))
+        et = np.repeat(np.arange(n_t), kq); er = rng.integers(0, n_ref, n_t * kq)
+        w = rng.choice(np.round(np.arange(1, 11) / (20.0 - np.arange(1, 11)), 2), n_t * kq)
+        grp = (rng.random(n_t) < rng.choice([0.1, 0.5, 0.9])).astype(np.uint8); grp[0] = 1
+        sd = int(rng.integers(0, 1 << 62))
+        res = nabo_amd.mapping_score_null(et, er, w, grp, n_ref, n_perm=P, seed=sd, key_bits=bits)
+        ref = orc.score_null(et, er, w, grp, n_ref, P, seed=sd, key_bits=bits)
+        if not (np.array_equal(res["sizes"], ref["sizes"]) and np.array_equal(res["obs"], ref["obs"]) and
+                np.array_equal(res["n_ge"], ref["n_ge"]) and np.allclose(res["null_mean"], ref["null_mean"], rtol=1e-11, atol=1e-11)):
+            fail("null case %d n_ref=%d n_t=%d kq=%d P=%d bits=%d" % (case, n_ref, n_t, kq, P, bits))
+    counts[kind] += 1
+    if case % 50 == 49:
+        print("%d cases ok (%.0f s)" % (case + 1, time.time() - t0), flush=True)
+print("all cases equal to the oracle: %s (%.0f s)" % (counts, time.time() - t0))
