@@ -63,12 +63,17 @@ for case in range(n_cases):
         if drop:
             X = Y[:m].copy()
         kk = k + (1 if drop else 0)
+        mask = None
+        if rng.random() < 0.4:
+            mask = (rng.random(n) < rng.choice([0.1, 0.6])).astype(np.uint8)
+            if int((mask == 0).sum()) < kk:
+                mask = None
         Ls = ShardedKnn.candidates_per_shard(kk, N)
         dx = _knn.DeviceBuffer(X.nbytes).upload(X)
         pi, pd, pb = [], [], []
         for r in range(N):
             lo, hi = shard_bounds(n, N, r)
-            ix = nabo_amd.KnnIndex(hi - lo, g, metric=metric, ref_index_base=lo).set_ref(Y[lo:hi])
+            ix = nabo_amd.KnnIndex(hi - lo, g, metric=metric, ref_index_base=lo).set_ref(Y[lo:hi], ref_mask=None if mask is None else mask[lo:hi])
             di, dd, db = _knn.DeviceBuffer(m * Ls * 8), _knn.DeviceBuffer(m * Ls * 8), _knn.DeviceBuffer(m * 8)
             ix.query_candidates_device(dx.ptr, m, Ls, di.ptr, dd.ptr, db.ptr)
             pi.append(di.download((m, Ls), np.int64)); pd.append(dd.download((m, Ls), np.float64)); pb.append(db.download((m,), np.float64))
@@ -76,7 +81,7 @@ for case in range(n_cases):
         mi, md = merge_numpy(np.stack(pi), np.stack(pd), kk, False)
         dk = md[:, kk - 1]
         ok = (mi[:, kk - 1] >= 0) & (dk * dk * (1 + 1e-12) < np.min(np.stack(pb), axis=0))
-        oi, od = oracle.knn(X, Y, kk, metric, nthreads=16)
+        oi, od = oracle.knn(X, Y, kk, metric, ref_mask=mask, nthreads=16)
         if not (np.array_equal(mi[ok], oi[ok]) and np.array_equal(md[ok], od[ok])):
             fail("sharded-certified case %d N=%d n=%d m=%d g=%d k=%d metric=%d flavour=%d" % (case, N, n, m, g, kk, metric, fl))
         if fl not in (1, 2, 4) and ok.mean() < 0.5:
