@@ -4,7 +4,7 @@
 TEST INFRASTRUCTURE ONLY.  Executed in the build container (where /root/reference is
 mounted) with /opt/conda/bin/python3.9 (h5py 3.3, numpy 1.26, networkx 2.6):
 
-    /opt/conda/bin/python3.9 oracle/gen_golden.py [--only kernels,mapping_small,dup,c1]
+    /opt/conda/bin/python3.9 oracle/gen_golden.py [--only kernels,mapping_small,dup,c1,minis]
 
 It never travels to / runs on the GPU box; only its outputs (tests/golden/*.npz: inputs
 and expected outputs, no reference source) are committed.
@@ -233,6 +233,36 @@ def gen_c1(mp, gr):
                      with_scores=True, seeds=[1001, 2001])
 
 
+MINIS = [
+    # tag, n_ref, n_target, comps stored, use_comps, k, dist_factor, chunk_size, n_ignored, name style
+    ("mini_0", 150, 120, 12, 12, 5, 0.25, 50, 0, "pad"),
+    ("mini_1", 180, 90, 25, 9, 7, 0.1, 37, 6, "plain"),
+    ("mini_2", 120, 140, 8, 8, 11, 1.0, 1000, 3, "pad"),
+    ("mini_3", 200, 60, 30, 30, 3, 0.5, 64, 0, "mixed"),
+    ("mini_4", 90, 200, 16, 5, 15, 0.25, 16, 10, "plain"),
+    ("mini_5", 160, 100, 40, 22, 9, 2.0, 33, 2, "pad"),
+]
+
+
+def gen_minis(mp, gr):
+    """Small full runs over a spread of parameters (use_comps < stored comps, k from 3 to 15, dist_factor from
+    0.1 to 2, chunk sizes that do and do not divide the cell counts, ignore lists, three naming styles)."""
+    for i, (tag, nr, nt, comps, uc, k, f, chunk, nign, style) in enumerate(MINIS):
+        ref = pca_like(nr, comps, seed=5000 + i)
+        tgt = pca_like(nt, comps, seed=6000 + i)
+        if style == "pad":
+            rn, tn = ["R%04d" % j for j in range(nr)], ["T%04d" % j for j in range(nt)]
+        elif style == "plain":
+            rn, tn = ["R%d" % j for j in range(nr)], ["c%d" % j for j in range(nt)]
+        else:
+            rn = [("cell-%d" % j if j % 3 else "AAC%dGT" % j) for j in range(nr)]
+            tn = ["t.%d" % (j * 7) for j in range(nt)]
+        rng = np.random.default_rng(7000 + i)
+        ignore = [rn[j] for j in sorted(rng.choice(nr, nign, replace=False))] if nign else None
+        run_mapping_case(mp, gr, tag, ref, rn, [("TG", tn, tgt, ignore)], (uc, k, f, chunk), min(32, nr - 1), min(32, nr - 1),
+                         store_inputs=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="kernels,mapping_small,dup")
@@ -248,6 +278,8 @@ def main():
         gen_dup(mp, gr)
     if "c1" in todo:
         gen_c1(mp, gr)
+    if "minis" in todo:
+        gen_minis(mp, gr)
 
 
 if __name__ == "__main__":

@@ -3,7 +3,7 @@ everything the reference wrote for the same inputs.  Executed by test_mapping.py
 when h5py is importable, otherwise under an interpreter that has it.
 
     python tests/_mapping_case.py validate     # API / validation rules only (no GPU needed)
-    python tests/_mapping_case.py small|dup|c1 # full runs (GPU)
+    python tests/_mapping_case.py small|dup|c1|mini_0..mini_5   # full runs (GPU)
 """
 import io
 import json
@@ -285,5 +285,5 @@ def run_validate():
 if __name__ == "__main__":
     mode = sys.argv[1]
     res = run_validate() if mode == "validate" else run_case({"small": "mapping_small", "dup": "dup",
-                                                                "c1": "c1_3k"}[mode])
+                                                                "c1": "c1_3k"}.get(mode, mode))
     print("RESULT " + json.dumps(res))

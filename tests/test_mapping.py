@@ -45,7 +45,7 @@ def test_mapping_api_validation_rules():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["small", "dup", "c1"])
+@pytest.mark.parametrize("mode", ["small", "dup", "c1"] + ["mini_%d" % i for i in range(6)])
 def test_mapping_end_to_end_vs_reference_outputs(mode):
     res = _run(mode)
     assert res["ref_cells_equal"]

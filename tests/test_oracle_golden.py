@@ -131,3 +131,28 @@ def test_snn_edges_match_reference_graph(golden):
     fixw = 0.5 / ((2 * (k - 1)) - 0.5)
     ref_edges = _graph_sets(g, "ref_graph")
     assert mine == {e for e in ref_edges if e[2] != fixw}
+
+
+@pytest.mark.parametrize("tag", ["mini_%d" % i for i in range(6)])
+def test_mini_cases_order_rows_and_target_graph(golden, tag):
+    """Six small full runs of the reference over a spread of parameters (use_comps < stored components, k 3..15,
+    dist_factor 0.1..2, chunk sizes that do / do not divide the cell counts, ignore lists, three naming styles):
+    the oracle reproduces the order rows, their distances and the target SNN graph."""
+    g = golden(tag)
+    uc, k, _ = [int(v) for v in g["params"]]
+    f = float(g["dist_factor"])
+    nk = g["ref_idx"].shape[1]
+    ref = _ordered(g, "ref_names", "ref_cells", "ref")[:, :uc]
+    idx, dist = oracle.knn(ref, ref, nk, oracle.EUCLIDEAN, drop_first=True)
+    ok = ~g["ref_ties"]
+    assert np.array_equal(idx[ok][:, :k], g["ref_idx"][ok][:, :k]) and np.array_equal(dist[:, :k], g["ref_dist"][:, :k])
+    X = _ordered(g, "t_TG_names", "t_TG_cells", "t_TG_data")[:, :uc]
+    mask = np.isin(g["ref_cells"], g["t_TG_ignore"]).astype(np.uint8)
+    idx, dist = oracle.knn(X, ref, nk, oracle.MOD_CANBERRA, f, ref_mask=mask)
+    tt = g["t_TG_ties"]
+    assert np.array_equal(idx[~tt][:, :k], g["t_TG_idx"][~tt][:, :k]) and np.array_equal(dist[:, :k], g["t_TG_dist"][:, :k])
+    if not tt.any() and not g["ref_ties"].any():
+        cells = list(g["ref_cells"])
+        t, j, w = oracle.snn_edges(g["t_TG_idx"].astype(np.int64), g["ref_idx"].astype(np.int64), k)
+        mine = {(str(g["t_TG_cells"][a]) + "_TG", cells[b] + "_WT", float(c)) for a, b, c in zip(t, j, w)}
+        assert mine == _graph_sets(g, "t_TG_graph")
