@@ -47,13 +47,17 @@ for case in range(n_cases):
         n = int(rng.choice([40, 300, 3000, 20000])); m = int(rng.choice([1, 33, 400, 1500])); g = int(rng.integers(1, 64))
         k = int(rng.integers(1, min(n, 24) + 1)); fl = int(rng.integers(0, 4))
         X, Y = data(n, m, g, fl)
+        mask = (rng.random(n) < 0.3).astype(np.uint8) if rng.random() < 0.3 else None
+        drop = bool(rng.integers(0, 2)) and m <= n and k < n
+        if drop:
+            X = Y[:m].copy()
         os.environ["NABO_L2_MODE"] = "f16x3"
         try:
-            gi, gd = nabo_amd.knn(X, Y, k, metric=0)
+            gi, gd = nabo_amd.knn(X, Y, k, metric=0, ref_mask=mask, drop_first=drop)
         finally:
             del os.environ["NABO_L2_MODE"]
-        oi, od = oracle.knn(X, Y, k, 0, nthreads=16)
-        if not (np.array_equal(gi, oi) and np.array_equal(gd, od)):
+        oi, od = oracle.knn(X, Y, k, 0, ref_mask=mask, drop_first=drop, nthreads=16)
+        if not (np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True)):
             fail("f16x3 case %d n=%d m=%d g=%d k=%d flavour=%d" % (case, n, m, g, k, fl))
     elif kind == "sharded":
         N = int(rng.integers(2, 9)); n = int(rng.choice([200, 3000, 20000])); m = int(rng.choice([5, 64, 301])); g = int(rng.integers(2, 60))
