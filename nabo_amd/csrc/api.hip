@@ -379,7 +379,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
     if ((rc = apply_mask(ix, ref_mask))) return rc;
     if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ref_tiles = (ix->n + 31) / 32;
-        ix->ref_tiles_alloc = ix->ref_tiles + 16;      // room for split padding (+inf-norm tiles)
+        ix->ref_tiles_alloc = ix->ref_tiles + 64;      // room for split padding (+inf-norm tiles; up to 32 splits)
         ix->packed_f32 = ix->packed_f16 = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
         if (ix->metric == NABO_METRIC_COSINE) {
@@ -556,7 +556,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 if (S2 > 1) { gx_tail = tail; gx_main = gx - tail; }
             }
         }
-        if (S > 8) S = 8;
+        if (S > 1024 / L) S = 1024 / L;                     // refine merges at most 1024 candidates per row (32 or 16 lists)
         if (S < 1) S = 1;
         if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
         const int64_t tps = (ix->ref_tiles + S - 1) / S;
