@@ -591,6 +591,7 @@ hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const do
     else if (ncl <= 2) NABO_RC(2);
     else if (ncl <= 4) NABO_RC(4);
     else if (ncl <= 8) NABO_RC(8);
+    else if (ncl <= 16) NABO_RC(16);
     else return hipErrorInvalidValue;
 #undef NABO_RC
     return hipGetLastError();

@@ -40,9 +40,9 @@ def data(n, m, g, flavour):
     return X, Y
 
 
-counts = {"f16x3": 0, "sharded": 0, "set_mask": 0, "snn": 0, "null": 0}
+counts = {"f16x3": 0, "sharded": 0, "set_mask": 0, "snn": 0, "null": 0, "sequence": 0, "lattice": 0, "pairwise": 0}
 for case in range(n_cases):
-    kind = ["f16x3", "sharded", "set_mask", "snn", "null"][int(rng.integers(0, 5))]
+    kind = ["f16x3", "sharded", "set_mask", "snn", "null", "sequence", "lattice", "pairwise"][int(rng.integers(0, 8))]
     if kind == "f16x3":
         n = int(rng.choice([40, 300, 3000, 20000])); m = int(rng.choice([1, 33, 400, 1500])); g = int(rng.integers(1, 64))
         k = int(rng.integers(1, min(n, 24) + 1)); fl = int(rng.integers(0, 4))
@@ -105,6 +105,45 @@ for case in range(n_cases):
             if not (np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True)):
                 fail("set_mask case %d rep %d n=%d m=%d g=%d k=%d metric=%d" % (case, rep, n, m, g, k, metric))
         ix.close()
+    elif kind == "sequence":
+        # one resident index, several queries of different shapes / list widths / modes: workspace reuse
+        n = int(rng.choice([300, 4000, 25000])); g = int(rng.integers(1, 100)); metric = int(rng.integers(0, 3))
+        _, Y = data(n, 1, g, int(rng.integers(0, 3)))
+        ix = nabo_amd.KnnIndex(n, g, metric=metric).set_ref(Y)
+        for rep in range(4):
+            m = int(rng.choice([1, 40, 300, 1200])); k = int(rng.choice([1, 5, 15, 24, 25, 40, 55])); k = min(k, n - 1)
+            drop = bool(rng.integers(0, 2)) and m <= n
+            X = Y[:m].copy() if drop else pca_like(m, g, seed=int(rng.integers(1, 1 << 30)))
+            gi, gd = ix.query(X, k, drop_first=drop)
+            oi, od = oracle.knn(X, Y, k, metric, 0.25, drop_first=drop, nthreads=16)
+            if not (np.array_equal(gi, oi) and np.array_equal(gd, od, equal_nan=True)):
+                fail("sequence case %d rep %d n=%d m=%d g=%d k=%d metric=%d drop=%s" % (case, rep, n, m, g, k, metric, drop))
+        ix.close()
+    elif kind == "lattice":
+        # integer lattices: large shells of exactly equal distances (second-chance pass, exact kernels, tie order)
+        gdim = int(rng.integers(2, 6)); side = int(rng.integers(4, 11)); metric = int(rng.choice([0, 0, 2, 1]))
+        Y = np.stack(np.meshgrid(*[np.arange(side)] * gdim, indexing="ij"), -1).reshape(-1, gdim).astype(np.float64)
+        if len(Y) > 12000:
+            Y = Y[rng.choice(len(Y), 12000, replace=False)]
+        if metric != 0:
+            Y = Y + 1.0                                   # keep away from the zero vector / zero components
+        m = int(rng.choice([10, 200, 900])); k = int(rng.choice([3, 15, 24, 30])); k = min(k, len(Y) - 1)
+        X = Y[rng.choice(len(Y), m, replace=True)].copy()
+        if rng.random() < 0.5:
+            os.environ["NABO_SPLITS"] = "1"
+        try:
+            gi, gd = nabo_amd.knn(X, Y, k, metric=metric, dist_factor=0.25)
+        finally:
+            os.environ.pop("NABO_SPLITS", None)
+        oi, od = oracle.knn(X, Y, k, metric, 0.25, nthreads=16)
+        if not (np.array_equal(gi, oi) and np.array_equal(gd, od)):
+            fail("lattice case %d dim=%d side=%d n=%d m=%d k=%d metric=%d" % (case, gdim, side, len(Y), m, k, metric))
+    elif kind == "pairwise":
+        m = int(rng.integers(1, 200)); n = int(rng.integers(1, 400)); g = int(rng.integers(1, 129)); metric = int(rng.integers(0, 3))
+        X, Y = data(n, m, g, int(rng.integers(0, 4)))
+        f = float(rng.choice([0.1, 0.25, 1.0, 3.0]))
+        if not np.array_equal(nabo_amd.pairwise(X, Y, metric, f), oracle.pairwise(X, Y, metric, f)):
+            fail("pairwise case %d m=%d n=%d g=%d metric=%d f=%g" % (case, m, n, g, metric, f))
     elif kind == "snn":
         n = int(rng.choice([50, 700, 5000])); k = int(rng.integers(3, 20)); m = int(rng.choice([10, 300, 2000]))   # k = 2: the reference divides by zero
         r_idx = np.stack([rng.choice(n, k, replace=False) for _ in range(n)]) if n > k else None
