@@ -131,6 +131,14 @@ def run_case(tag):
                 out["t_%s_score_maxerr" % tn] = float(max(abs(sc[n] - gs[n]) for n in gs))
                 sc2 = nabo_amd.get_mapping_score(map_fn, "WT", tn)          # the product's own function
                 out["t_%s_score_api_maxerr" % tn] = float(max(abs(sc2[n] - gs[n]) for n in gs))
+        # permutation null read straight from the mapping file (needs two mapped samples): its observed score is
+        # the reference's mapping score of the sample of interest
+        if len(targets) >= 2:
+            ta, tb = targets[0][0], targets[1][0]
+            nul = nabo_amd.get_mapping_score_null(map_fn, "WT", ta, tb, n_perm=64, seed=5)
+            sc_a = nabo_amd.get_mapping_score(map_fn, "WT", ta)
+            out["null_obs_is_mapping_score"] = bool(all(abs(nul[n][0] - sc_a[n]) <= 1e-9 * max(1.0, abs(sc_a[n])) for n in sc_a))
+            out["null_pvalues_in_range"] = bool(all(1.0 / 65 <= v[1] <= 1.0 for v in nul.values()))
         # use_stored_distances: rebuild the graphs from the stored lists only
         with redirect_stdout(buf):
             m2 = nabo_amd.Mapping(map_fn, "WT", ref_fn, "data")

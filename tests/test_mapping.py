@@ -59,3 +59,5 @@ def test_mapping_end_to_end_vs_reference_outputs(mode):
             assert v < 1e-9, (k, v)
     assert res["stored_distances_same_graph"] and res["columnar_same_graph"] and res["dense_input_same_graph"]
     assert res["target_metric_euclidean"]
+    if "null_obs_is_mapping_score" in res:
+        assert res["null_obs_is_mapping_score"] and res["null_pvalues_in_range"]
