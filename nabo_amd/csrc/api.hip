@@ -543,9 +543,23 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (!forced) {
             S = 1;
             if (gx < slots) {
-                S = (int)((2 * slots + gx - 1) / gx);
-                const int64_t max_by_tiles = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
-                if (S > max_by_tiles) S = (int)max_by_tiles;
+                // Fewer workgroups than the chip holds: pick the split count from a cost model.  A workgroup costs
+                // (reference tiles it streams) x t_tile for the MFMA chains PLUS a per-row list warm-up that does
+                // not shrink with the stream (~lkeep * ln(stream / lkeep) appends per row: 5.1 ms per workgroup at
+                // lkeep = 24 over 1M references, measured); every split pays the warm-up again.
+                int64_t s_hi = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
+                if (s_hi > 1024 / L) s_hi = 1024 / L;
+                // ms per reference tile and workgroup, measured: 105 ms / 31250 tiles (fp32, 256 rows, 25 k-steps); 1.2 us f16x3
+                const double t_tile = use_h ? 1.2e-3 * ix->ks16 / 4.0 : 3.36e-3 * (rows_per_wg / 256.0) * (ix->ksteps / 25.0);
+                double best = 1e30;
+                for (int s2 = 1; s2 <= (int)s_hi; ++s2) {
+                    const double rounds = (double)((gx * s2 + slots - 1) / slots);
+                    const double stream = (double)ix->n / s2;
+                    double lg = std::log(stream / lkeep > 2.0 ? stream / lkeep : 2.0);
+                    const double warm = 5.1 * (lkeep / 24.0) * (lg / 10.6) * (rows_per_wg / 256.0);
+                    const double cost = rounds * ((double)ix->ref_tiles / s2 * t_tile + warm);
+                    if (cost < best * (1.0 - 1e-3)) { best = cost; S = s2; }
+                }
             } else if (gx % slots != 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && ix->ref_tiles >= 256) {
                 const int64_t tail = gx % slots;
                 double best = 1.0;
