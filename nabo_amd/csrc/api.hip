@@ -517,10 +517,20 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             nabo::l2h_topk_geometry(ix->ks16, &rows_per_wg, &wg_per_cu, &lkeep_max);
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
+        // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
+        // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
+        bool r1 = false;
         if (!use_h) {
             lkeep_max = L;
             nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu);
+            const int r1_mode = env_int("NABO_L2_R1", -1);             // -1 auto, 0 never, 1 always (experiments)
+            if (epl == 1 && ix->ksteps <= 25 && r1_mode != 0 &&
+                (r1_mode == 1 || (m + rows_per_wg - 1) / rows_per_wg < (int64_t)ix->n_cu * wg_per_cu)) {
+                r1 = true;
+                nabo::l2_topk_geometry(ix->ksteps, -1, &rows_per_wg, &wg_per_cu);
+            }
         }
+        const int epl_launch = r1 ? -1 : epl;
         if ((rc = ensure_packed(ix, use_h))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
@@ -608,11 +618,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(), st));
         } else {
             if (gx_main > 0)
-                HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,
+                HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl_launch, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,
                                              (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
                                              ix->cand_tau.as<float>(), st));
             if (gx_tail > 0)
-                HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps2, S2,
+                HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl_launch, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps2, S2,
                                              (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
                                              ix->cand_tau2.as<float>(), st));
         }

@@ -110,7 +110,7 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
 // Two waves per SIMD need <= 256 VGPRs; that holds while the resident target fragments
 // (R*KSTEPS registers) stay <= 64 -- larger shapes run one wave per SIMD without spilling.
 template <int KSTEPS, int R, int EPL, int ROWN>
-__global__ __launch_bounds__(256, (R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kernel(const float *__restrict__ Xpk,
+__global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kernel(const float *__restrict__ Xpk,
                                                                                   const float *__restrict__ Ypk,
                                                                                   int tiles_per_split,
                                                                                   int64_t tile_off, int lkeep,
@@ -210,9 +210,10 @@ static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_s
 // Rows per workgroup and co-resident workgroups per CU of the variant that will run.
 void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu)
 {
-    const int R = epl == 1 ? 2 : 1;
-    *rows_per_wg = 4 * R * 32;
+    int R = epl == 1 ? 2 : 1;
     *wg_per_cu = (R * ksteps <= 64) ? 2 : 1;
+    if (epl == -1) { R = 1; *wg_per_cu = 3; }          // epl = -1: the one-row-block, three-waves-per-SIMD variant
+    *rows_per_wg = 4 * R * 32;
 }
 
 // ksteps must be one of the instantiated values; epl 1 -> lists of <= 32 (R=2), 2 -> <= 64 (R=1).
@@ -223,6 +224,9 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
 {
 #define NABO_CASE(KS)                                                                                                 \
     case KS:                                                                                                          \
+        if (epl == -1)                                                                                                \
+            return launch_one<KS, 1, 1, 40>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,      \
+                                            cand_tau, st);                                                            \
         return epl == 1 ? launch_one<KS, 2, 1, 40>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st)                                                       \
                         : launch_one<KS, 1, 2, 80>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
