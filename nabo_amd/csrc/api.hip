@@ -524,8 +524,17 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             lkeep_max = L;
             nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu);
             const int r1_mode = env_int("NABO_L2_R1", -1);             // -1 auto, 0 never, 1 always (experiments)
+            // ... and also when the list warm-up is a large share of a workgroup's time (short reference streams,
+            // e.g. one shard of eight): the same per-workgroup model as the split choice below, threshold measured
+            // (the variant pays ~8 % more per reference tile, it wins from ~7.5 % warm-up share on)
+            int lk_est = cand_mode ? (kk < 4 ? 4 : kk) : (kk + 8 < 16 ? 16 : kk + 8);
+            if (lk_est > L) lk_est = L;
+            const double stream_ms = (double)((ix->n + 31) / 32) * 3.36e-3 * (ix->ksteps / 25.0);
+            const double lg_est = std::log((double)ix->n / lk_est > 2.0 ? (double)ix->n / lk_est : 2.0);
+            const double warm_ms = 5.1 * (lk_est / 24.0) * (lg_est / 10.6);
             if (epl == 1 && ix->ksteps <= 25 && r1_mode != 0 &&
-                (r1_mode == 1 || (m + rows_per_wg - 1) / rows_per_wg < (int64_t)ix->n_cu * wg_per_cu)) {
+                (r1_mode == 1 || (m + rows_per_wg - 1) / rows_per_wg < (int64_t)ix->n_cu * wg_per_cu ||
+                 warm_ms > 0.075 * stream_ms)) {
                 r1 = true;
                 nabo::l2_topk_geometry(ix->ksteps, -1, &rows_per_wg, &wg_per_cu);
             }
