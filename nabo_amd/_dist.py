@@ -19,8 +19,8 @@ float64.  Instead each shard emits its first Ls < k' order-row entries (exact di
 on the squared distance of everything it did not emit (nabo_index_query_candidates); the owner of a
 target row merges the N*Ls entries and accepts the k'-th merged distance d when d^2 < min over shards
 of the bound -- then no unreported reference anywhere can enter or tie.  Rows that fail (a shard held
-more than Ls of the global top-k': 151 of 1M rows at N=8, Ls=9, measured) are re-solved exactly in a
-second, tiny round with the certified local query.  Same bits, ~half the list maintenance per shard.
+more than Ls of the global top-k': Ls is chosen so that < 0.1 rows of a batch are expected to) are re-solved
+exactly in a second, tiny round with the certified local query.  Same bits, ~half the list maintenance per shard.
 
 torch is used for the process group, the collectives and (on GPU) tensor memory only; the
 compute goes through the C ABI with raw pointers.  The two compute steps are injectable so
@@ -97,11 +97,28 @@ class ShardedKnn:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
 
     @staticmethod
-    def candidates_per_shard(kk, world):
-        """Entries each shard emits: the expected share k'/N, 50 % head room, +6; never fewer than
-        ceil(k'/N) (the merge must be able to produce k' entries) and never more than k'+8."""
-        ls = max(8, -(-3 * kk // (2 * world)) + 6, -(-kk // world))
-        return min(ls, kk + 8, 32)
+    def candidates_per_shard(kk, world, m=None):
+        """Entries each shard emits.  A row needs the second round when some shard holds at least Ls of its global
+        top-k'; for exchangeable shards that is world * P[Bin(k', 1/world) >= Ls] per row.  With `m` (target rows)
+        given, Ls is the smallest length that leaves an expected < 0.1 such rows in the whole batch -- never more
+        than k'+1 (a shard cannot hold more than k' of the top k') -- because a longer list costs ~0.7 ms per
+        entry and step while the second round costs ~3.5 ms plus three more collectives.  Without `m`: the share
+        k'/N with 50 % head room, +6."""
+        cap = min(kk + 1, 32)
+        if m is None:
+            ls = max(8, -(-3 * kk // (2 * world)) + 6, -(-kk // world))
+            return min(ls, kk + 8, 32)
+        from math import comb
+        p = 1.0 / world
+        tail = 0.0
+        ls = cap
+        for j in range(kk, 0, -1):                       # tail = P[Bin(kk, p) >= j]
+            tail += comb(kk, j) * p ** j * (1.0 - p) ** (kk - j)
+            if tail * world * m >= 0.1:
+                ls = j + 1
+                break
+            ls = j
+        return max(min(ls, cap), -(-kk // world), 1)
 
     def query(self, X, m, k, drop_first=False):
         import torch
@@ -140,7 +157,7 @@ class ShardedKnn:
         d0 = 1 if drop_first else 0
         kk = k + d0
         N, dev = self.world, self.device
-        Ls = self.candidates_per_shard(kk, N)
+        Ls = self.candidates_per_shard(kk, N, m)
         ci, cd, cb = self.local_cand(X, Ls)
         mr = (m + N - 1) // N
         m_pad = mr * N

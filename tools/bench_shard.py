@@ -24,7 +24,7 @@ for N in (1, 2, 4, 8):
     for name in ("local", "cand"):
         if name == "cand" and N == 1:
             continue
-        nc = candidates_per_shard(kk, N)
+        nc = candidates_per_shard(kk, N, m)
         ts = []
         for it in range(4):
             t0 = time.perf_counter()

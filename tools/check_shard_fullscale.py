@@ -20,7 +20,7 @@ X = pca_like(m, d, seed=2003)
 ix = nabo_amd.KnnIndex(n, d, metric=0).set_ref(Y)
 ri, rd = ix.query(X, k)
 ix.close()
-Ls = ShardedKnn.candidates_per_shard(k, N)
+Ls = ShardedKnn.candidates_per_shard(k, N, m)
 dx = _knn.DeviceBuffer(X.nbytes).upload(X)
 pi = np.empty((N, m, Ls), dtype=np.int64)
 pd = np.empty((N, m, Ls), dtype=np.float64)

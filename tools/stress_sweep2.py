@@ -72,7 +72,7 @@ for case in range(n_cases):
             mask = (rng.random(n) < rng.choice([0.1, 0.6])).astype(np.uint8)
             if int((mask == 0).sum()) < kk:
                 mask = None
-        Ls = ShardedKnn.candidates_per_shard(kk, N)
+        Ls = ShardedKnn.candidates_per_shard(kk, N, m)
         dx = _knn.DeviceBuffer(X.nbytes).upload(X)
         pi, pd, pb = [], [], []
         for r in range(N):
