@@ -151,6 +151,15 @@ int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const
                     int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge, double *out_mean,
                     double *out_sd, int64_t *out_sizes /* [n_perm] or NULL */);
 
+/* The same null from an edge LIST in any order (what a mapping yields: one (reference cell, target cell, weight)
+ * triple per kept neighbour): the CSR is built on the device by a stable sort on edge_ref, so a reference
+ * node's edges are summed in the order the caller listed them -- results are identical to nabo_score_null on
+ * the CSR a stable host sort would give.  HOST pointers; n_edges < 2^32-1. */
+int nabo_score_null_edges(int32_t device, int64_t n_ref, int64_t n_edges, const int64_t *edge_ref,
+                          const int64_t *edge_t, const double *edge_w, int64_t n_t, const uint8_t *group,
+                          int32_t n_perm, uint64_t seed, int32_t key_bits, double multiplier, double *out_obs,
+                          int64_t *out_nge, double *out_mean, double *out_sd, int64_t *out_sizes);
+
 /* ---- plain device-memory helpers so a ctypes host needs no other GPU binding ------------ */
 int nabo_dev_malloc(int32_t device, void **ptr, size_t bytes);
 int nabo_dev_free(int32_t device, void *ptr);

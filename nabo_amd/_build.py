@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnabo_knn.so")
-SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "score_null.hip"]
+SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "score_null.hip", "csr_build.hip"]
 # per-file extra flags: keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
 # v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
 FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}

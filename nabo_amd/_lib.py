@@ -21,7 +21,7 @@ SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
     "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
     "nabo_index_query_candidates",
-    "nabo_index_last_stats", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_dev_malloc", "nabo_dev_free",
+    "nabo_index_last_stats", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
 ]
 

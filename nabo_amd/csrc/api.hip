@@ -90,6 +90,11 @@ hipError_t null_score_launch(int64_t n_ref, const int64_t *row_ptr, const int64_
                              double *out_obs, int64_t *out_nge, double *out_mean, double *out_sd, hipStream_t st);
 hipError_t snn_counts_launch(const int64_t *t_idx, int64_t m, const int64_t *r_idx, int64_t n, int k, int32_t *out,
                              hipStream_t st);
+hipError_t csr_sort_temp_bytes(int64_t E, int64_t n_ref, size_t *bytes);
+hipError_t csr_build_launch(const int64_t *edge_r, const int64_t *edge_t, const double *edge_w, int64_t E, int64_t n_ref,
+                            int64_t n_t, uint32_t *keys_a, uint32_t *pos_a, uint32_t *keys_b, uint32_t *pos_b, void *temp,
+                            size_t temp_bytes, int64_t *row_ptr, int64_t *out_t, double *out_w, unsigned int *flag,
+                            hipStream_t st);
 }  // namespace nabo
 
 namespace {
@@ -1007,23 +1012,32 @@ int nabo_snn_counts(int32_t device, const int64_t *t_idx, int64_t m, const int64
     return NABO_OK;
 }
 
-int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const int64_t *edge_t,
-                    const double *edge_w, int64_t n_t, const uint8_t *group, int32_t n_perm, uint64_t seed,
-                    int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge, double *out_mean,
-                    double *out_sd, int64_t *out_sizes)
+// row_ptr != NULL: edges in CSR by reference node (edge_r unused); row_ptr == NULL: COO, E = n_edges, the CSR is built
+// on the device by a stable sort (csr_build.hip).
+static int score_null_impl(int32_t device, int64_t n_ref, const int64_t *row_ptr, int64_t n_edges, const int64_t *edge_r,
+                           const int64_t *edge_t, const double *edge_w, int64_t n_t, const uint8_t *group, int32_t n_perm,
+                           uint64_t seed, int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge,
+                           double *out_mean, double *out_sd, int64_t *out_sizes)
 {
-    if (!row_ptr || !group || !out_obs || !out_nge || !out_mean || !out_sd) return fail(NABO_E_INVALID, "NULL argument");
+    const bool coo = row_ptr == nullptr;
+    if (!group || !out_obs || !out_nge || !out_mean || !out_sd) return fail(NABO_E_INVALID, "NULL argument");
     if (n_ref < 1 || n_t < 1) return fail(NABO_E_INVALID, "empty operand");
     if (n_perm < 1 || n_perm > 4096) return fail(NABO_E_UNSUPPORTED, "n_perm=%d: 1..4096 supported", n_perm);
     if (key_bits < 8 || key_bits > 64 || key_bits % 8) return fail(NABO_E_INVALID, "key_bits must be 8, 16, .., 64");
     if (n_ref >= 0x7FFFFFFFll) return fail(NABO_E_UNSUPPORTED, "n_ref too large for one launch");
-    const int64_t E = row_ptr[n_ref];
-    if (row_ptr[0] != 0 || E < 0) return fail(NABO_E_INVALID, "row_ptr must start at 0");
+    const int64_t E = coo ? n_edges : row_ptr[n_ref];
+    if (coo) {
+        if (E < 0) return fail(NABO_E_INVALID, "n_edges < 0");
+        if (E >= 0xFFFFFFFFll) return fail(NABO_E_UNSUPPORTED, "n_edges=%lld: fewer than 2^32-1 supported", (long long)E);
+        if (E > 0 && !edge_r) return fail(NABO_E_INVALID, "NULL edge arrays");
+    } else {
+        if (row_ptr[0] != 0 || E < 0) return fail(NABO_E_INVALID, "row_ptr must start at 0");
+        for (int64_t r = 0; r < n_ref; ++r)
+            if (row_ptr[r + 1] < row_ptr[r]) return fail(NABO_E_INVALID, "row_ptr must be non-decreasing");
+        for (int64_t e = 0; e < E; ++e)
+            if (edge_t[e] < 0 || edge_t[e] >= n_t) return fail(NABO_E_INVALID, "edge_t[%lld] out of range", (long long)e);
+    }
     if (E > 0 && (!edge_t || !edge_w)) return fail(NABO_E_INVALID, "NULL edge arrays");
-    for (int64_t r = 0; r < n_ref; ++r)
-        if (row_ptr[r + 1] < row_ptr[r]) return fail(NABO_E_INVALID, "row_ptr must be non-decreasing");
-    for (int64_t e = 0; e < E; ++e)
-        if (edge_t[e] < 0 || edge_t[e] >= n_t) return fail(NABO_E_INVALID, "edge_t[%lld] out of range", (long long)e);
     int64_t n_a = 0;
     for (int64_t t = 0; t < n_t; ++t) n_a += group[t] ? 1 : 0;
     if (n_a < 1) return fail(NABO_E_INVALID, "the group of interest is empty");
@@ -1032,8 +1046,10 @@ int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const
     const int P = n_perm, W = (P + 1 + 31) / 32;
     hipStream_t st = nullptr;
     DevBuf d_rp, d_et, d_ew, d_grp, d_pre, d_hist, d_bits, d_nl, d_obs, d_nge, d_mean, d_sd;
+    DevBuf c_r, c_t, c_w, c_ka, c_kb, c_pa, c_pb, c_tmp, c_flag;          // COO staging + sort scratch
     auto release = [&]() {
-        DevBuf *all[] = {&d_rp, &d_et, &d_ew, &d_grp, &d_pre, &d_hist, &d_bits, &d_nl, &d_obs, &d_nge, &d_mean, &d_sd};
+        DevBuf *all[] = {&d_rp, &d_et, &d_ew, &d_grp, &d_pre, &d_hist, &d_bits, &d_nl, &d_obs, &d_nge, &d_mean, &d_sd,
+                         &c_r,  &c_t,  &c_w,  &c_ka,  &c_kb,  &c_pa,   &c_pb,   &c_tmp, &c_flag};
         for (DevBuf *b : all) b->release();
     };
 #define NS_TRY(expr)                                                                     \
@@ -1064,10 +1080,43 @@ int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const
     NS_RES(d_nge, (size_t)n_ref * 8);
     NS_RES(d_mean, (size_t)n_ref * 8);
     NS_RES(d_sd, (size_t)n_ref * 8);
-    NS_TRY(hipMemcpyAsync(d_rp.p, row_ptr, (size_t)(n_ref + 1) * 8, hipMemcpyHostToDevice, st));
-    if (E) {
-        NS_TRY(hipMemcpyAsync(d_et.p, edge_t, (size_t)E * 8, hipMemcpyHostToDevice, st));
-        NS_TRY(hipMemcpyAsync(d_ew.p, edge_w, (size_t)E * 8, hipMemcpyHostToDevice, st));
+    if (!coo) {
+        NS_TRY(hipMemcpyAsync(d_rp.p, row_ptr, (size_t)(n_ref + 1) * 8, hipMemcpyHostToDevice, st));
+        if (E) {
+            NS_TRY(hipMemcpyAsync(d_et.p, edge_t, (size_t)E * 8, hipMemcpyHostToDevice, st));
+            NS_TRY(hipMemcpyAsync(d_ew.p, edge_w, (size_t)E * 8, hipMemcpyHostToDevice, st));
+        }
+    } else {
+        size_t tb = 0;
+        NS_TRY(nabo::csr_sort_temp_bytes(E, n_ref, &tb));
+        const size_t e1 = (size_t)(E ? E : 1);
+        NS_RES(c_r, e1 * 8);
+        NS_RES(c_t, e1 * 8);
+        NS_RES(c_w, e1 * 8);
+        NS_RES(c_ka, e1 * 4);
+        NS_RES(c_kb, e1 * 4);
+        NS_RES(c_pa, e1 * 4);
+        NS_RES(c_pb, e1 * 4);
+        NS_RES(c_tmp, tb ? tb : 1);
+        NS_RES(c_flag, sizeof(unsigned int));
+        if (E) {
+            NS_TRY(hipMemcpyAsync(c_r.p, edge_r, (size_t)E * 8, hipMemcpyHostToDevice, st));
+            NS_TRY(hipMemcpyAsync(c_t.p, edge_t, (size_t)E * 8, hipMemcpyHostToDevice, st));
+            NS_TRY(hipMemcpyAsync(c_w.p, edge_w, (size_t)E * 8, hipMemcpyHostToDevice, st));
+        }
+        NS_TRY(nabo::csr_build_launch(c_r.as<int64_t>(), c_t.as<int64_t>(), c_w.as<double>(), E, n_ref, n_t,
+                                      c_ka.as<uint32_t>(), c_pa.as<uint32_t>(), c_kb.as<uint32_t>(), c_pb.as<uint32_t>(),
+                                      c_tmp.p, tb, d_rp.as<int64_t>(), d_et.as<int64_t>(), d_ew.as<double>(),
+                                      c_flag.as<unsigned int>(), st));
+        unsigned int bad = 0;
+        NS_TRY(hipMemcpyAsync(&bad, c_flag.p, sizeof(bad), hipMemcpyDeviceToHost, st));
+        NS_TRY(hipStreamSynchronize(st));
+        if (bad) {
+            release();
+            return fail(NABO_E_INVALID, "%s out of range", (bad & 1u) ? "edge_ref" : "edge_t");
+        }
+        DevBuf *stage[] = {&c_r, &c_t, &c_w, &c_ka, &c_kb, &c_pa, &c_pb, &c_tmp};
+        for (DevBuf *b : stage) b->release();
     }
     NS_TRY(hipMemcpyAsync(d_grp.p, group, (size_t)n_t, hipMemcpyHostToDevice, st));
     // radix select of the n_A-th smallest key of every permutation, 8 bits per pass
@@ -1111,6 +1160,25 @@ int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const
 #undef NS_TRY
 #undef NS_RES
     return NABO_OK;
+}
+
+int nabo_score_null(int32_t device, int64_t n_ref, const int64_t *row_ptr, const int64_t *edge_t,
+                    const double *edge_w, int64_t n_t, const uint8_t *group, int32_t n_perm, uint64_t seed,
+                    int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge, double *out_mean,
+                    double *out_sd, int64_t *out_sizes)
+{
+    if (!row_ptr) return fail(NABO_E_INVALID, "NULL argument");
+    return score_null_impl(device, n_ref, row_ptr, 0, nullptr, edge_t, edge_w, n_t, group, n_perm, seed, key_bits,
+                           multiplier, out_obs, out_nge, out_mean, out_sd, out_sizes);
+}
+
+int nabo_score_null_edges(int32_t device, int64_t n_ref, int64_t n_edges, const int64_t *edge_ref, const int64_t *edge_t,
+                          const double *edge_w, int64_t n_t, const uint8_t *group, int32_t n_perm, uint64_t seed,
+                          int32_t key_bits, double multiplier, double *out_obs, int64_t *out_nge, double *out_mean,
+                          double *out_sd, int64_t *out_sizes)
+{
+    return score_null_impl(device, n_ref, nullptr, n_edges, edge_ref, edge_t, edge_w, n_t, group, n_perm, seed, key_bits,
+                           multiplier, out_obs, out_nge, out_mean, out_sd, out_sizes);
 }
 
 int nabo_dev_malloc(int32_t device, void **ptr, size_t bytes)

@@ -18,7 +18,7 @@ int main(int argc, char **argv)
                           (void *)nabo_pairwise, (void *)nabo_index_create, (void *)nabo_index_destroy,
                           (void *)nabo_index_set_ref, (void *)nabo_index_set_mask, (void *)nabo_index_query,
                           (void *)nabo_index_query_candidates, (void *)nabo_index_last_stats, (void *)nabo_merge_topk,
-                          (void *)nabo_snn_counts, (void *)nabo_score_null, (void *)nabo_dev_malloc, (void *)nabo_dev_free,
+                          (void *)nabo_snn_counts, (void *)nabo_score_null, (void *)nabo_score_null_edges, (void *)nabo_dev_malloc, (void *)nabo_dev_free,
                           (void *)nabo_memcpy_h2d, (void *)nabo_memcpy_d2h, (void *)nabo_dev_synchronize};
     printf("%s: %d entry points\n", nabo_version(), (int)(sizeof(syms) / sizeof(syms[0])));
     if (argc < 2 || strcmp(argv[1], "run") != 0) return 0;

@@ -579,6 +579,45 @@ def test_mapping_score_null_rejects_bad_input(gpu_lib):
         nabo_amd.mapping_score_null(edge_t, edge_r, w, group, 10, n_perm=5000)               # > 4096 permutations
 
 
+def test_mapping_score_null_edge_list_in_any_order(gpu_lib):
+    """The device-side CSR build (csr_build.hip) is a STABLE sort by reference node: a shuffled edge list, long
+    enough for several radix-sort blocks, gives the oracle's float64 sums (which follow the listed order inside a
+    row), and the CSR entry point fed with a host-side stable sort gives the same bits."""
+    import ctypes as C
+    import nabo_amd
+    from nabo_amd import _lib
+    from oracle import oracle as orc
+    n_ref, n_t, k, P = 3000, 40000, 6, 96
+    edge_t, edge_r, w, group = _null_case(n_ref, n_t, k, 99)
+    rng = np.random.default_rng(4)
+    sh = rng.permutation(edge_t.shape[0])
+    edge_t, edge_r, w = edge_t[sh], edge_r[sh], w[sh]
+    res = nabo_amd.mapping_score_null(edge_t, edge_r, w, group, n_ref, n_perm=P, seed=77)
+    ref = orc.score_null(edge_t, edge_r, w, group, n_ref, P, seed=77)
+    assert np.array_equal(res["obs"], ref["obs"]) and np.array_equal(res["n_ge"], ref["n_ge"])
+    assert np.array_equal(res["sizes"], ref["sizes"])
+    # CSR entry point (nabo_score_null) on the host-sorted edges
+    order = np.argsort(edge_r, kind="stable")
+    rp = np.zeros(n_ref + 1, dtype=np.int64)
+    np.cumsum(np.bincount(edge_r, minlength=n_ref), out=rp[1:])
+    et, ew = np.ascontiguousarray(edge_t[order], dtype=np.int64), np.ascontiguousarray(w[order])
+    obs, mean, sd = np.empty(n_ref), np.empty(n_ref), np.empty(n_ref)
+    nge, sizes = np.empty(n_ref, dtype=np.int64), np.empty(P, dtype=np.int64)
+    L = _lib.lib()
+    L.nabo_score_null.argtypes = [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_int32, C.c_uint64, C.c_int32, C.c_double] + [C.c_void_p] * 5
+    _lib.check(L.nabo_score_null(0, n_ref, rp.ctypes.data, et.ctypes.data, ew.ctypes.data, n_t, group.ctypes.data, P, 77,
+                                 64, 1000.0, obs.ctypes.data, nge.ctypes.data, mean.ctypes.data, sd.ctypes.data,
+                                 sizes.ctypes.data))
+    assert np.array_equal(obs, res["obs"]) and np.array_equal(nge, res["n_ge"])
+    assert np.array_equal(mean, res["null_mean"]) and np.array_equal(sd, res["null_sd"])
+    # no edges at all: every score is 0, every permutation ties with it
+    z = nabo_amd.mapping_score_null(edge_t[:0], edge_r[:0], w[:0], group, n_ref, n_perm=8)
+    assert not z["obs"].any() and (z["n_ge"] == 8).all()
+    with pytest.raises(ValueError):
+        nabo_amd.mapping_score_null(edge_t + n_t, edge_r, w, group, n_ref, n_perm=8)          # target out of range
+
+
 # ---- randomized sweep: many small shapes, every metric, masks, duplicates, drop_first ---------------------------
 @pytest.mark.parametrize("metric", [0, 1, 2])
 def test_random_small_shapes_sweep(gpu_lib, metric):
