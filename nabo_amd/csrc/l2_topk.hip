@@ -75,27 +75,37 @@ __device__ __forceinline__ void load_ref_tile(RefTile<KSTEPS> &y, const float *_
 }
 
 // One accumulation chain: 32 refs x 32 targets x (2*KSTEPS) components.
-// RELOAD: overwrite the tile registers with `next` as soon as their last use has issued.
+// RELOAD: overwrite the tile registers with `next` once their last reader is out of the matrix pipe.
+//
+// Where the refills sit matters more than anything else in this loop (hit-free kernel time at 1M x 1M x 50,
+// tools/abl.sh history in DESIGN.md 4.1): a VMEM load whose destination is an operand of the MFMA that has just
+// issued waits for that MFMA, and the next MFMA waits behind the load -- refilling each fragment group right
+// behind its last reader cost 52 ms, no refills at all 678 ms against 776 ms.  Issued RELOAD_LAG MFMAs later the
+// last reader has retired and the load goes out at once: 763 -> 711 ms hit-free, 818 -> 787 ms with hits
+// (lag 1: 728 / 790, lag 2: 711 / 788, lag 3: 711 / 787, lag 4: 728).  The norm block (C-in of MFMA 0) is best
+// refilled directly behind MFMA 0 (later positions: +7..+20 ms).
+constexpr int RELOAD_LAG = 2;
+
 template <int KSTEPS, bool RELOAD>
 __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&xb)[KSTEPS],
                                              const float *__restrict__ next, int lane)
 {
     constexpr int Q = q_groups(KSTEPS);
     f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb[0], y.n, 0, 0, 0);
-    // The sched_barriers pin each reload right behind the last MFMA that reads the old
-    // registers: left alone, hipcc sinks some of them to the end of the chain and the next
-    // chain then waits a full L2 round trip for its first fragment.
+    // The sched_barriers pin each reload where it is written: left alone, hipcc sinks some of them to the end of
+    // the chain and the next chain then waits a full L2 round trip for its first fragment.
     if (RELOAD) {
         __builtin_amdgcn_sched_barrier(0);
         y.n = *reinterpret_cast<const f32x16 *>(next + Q * 256 + (lane >> 5) * 16);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int s = 1; s < KSTEPS; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb[s], acc, 0, 0, 0);
-        if (RELOAD && ((s & 3) == 3 || s == KSTEPS - 1)) {
+    for (int s = 1; s < KSTEPS + (RELOAD ? RELOAD_LAG : 0); ++s) {
+        if (s < KSTEPS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb[s], acc, 0, 0, 0);
+        const int r = s - RELOAD_LAG;           // MFMA r retired: if it was the last reader of its group, refill it
+        if (RELOAD && r >= 0 && ((r & 3) == 3 || r == KSTEPS - 1)) {
             __builtin_amdgcn_sched_barrier(0);
-            load_group<KSTEPS>(y.f[s >> 2], next, s >> 2, lane);
+            load_group<KSTEPS>(y.f[r >> 2], next, r >> 2, lane);
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -11,7 +11,9 @@ constexpr int KS = 25;
 //            2 = filter VALU (8 min3 + cmp -> flag) on the previous chain
 //            4 = reload the A registers from memory every tile (rolling)
 //            8 = interleave the two chains MFMA by MFMA
-template <int MODE>
+//           16 = (with 4) stream the reloads from a 228 MB array, one 7296-byte tile per iteration, as production does
+//           32 = (with 16) every wave touches one dword per 128-byte line of the tile PF tiles ahead (pulls it into L2)
+template <int MODE, int PF = 2>
 __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, float *out, int tiles)
 {
     const int lane = threadIdx.x & 63;
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, flo
     f32x16 accA = cin, accB = cin, accP = cin;
     float tau = -1e30f;
     int hits = 0;
+    float pfv = 0.0f, junk = 0.0f;
     const float *p = src + 4096 + (blockIdx.x & 7) * 64;
     for (int t = 0; t < tiles; ++t) {
         if (MODE & 8) {
@@ -60,10 +63,17 @@ __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, flo
                 accP = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], (s == 0 && (MODE & 1)) ? cin : accP, 0, 0, 0);
                 if ((MODE & 4) && (s & 3) == 3) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f32x4 v = *reinterpret_cast<const f32x4 *>(p + ((t & 63) * 1024 + (s >> 2) * 256 + lane * 4));
+                    f32x4 v = (MODE & 16) ? *reinterpret_cast<const f32x4 *>(src + ((size_t)(t % 31250) * 1824 + (s >> 2) * 256 + lane * 4))
+                                          : *reinterpret_cast<const f32x4 *>(p + ((t & 63) * 1024 + (s >> 2) * 256 + lane * 4));
                     a[s - 3] = v[0]; a[s - 2] = v[1]; a[s - 1] = v[2]; a[s] = v[3];
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if (MODE & 32) {
+                junk += pfv;
+                __builtin_amdgcn_sched_barrier(0);
+                pfv = src[(size_t)((t + PF) % 31250) * 1824 + lane * 32];
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (MODE & 2) {
                 float m = accA[0];
@@ -73,49 +83,56 @@ __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, flo
             }
         }
     }
-    float s = hits;
+    float s = hits + junk + pfv;
     for (int r = 0; r < 16; ++r) s += accA[r] + accB[r] + accP[r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-template <int MODE>
-static void run(int wg_per_cu, int tiles)
+template <int MODE, int PF = 2>
+static void run(int wg_per_cu, int tiles, int rounds = 1)
 {
     float *src, *out;
-    hipMalloc(&src, 1 << 22);
-    hipMemset(src, 0, 1 << 22);
-    int blocks = 256 * wg_per_cu;
+    const size_t sb = (MODE & 16) ? (size_t)31250 * 7296 + (1 << 22) : (size_t)(1 << 22);
+    hipMalloc(&src, sb);
+    hipMemset(src, 0, sb);
+    int blocks = 256 * wg_per_cu * rounds;
     hipMalloc(&out, blocks * 256 * sizeof(float));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(lab<MODE>, dim3(blocks), dim3(256), 0, 0, src, out, tiles / 8);
+    hipLaunchKernelGGL((lab<MODE, PF>), dim3(blocks), dim3(256), 0, 0, src, out, tiles / 8);
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL(lab<MODE>, dim3(blocks), dim3(256), 0, 0, src, out, tiles);
+        hipLaunchKernelGGL((lab<MODE, PF>), dim3(blocks), dim3(256), 0, 0, src, out, tiles);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
     double flop = (double)blocks * 4 * (double)tiles * 2 * KS * 4096.0;
-    printf("mode=%2d [%s%s%s%s] wg/cu=%d  %8.3f ms  %6.1f TFLOP/s  %5.1f%%\n", MODE, (MODE & 1) ? "restart " : "",
-           (MODE & 2) ? "filter " : "", (MODE & 4) ? "reload " : "", (MODE & 8) ? "interleave " : "", wg_per_cu, best,
+    printf("mode=%2d pf=%d [%s%s%s%s%s] wg/cu=%d rounds=%d %8.3f ms  %6.1f TFLOP/s  %5.1f%%\n", MODE, (MODE & 32) ? PF : 0, (MODE & 1) ? "restart " : "",
+           (MODE & 2) ? "filter " : "", (MODE & 4) ? "reload " : "", (MODE & 8) ? "interleave " : "", (MODE & 16) ? "stream228MB " : "", wg_per_cu, rounds, best,
            flop / best / 1e9, flop / best / 1e9 / 157.3 * 100);
     hipFree(src); hipFree(out);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    const bool full = argc > 1;
     const int T = 4000;
-    run<0>(1, T); run<0>(2, T);
-    run<1>(1, T); run<1>(2, T);
-    run<3>(1, T); run<3>(2, T);
-    run<7>(1, T); run<7>(2, T);
-    run<8>(1, T); run<8>(2, T);
-    run<9>(1, T); run<9>(2, T);
-    run<11>(1, T); run<11>(2, T);
-    run<15>(1, T); run<15>(2, T);
+    if (full) {
+        run<0>(1, T); run<0>(2, T);
+        run<1>(1, T); run<1>(2, T);
+        run<3>(1, T); run<3>(2, T);
+        run<7>(1, T); run<7>(2, T);
+        run<8>(1, T); run<8>(2, T);
+        run<9>(1, T); run<9>(2, T);
+        run<11>(1, T); run<11>(2, T);
+        run<15>(1, T); run<15>(2, T);
+    }
+    run<7>(2, 31250); run<23>(2, 31250); run<23>(2, 31250, 3); run<23>(1, 31250);
+    run<55, 1>(2, 31250); run<55, 2>(2, 31250); run<55, 4>(2, 31250); run<55, 8>(2, 31250);
+    run<55, 2>(2, 31250, 3); run<55, 4>(2, 31250, 3); run<55, 8>(2, 31250, 3);
     return 0;
 }
