@@ -41,6 +41,22 @@ struct RefTile {
     f32x16 n;
 };
 
+// Reference tiles are read with BUFFER loads: `buffer_load_dwordx4 v, v_off, s[rsrc], s_off offen offset:imm` takes its
+// lane address from ONE 32-bit VGPR (lane * 16) and everything uniform -- the tile's base in the descriptor, whole
+// 4 KB blocks in the scalar offset -- from SGPRs.  With flat `global_load`s hipcc keeps 64-bit per-lane addresses in
+// VGPR pairs for every load past the first 4 KB of a tile (and for all of them if asked nicely), and on gfx950, where
+// the fp32 MFMA shares the vector ALU's operand paths, each such load costs ~20 ms per step at 1M x 1M
+// (tools/ab: 7 of 11 loads per tile with VGPR-pair addresses 785 ms, all 11: 867 ms).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *tile_base)
+{
+    // raw buffer, no swizzle, no bounds (num_records = 2^31-1 bytes from the tile's own base); dword 3 as for
+    // gfx90a / gfx94x / gfx950: DATA_FORMAT = 32-bit
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tile_base), 0, 0x7FFFFFFF, 0x00020000);
+}
+
 // Load fragment group q of a packed tile: only the components that exist (the last group of a
 // KSTEPS that is not a multiple of 4 is partial; loading its unused lanes would hand hipcc dead
 // registers it reuses as temporaries -- and then guards with a full vmcnt(0)).
@@ -49,20 +65,37 @@ __device__ __forceinline__ void load_group(f32x4 &dst, const float *__restrict__
 {
     constexpr int Q = q_groups(KSTEPS);
     constexpr int TAIL = KSTEPS - 4 * (Q - 1);
-    const float *p = tile_base + (q * 64 + lane) * 4;
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile_base);
+    const int voff = lane * 16 + (q & 3) * 1024, soff = (q >> 2) * 4096;
     if (q < Q - 1 || TAIL == 4) {
-        dst = *reinterpret_cast<const f32x4 *>(p);
+        dst = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     } else if (TAIL == 1) {
-        dst[0] = p[0];
+        dst[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
     } else if (TAIL == 2) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 v = *reinterpret_cast<const f32x2 *>(p);
+        f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
         dst[0] = v[0]; dst[1] = v[1];
     } else {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2 v = *reinterpret_cast<const f32x2 *>(p);
-        dst[0] = v[0]; dst[1] = v[1]; dst[2] = p[2];
+        f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+        dst[0] = v[0]; dst[1] = v[1];
+        dst[2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff + 8, soff, 0));
     }
+}
+
+template <int KSTEPS>
+__device__ __forceinline__ f32x16 load_norm_block(const float *__restrict__ tile_base, int lane)
+{
+    constexpr int Q = q_groups(KSTEPS);
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(tile_base);
+    const int voff = (lane >> 5) * 64;
+    f32x16 n;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16 * i, Q * 1024, 0));
+        n[4 * i] = v[0]; n[4 * i + 1] = v[1]; n[4 * i + 2] = v[2]; n[4 * i + 3] = v[3];
+    }
+    return n;
 }
 
 template <int KSTEPS>
@@ -71,7 +104,7 @@ __device__ __forceinline__ void load_ref_tile(RefTile<KSTEPS> &y, const float *_
     constexpr int Q = q_groups(KSTEPS);
 #pragma unroll
     for (int q = 0; q < Q; ++q) load_group<KSTEPS>(y.f[q], tile_base, q, lane);
-    y.n = *reinterpret_cast<const f32x16 *>(tile_base + Q * 256 + (lane >> 5) * 16);
+    y.n = load_norm_block<KSTEPS>(tile_base, lane);
 }
 
 // One accumulation chain: 32 refs x 32 targets x (2*KSTEPS) components.
@@ -82,8 +115,7 @@ __device__ __forceinline__ void load_ref_tile(RefTile<KSTEPS> &y, const float *_
 // issued waits for that MFMA, and the next MFMA waits behind the load -- refilling each fragment group right
 // behind its last reader cost 52 ms, no refills at all 678 ms against 776 ms.  Issued RELOAD_LAG MFMAs later the
 // last reader has retired and the load goes out at once: 763 -> 711 ms hit-free, 818 -> 787 ms with hits
-// (lag 1: 728 / 790, lag 2: 711 / 788, lag 3: 711 / 787, lag 4: 728).  The norm block (C-in of MFMA 0) is best
-// refilled directly behind MFMA 0 (later positions: +7..+20 ms).
+// (lag 1: 728 / 790, lag 2: 711 / 788, lag 3: 711 / 787, lag 4: 728).
 constexpr int RELOAD_LAG = 2;
 
 template <int KSTEPS, bool RELOAD>
@@ -91,18 +123,26 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
                                              const float *__restrict__ next, int lane)
 {
     constexpr int Q = q_groups(KSTEPS);
-    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb[0], y.n, 0, 0, 0);
-    // The sched_barriers pin each reload where it is written: left alone, hipcc sinks some of them to the end of
-    // the chain and the next chain then waits a full L2 round trip for its first fragment.
+    f32x16 acc;
     if (RELOAD) {
-        __builtin_amdgcn_sched_barrier(0);
-        y.n = *reinterpret_cast<const f32x16 *>(next + Q * 256 + (lane >> 5) * 16);
-        __builtin_amdgcn_sched_barrier(0);
+        // C-in straight from the norm registers into a DIFFERENT destination.  Written as a builtin, hipcc ties
+        // destination and C-in of this MFMA and copies the block first (8 v_mov_b64 per tile) -- and on gfx950 the
+        // fp32 MFMA shares the vector ALU: every VALU cycle is a cycle the matrix chain does not get (tools/mfma_lab:
+        // a 480-cycle VALU detour in one of a SIMD's two waves costs the SIMD 380 cycles).  The norm block is refilled
+        // RELOAD_LAG MFMAs later, like the fragment groups.
+        asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %3" : "=&v"(acc) : "v"(y.f[0][0]), "v"(xb[0]), "v"(y.n));
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[0][0], xb[0], y.n, 0, 0, 0);
     }
 #pragma unroll
     for (int s = 1; s < KSTEPS + (RELOAD ? RELOAD_LAG : 0); ++s) {
         if (s < KSTEPS) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y.f[s >> 2][s & 3], xb[s], acc, 0, 0, 0);
         const int r = s - RELOAD_LAG;           // MFMA r retired: if it was the last reader of its group, refill it
+        if (RELOAD && r == 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            y.n = load_norm_block<KSTEPS>(next, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (RELOAD && r >= 0 && ((r & 3) == 3 || r == KSTEPS - 1)) {
             __builtin_amdgcn_sched_barrier(0);
             load_group<KSTEPS>(y.f[r >> 2], next, r >> 2, lane);
@@ -165,34 +205,35 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS
     }
     uint2 *wbuf = smem + (size_t)wave * R * 32 * ROW;
 
-    const int64_t t_begin = (int64_t)split * tiles_per_split;
-    const int64_t t_end = t_begin + tiles_per_split;
+    // tile counters are 32-bit (n_ref < 2^32 - 16 => < 2^27 tiles): the loop test stays on the scalar unit
+    const int t_begin = split * tiles_per_split;
+    const int t_end = t_begin + tiles_per_split;
     const float *ybase = Ypk;
 
     RefTile<KSTEPS> y;
-    load_ref_tile<KSTEPS>(y, ybase + t_begin * RTF, lane);
+    load_ref_tile<KSTEPS>(y, ybase + (int64_t)t_begin * RTF, lane);
 
     f32x16 accP;                  // chain whose filter is still pending
 #pragma unroll
     for (int r = 0; r < 16; ++r) accP[r] = __builtin_inff();   // inf < tau is false: nothing pending
 
     if (R == 2) {
-        for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (t + 1 < t_end) ? t + 1 : t;
+        for (int t = t_begin; t < t_end; ++t) {
+            const int tn = (t + 1 < t_end) ? t + 1 : t;
             f32x16 accA = mfma_chain<KSTEPS, false>(y, xb[0], nullptr, lane);
-            filter_and_append<EPL, ROWN>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, (uint32_t)((t - 1) * 32 + 4 * hh), lkeep);
-            accP = mfma_chain<KSTEPS, true>(y, xb[R - 1], ybase + tn * RTF, lane);
-            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)(t * 32 + 4 * hh), lkeep);
+            filter_and_append<EPL, ROWN>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, ((uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh), lkeep);
+            accP = mfma_chain<KSTEPS, true>(y, xb[R - 1], ybase + (int64_t)tn * RTF, lane);
+            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, ((uint32_t)t * 32u + 4u * (uint32_t)hh), lkeep);
         }
-        filter_and_append<EPL, ROWN>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, (uint32_t)((t_end - 1) * 32 + 4 * hh), lkeep);
+        filter_and_append<EPL, ROWN>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, ((uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh), lkeep);
     } else {
-        for (int64_t t = t_begin; t < t_end; ++t) {
-            const int64_t tn = (t + 1 < t_end) ? t + 1 : t;
-            f32x16 accA = mfma_chain<KSTEPS, true>(y, xb[0], ybase + tn * RTF, lane);
-            filter_and_append<EPL, ROWN>(accP, st[0], wbuf, (uint32_t)((t - 1) * 32 + 4 * hh), lkeep);
+        for (int t = t_begin; t < t_end; ++t) {
+            const int tn = (t + 1 < t_end) ? t + 1 : t;
+            f32x16 accA = mfma_chain<KSTEPS, true>(y, xb[0], ybase + (int64_t)tn * RTF, lane);
+            filter_and_append<EPL, ROWN>(accP, st[0], wbuf, ((uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh), lkeep);
             accP = accA;
         }
-        filter_and_append<EPL, ROWN>(accP, st[0], wbuf, (uint32_t)((t_end - 1) * 32 + 4 * hh), lkeep);
+        filter_and_append<EPL, ROWN>(accP, st[0], wbuf, ((uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh), lkeep);
     }
 
 #pragma unroll

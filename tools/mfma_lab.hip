@@ -12,6 +12,8 @@ constexpr int KS = 25;
 //            4 = reload the A registers from memory every tile (rolling)
 //            8 = interleave the two chains MFMA by MFMA
 //           16 = (with 4) stream the reloads from a 228 MB array, one 7296-byte tile per iteration, as production does
+//           64 = every second tile the wave takes a detour of 120 dependent VALU instructions (a stand-in for a hit
+//                episode); 128 = (with 64) the detour runs at s_setprio 0, the loop at s_setprio 3
 //           32 = (with 16) every wave touches one dword per 128-byte line of the tile PF tiles ahead (pulls it into L2)
 template <int MODE, int PF = 2>
 __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, float *out, int tiles)
@@ -26,6 +28,7 @@ __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, flo
     f32x16 accA = cin, accB = cin, accP = cin;
     float tau = -1e30f;
     int hits = 0;
+    if (MODE & 128) __builtin_amdgcn_s_setprio(3);
     float pfv = 0.0f, junk = 0.0f;
     const float *p = src + 4096 + (blockIdx.x & 7) * 64;
     for (int t = 0; t < tiles; ++t) {
@@ -68,6 +71,14 @@ __global__ __launch_bounds__(256, 2) void lab(const float *__restrict__ src, flo
                     a[s - 3] = v[0]; a[s - 2] = v[1]; a[s - 1] = v[2]; a[s] = v[3];
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            if ((MODE & 64) && (t & 1)) {
+                if (MODE & 128) __builtin_amdgcn_s_setprio(0);
+                float z = junk;
+#pragma unroll
+                for (int i = 0; i < 120; ++i) z = __builtin_fmaf(z, 1.0000001f, 0.5f);
+                junk = z;
+                if (MODE & 128) __builtin_amdgcn_s_setprio(3);
             }
             if (MODE & 32) {
                 junk += pfv;
@@ -131,6 +142,8 @@ int main(int argc, char **argv)
         run<11>(1, T); run<11>(2, T);
         run<15>(1, T); run<15>(2, T);
     }
+    run<7>(2, 8000); run<71>(2, 8000); run<199>(2, 8000); run<7>(1, 8000); run<71>(1, 8000);
+    if (!full) return 0;
     run<7>(2, 31250); run<23>(2, 31250); run<23>(2, 31250, 3); run<23>(1, 31250);
     run<55, 1>(2, 31250); run<55, 2>(2, 31250); run<55, 4>(2, 31250); run<55, 8>(2, 31250);
     run<55, 2>(2, 31250, 3); run<55, 4>(2, 31250, 3); run<55, 8>(2, 31250, 3);
