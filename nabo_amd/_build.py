@@ -12,9 +12,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnabo_knn.so")
 SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "score_null.hip", "csr_build.hip"]
-# per-file extra flags: keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
+# per-file extra flags: -fno-honor-nans for the fp32 score kernel (scores are finite or +inf by construction; without it
+# every fminf tree starts with two v_max canonicalisations, and on gfx950 the fp32 MFMA cannot overlap vector-ALU work);
+# keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
 # v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
-FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 HEADERS = [os.path.join(CSRC, "knn_common.h"), os.path.join(CSRC, "topk_lists.h"), os.path.join(HERE, "..", "include", "nabo_knn.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
