@@ -83,6 +83,29 @@ __device__ __forceinline__ void slow_append(f32x16 a, float m, RowState &st, uin
     const int tl = lane & 31, hh = lane >> 5;
     uint2 *sub = blockbuf + tl * ROW + lkeep + hh * (ph + 1);
     bool hit = m < st.tau;
+    {
+        // Fast path (nearly every episode): every hitting lane has exactly ONE score below its threshold and room for
+        // it.  One compare per register finds the register (per lane) and, through the scalar unit, the number of
+        // hits in the wave; if that equals the number of hitting lanes nothing else can be pending, and the
+        // knock-out / second look of the general loop below (40 of its ~80 vector instructions) is not needed.
+        // On gfx950 vector-ALU instructions are not hidden behind the fp32 MFMAs of the SIMD's other wave.
+        uint32_t rs = 0;
+        int total = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool below = a[r] < st.tau;
+            total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(below));
+            rs = below ? (uint32_t)r : rs;
+        }
+        const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
+        const uint64_t full = __builtin_amdgcn_ballot_w64(hit && st.pc >= (uint32_t)ph);
+        if (total == __builtin_popcountll(hm) && full == 0) {
+            const uint32_t slot = hit ? st.pc : (uint32_t)ph;
+            sub[slot] = make_uint2(__float_as_uint(m), jb + (rs & 3u) + 8u * (rs >> 2));
+            st.pc += hit ? 1u : 0u;
+            return;
+        }
+    }
     for (;;) {
         const uint64_t fm = __builtin_amdgcn_ballot_w64(hit && st.pc >= (uint32_t)ph);
         if (fm != 0) {
