@@ -83,7 +83,9 @@ __device__ __forceinline__ void slow_append(f32x16 a, float m, RowState &st, uin
     const int tl = lane & 31, hh = lane >> 5;
     uint2 *sub = blockbuf + tl * ROW + lkeep + hh * (ph + 1);
     bool hit = m < st.tau;
-    {
+    if (EPL == 1) {
+        // (Short lists only: with 64-entry lists -- k' > 24 -- several hits per lane and full rows are common enough
+        // that the test costs more than it saves: cosine d=100, k=50 at 1M x 1M 1680 vs 1660 ms.)
         // Fast path (nearly every episode): every hitting lane has exactly ONE score below its threshold and room for
         // it.  One compare per register finds the register (per lane) and, through the scalar unit, the number of
         // hits in the wave; if that equals the number of hitting lanes nothing else can be pending, and the

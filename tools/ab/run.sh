@@ -3,6 +3,6 @@
 # Box-to-box spread of the 1M x 1M kernel is ~1 % (783-792 ms): differences smaller than that need the same box.
 for rep in 1 2; do for v in "$@"; do
   cp tools/ab/$v.so nabo_amd/libnabo_knn.so
-  timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ab_$v.log 2>&1 || exit 1
+  timeout -k 10 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $BENCH_ARGS > gpurun_out/ab_$v.log 2>&1 || exit 1
   echo "$v $(tail -1 gpurun_out/ab_$v.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["roofline"]["kernel_ms"], d["phases_ms"]["ms_fallback"])')"
 done; done
