@@ -14,6 +14,8 @@ SO = os.path.join(HERE, "libnabo_knn.so")
 SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "score_null.hip", "csr_build.hip"]
 # per-file extra flags: -fno-honor-nans for the fp32 score kernel (scores are finite or +inf by construction; without it
 # every fminf tree starts with two v_max canonicalisations, and on gfx950 the fp32 MFMA cannot overlap vector-ALU work);
+# (NOT for l2h_topk.hip: its masked / padding cells carry an inf - inf = NaN low part, and the filter relies on NaN
+# comparing false -- with the flag 4 of 1000 rows lose their certificate);
 # keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
 # v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
 FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
