@@ -16,9 +16,13 @@ SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "refine.hip", "
 # every fminf tree starts with two v_max canonicalisations, and on gfx950 the fp32 MFMA cannot overlap vector-ALU work);
 # (NOT for l2h_topk.hip: its masked / padding cells carry an inf - inf = NaN low part, and the filter relies on NaN
 # comparing false -- with the flag 4 of 1000 rows lose their certificate);
+# canberra_f32.hip with LLVM's iterative-ilp scheduler: the counting loop is four independent packed-f16 chains per
+# dimension pair, and the default scheduler leaves 156 hazard s_nop in it (none with this one): kernel 45.4 -> 40.8 ms at
+# 100k x 100k, 3.79 -> 3.43 s at 1M x 1M;
 # keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
 # v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
-FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+              "canberra_f32.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 HEADERS = [os.path.join(CSRC, "knn_common.h"), os.path.join(CSRC, "topk_lists.h"), os.path.join(HERE, "..", "include", "nabo_knn.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
