@@ -19,9 +19,11 @@ SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "refine.hip", "
 # canberra_f32.hip with LLVM's iterative-ilp scheduler: the counting loop is four independent packed-f16 chains per
 # dimension pair, and the default scheduler leaves 156 hazard s_nop in it (none with this one): kernel 45.4 -> 40.8 ms at
 # 100k x 100k, 3.79 -> 3.43 s at 1M x 1M;
+# the same scheduler for l2_topk.hip (hit path and filter are plain vector code around the fenced MFMA chains): 1M x 1M
+# kernel 755 -> 735 ms; no effect on l2h_topk.hip (372 ms either way);
 # keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
 # v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
-FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
               "canberra_f32.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 HEADERS = [os.path.join(CSRC, "knn_common.h"), os.path.join(CSRC, "topk_lists.h"), os.path.join(HERE, "..", "include", "nabo_knn.h")]
 ARCH = "gfx950"
