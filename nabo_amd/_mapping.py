@@ -136,17 +136,90 @@ def snn_weight_table(k):
     return tab
 
 
+def pyset_iteration_order(rows):
+    """For every row of DISTINCT non-negative ints: the permutation of its columns in which CPython iterates
+    `set(row)` -- the order in which the reference's `for j in a` (nabo/_mapping.py:190-191) visits a cell's
+    neighbours, hence the order of every node's rows in the `<uid>_graph` datasets (networkx keeps insertion
+    order).  Restates CPython's open-addressing set (Objects/setobject.c: 8-slot table, hash(int) = int,
+    9 linear probes, perturb shift 5, growth to the first power of two > 4*used once fill*5 >= mask*3; the
+    same in 3.7 .. 3.12), vectorised over the rows.  Pinned against the interpreter's own `set` by
+    tests/test_host_logic.py and against the reference's files by the `*_graph_dst` goldens."""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    n, k = rows.shape
+    if n == 0 or k == 0:
+        return np.zeros((n, k), dtype=np.int64)
+    if rows.min() < 0:
+        raise ValueError("ERROR: neighbour indices must be non-negative")
+
+    def place(table, rsel, cols, vals, mask):
+        """One insertion per selected row: column id cols[q] (hash vals[q]) into row rsel[q] of `table`
+        [n, mask+1] (-1 = empty): set_add_entry / set_insert_clean without the equality tests (keys differ)."""
+        i = vals & mask
+        perturb = vals.copy()
+        live = np.arange(rsel.size)
+        while live.size:
+            r, ii = rsel[live], i[live]
+            free = table[r, ii] < 0
+            table[r[free], ii[free]] = cols[live[free]]
+            live, r, ii = live[~free], r[~free], ii[~free]
+            if not live.size:
+                break
+            placed = np.zeros(live.size, dtype=bool)
+            lin = ii + 9 <= mask
+            for j in range(1, 10):
+                cand = np.nonzero(lin & ~placed)[0]
+                if not cand.size:
+                    break
+                fr = table[r[cand], ii[cand] + j] < 0
+                hit = cand[fr]
+                table[r[hit], ii[hit] + j] = cols[live[hit]]
+                placed[hit] = True
+            live, ii = live[~placed], ii[~placed]
+            perturb[live] >>= 5
+            i[live] = (ii * 5 + 1 + perturb[live]) & mask
+
+    mask = 7
+    table = np.full((n, mask + 1), -1, dtype=np.int64)
+    every = np.arange(n)
+    for c in range(k):
+        place(table, every, np.full(n, c, dtype=np.int64), rows[:, c].copy(), mask)
+        fill = c + 1
+        if fill * 5 >= mask * 3:                               # set_table_resize(used > 50000 ? used*2 : used*4)
+            minused = fill * 2 if fill > 50000 else fill * 4
+            newsize = 8
+            while newsize <= minused:
+                newsize <<= 1
+            old, mask = table, newsize - 1
+            table = np.full((n, newsize), -1, dtype=np.int64)
+            for s_ in range(old.shape[1]):                      # old entries re-inserted in table order
+                sub = np.nonzero(old[:, s_] >= 0)[0]
+                if sub.size:
+                    cc = old[sub, s_]
+                    place(table, sub, cc, rows[sub, cc].copy(), mask)
+    return table[table >= 0].reshape(n, k)                      # occupied slots of every row, left to right
+
+
+def snn_edges_from_counts(t_idx, cnt, k):
+    """Host half of `snn_edges`: shared-neighbour counts [m,k] -> (t, j, weight) edge list, a cell's edges in
+    the order the reference's set iteration yields them (`pyset_iteration_order`)."""
+    t_idx = np.asarray(t_idx)[:, :k]
+    cnt = np.asarray(cnt)[:, :k]
+    tab = snn_weight_table(k)
+    perm = pyset_iteration_order(t_idx)
+    t_idx = np.take_along_axis(t_idx, perm, axis=1)
+    cnt = np.take_along_axis(cnt, perm, axis=1)
+    tt, ss = np.nonzero(cnt > 0)
+    w = tab[cnt[tt, ss]]
+    if np.isnan(w).any() or (k == 1 and cnt.size):
+        raise ZeroDivisionError("division by zero")        # what round(snn/(factor-snn)) does at :194 (k = 1: 0/0)
+    return tt.astype(np.int64), t_idx[tt, ss].astype(np.int64), w
+
+
 def snn_edges(t_idx, r_idx, k, device=0):
     """(t, j, weight) for every j in order_t[:k] sharing >= 1 neighbour with order_ref_j[:k]
     (nabo/_mapping.py:186-198).  Counting runs on the GPU (nabo_snn_counts)."""
     t_idx = np.asarray(t_idx)[:, :k]
-    cnt = _knn.snn_counts(t_idx, r_idx, k, device=device)
-    tab = snn_weight_table(k)
-    tt, ss = np.nonzero(cnt > 0)
-    w = tab[cnt[tt, ss]]
-    if np.isnan(w).any():
-        raise ZeroDivisionError("division by zero")        # what round(snn/(factor-snn)) does at :194
-    return tt.astype(np.int64), t_idx[tt, ss].astype(np.int64), w
+    return snn_edges_from_counts(t_idx, _knn.snn_counts(t_idx, r_idx, k, device=device), k)
 
 
 def _component_labels(n, a, b):

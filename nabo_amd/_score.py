@@ -27,33 +27,98 @@ def mapping_score_from_edges(n_ref, edge_ref_idx, edge_weight, n_target_nodes, m
     return sc
 
 
-def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0, weighted=True,
-                      score_multiplier=1000, remove_suffix=False):
-    """{reference node name: score} for one mapped target, read straight from the mapping file
-    (same defaults and meaning as nabo.Graph.get_mapping_score with all_nodes=True)."""
+def _target_uid(h5, target):
+    uid = None
+    for i in h5["name_stash/target_names"][:]:
+        if i[0].decode("UTF-8") == target:
+            uid = i[1].decode("UTF-8")
+    if uid is None:
+        raise ValueError("ERROR: %s not present in graph" % target)
+    return uid
+
+
+def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0, weighted=True, by_cluster=False,
+                      sorted_names_only=False, top_n_only=None, all_nodes=True, score_multiplier=1000,
+                      ignore_nodes=None, include_nodes=None, remove_suffix=False, verbose=False):
+    """Mapping score of one mapped target, read straight from the mapping file: same parameters, defaults,
+    return shapes and errors as nabo.Graph.get_mapping_score (nabo/_graph.py:555-697), which needs the whole
+    networkx graph in memory; `mapping_h5_fn, ref_name` stand for the Graph object (what `load_from_h5`
+    would have been given, nabo/_graph.py:31-116).
+
+      * nodes are named `<cell>_<sample>`; reference nodes come in the order `load_from_h5` meets them
+        (HDF5 name order of the reference's `<uid>_graph` group, nabo/_graph.py:93-107) -- that order decides
+        ties in `sorted_names_only` (a stable ascending sort, reversed: :678-684);
+      * `ignore_nodes` / `include_nodes` (target NODE names; unknown names are dropped, :611-628) restrict the
+        target nodes whose edges count, and the denominator is the number of nodes that remain (:629,652-653);
+      * `top_n_only` (with `sorted_names_only`) ignores `min_score` (:677-681); `all_nodes=False` keeps only
+        scores >= min_score, otherwise smaller scores are reset to 0 (:689-692);
+      * `remove_suffix=True` returns a LIST of cell names in both the sorted and the dict form -- the
+        reference iterates the dict there (:693-694), kept as is;
+      * `by_cluster` needs `Graph.make_clusters` / `import_clusters`, which are not on the mapping hot path
+        (out of scope): ValueError, as the reference raises when no clusters exist.
+    """
     import h5py
+    if by_cluster:
+        raise ValueError('ERROR: Calculate clusters first using "make_clusters" or import clusters using '
+                         '"import_clusters"')
     with h5py.File(mapping_h5_fn, "r") as h5:
         if h5["name_stash/ref_name"][0].decode("UTF-8") != ref_name:
             raise KeyError("ERROR: The reference is not named %s in the mapping file" % ref_name)
-        uid = None
-        for i in h5["name_stash/target_names"][:]:
-            if i[0].decode("UTF-8") == target:
-                uid = i[1].decode("UTF-8")
-        if uid is None:
+        if "target_names" not in h5["name_stash"]:
             raise ValueError("ERROR: %s not present in graph" % target)
-        ref_cells = [x.decode("UTF-8") for x in h5["ref_cells/ref_cells"][:]]
-        pos = {c + "_" + ref_name: i for i, c in enumerate(ref_cells)}
+        uid = _target_uid(h5, target)
+        if ignore_nodes is not None and include_nodes is not None:
+            raise ValueError("ERROR: PLease provide only one of either 'ignore_nodes' or 'include_nodes' at a time")
+        ref_uid = h5["name_stash/ref_name"][1].decode("UTF-8")
+        if ref_uid + "_graph" in h5:
+            ref_nodes = [n for n in h5[ref_uid + "_graph"]]            # load order of Graph.refNodes
+        else:
+            ref_nodes = sorted(x.decode("UTF-8") + "_" + ref_name for x in h5["ref_cells/ref_cells"][:])
+        pos = {n: i for i, n in enumerate(ref_nodes)}
         grp = h5[uid + "_graph"]
+        t_nodes = [n for n in grp]
+        tset = {n: None for n in t_nodes}
+        ign = set(n for n in (ignore_nodes or []) if n in tset)
+        inc = list(t_nodes) if include_nodes is None else [n for n in include_nodes if n in tset]
+        inc = set(inc).difference(ign)
         ridx, w = [], []
-        n_nodes = 0
-        for node in grp:
-            n_nodes += 1
-            for row in grp[node]:
+        n_iso_t = 0
+        for node in t_nodes:
+            if node not in inc:
+                continue
+            rows = grp[node]
+            if rows.shape[0] == 0:
+                n_iso_t += 1
+            for row in rows:
                 ridx.append(pos[row[0].decode("UTF-8")])
                 w.append(float(row[1].decode("UTF-8")))
-    sc = mapping_score_from_edges(len(ref_cells), ridx, w, n_nodes, min_weight, min_score, weighted, score_multiplier)
-    names = ref_cells if remove_suffix else [c + "_" + ref_name for c in ref_cells]
-    return dict(zip(names, sc.tolist()))
+    if verbose:
+        hit = np.zeros(len(ref_nodes), dtype=bool)
+        hit[np.asarray(ridx, dtype=np.int64)] = True
+        print("INFO: The bipartite graph has %d edges" % len(ridx))
+        print("INFO: Mapping calculated against %d %s nodes" % (len(inc), target))
+        print("INFO: %d reference nodes do not connect with any target node" % int((~hit).sum()))
+        print("INFO: %d target nodes do not connect with any reference node" % n_iso_t)
+    if len(inc) == 0:
+        raise ZeroDivisionError("division by zero")                      # :652-653 with no target node left
+    # raw scores (no min_score reset yet: the sorted forms filter on the raw value)
+    sc = mapping_score_from_edges(len(ref_nodes), ridx, w, len(inc), min_weight, -np.inf, weighted, score_multiplier)
+    score = dict(zip(ref_nodes, sc.tolist()))
+    if sorted_names_only:
+        if top_n_only is not None:
+            if top_n_only > len(score):
+                raise ValueError("ERROR: Value of top_n_only should be less than total number of nodes in "
+                                 "reference graph")
+            retval = [x[0] for x in sorted(score.items(), key=lambda x: x[1])][::-1][:top_n_only]
+        else:
+            ms = {k: v for k, v in score.items() if v >= min_score}
+            retval = [x[0] for x in sorted(ms.items(), key=lambda x: x[1])][::-1]
+        return [x.rsplit("_", 1)[0] for x in retval] if remove_suffix else retval
+    if not all_nodes:
+        retval = {k: v for k, v in score.items() if v >= min_score}
+    else:
+        retval = {k: v if v >= min_score else 0 for k, v in score.items()}
+    return [x.rsplit("_", 1)[0] for x in retval] if remove_suffix else retval
 
 
 # ---- permutation null (EXTENSION: BASELINE.json configs[4]; the reference has no permutation test) ------------

@@ -52,6 +52,21 @@ def read_graph_like_reference(fn, name, kind):
         return nodes, edges, uid
 
 
+def read_graph_raw(fn, uid):
+    """nodes in HDF5 order and, per node, its rows as stored: (neighbour bytes, weight bytes) in row order"""
+    with h5py.File(fn, "r") as h5:
+        grp = h5[uid + "_graph"]
+        return [(n, [(r[0], r[1]) for r in grp[n][()].tolist()] if grp[n].shape != (0,) else []) for n in grp]
+
+
+def golden_raw(g, prefix):
+    """the same from a golden: what the REFERENCE's file held (oracle/gen_golden.py read_graph keeps file order)"""
+    rows = {str(n): [] for n in g[prefix + "_nodes"]}
+    for s, d, w in zip(g[prefix + "_src"], g[prefix + "_dst"], g[prefix + "_wraw"]):
+        rows[str(s)].append((str(d).encode("ascii"), str(w).encode("ascii")))
+    return [(str(n), rows[str(n)]) for n in g[prefix + "_nodes"]]
+
+
 def golden_edges(g, prefix):
     return {(str(s), str(d), float(w)) for s, d, w in zip(g[prefix + "_src"], g[prefix + "_dst"], g[prefix + "_w"])}
 
@@ -112,6 +127,8 @@ def run_case(tag):
         out["ref_graph_edges_equal"] = edges == ge
         out["ref_graph_missing"] = sorted(ge - edges)[:5]
         out["ref_graph_extra"] = sorted(edges - ge)[:5]
+        # the datasets themselves: node order, per-node ROW order, neighbour names and weight STRINGS as stored
+        out["ref_graph_raw_equal"] = read_graph_raw(map_fn, uid) == golden_raw(g, "ref_graph")
         fixw = 0.5 / ((2 * (k - 1)) - 0.5)
         out["n_repair_edges"] = len({e for e in ge if e[2] == fixw}) // 2
         for (tn, names, data, ign) in targets:
@@ -125,6 +142,10 @@ def run_case(tag):
                 tied = {str(c) + "_" + tn for c, t in zip(g["t_%s_cells" % tn], tt) if t}
                 out["t_%s_graph_edges_equal" % tn] = ({e for e in tedges if e[0] not in tied} ==
                                                       {e for e in gte if e[0] not in tied})
+            raw, graw = read_graph_raw(map_fn, tuid), golden_raw(g, "t_%s_graph" % tn)
+            tied_n = {str(c) + "_" + tn for c, t in zip(g["t_%s_cells" % tn], tt) if t}
+            out["t_%s_graph_raw_equal" % tn] = ([x for x in raw if x[0] not in tied_n] ==
+                                               [x for x in graw if x[0] not in tied_n])
             if "score_%s_nodes" % tn in g.files and not tt.any():
                 sc = mapping_score(nodes, tnodes, tedges)
                 gs = dict(zip([str(x) for x in g["score_%s_nodes" % tn]], g["score_%s_vals" % tn]))

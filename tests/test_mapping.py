@@ -53,7 +53,7 @@ def test_mapping_end_to_end_vs_reference_outputs(mode):
     assert res["ref_graph_nodes_equal"]
     assert res["ref_graph_edges_equal"], (res["ref_graph_missing"], res["ref_graph_extra"], res["log"])
     for k, v in res.items():
-        if k.endswith("_graph_nodes_equal") or k.endswith("_graph_edges_equal"):
+        if k.endswith("_graph_nodes_equal") or k.endswith("_graph_edges_equal") or k.endswith("_graph_raw_equal"):
             assert v is True, k
         if k.endswith("_score_maxerr") or k.endswith("_score_api_maxerr"):
             assert v < 1e-9, (k, v)
