@@ -2,17 +2,27 @@
 """bench.py -- k-NN mapping throughput on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--targets M --refs N --dims D --neighbors K]
+                    [--metric euclidean|cosine|canberra]
 
-A step = one full k-NN build of the workload: pack the (sharded) references, fused
-distance + top-k on the MFMA pipe, float64 refine, and for N>1 the RCCL exchange + merge.
-Inputs (float64 PCA-like embeddings) are already resident in HBM when the timed region starts.
+A step = one full k-NN build of the workload: pack the (sharded) references, fused distance + top-k filter on the
+matrix pipe, float64 refine + certification, and for N>1 the RCCL exchange + merge (nabo_sharded_query).  Inputs
+(float64 PCA-like embeddings) are already resident in HBM when the timed region starts.
 Default workload: BASELINE.json configs[2], 1M ref x 1M target, d=50, k=15, Euclidean.
-For N>1 the driver launches this file under torch.distributed.run (one rank per GPU); reference
-rows are sharded, total work is fixed ("strong" scaling).
+
+For N>1 the driver launches this file under torch.distributed.run, one rank per GPU; only the launcher is torch: the
+ranks read RANK / LOCAL_RANK / WORLD_SIZE from the environment, rank 0 hands the RCCL unique id to the others through
+a file (single node), and every collective -- the data path's and the barrier / max-over-ranks of the timing -- goes
+through libnabo_knn.so's C ABI (nabo_comm_*).  Reference rows are sharded, total work is fixed ("strong" scaling).
+
+The default N=1 line also carries (outside the timed region): `canberra` -- the reference's default target<->reference
+metric (nabo/_mapping.py:122-124) on the same 1M x 1M workload, checked against the oracle on sampled rows;
+`alt` -- the other Euclidean filter kernel on the same step (same bits required); `cpu_baseline` -- the oracle on this
+box's host cores (OpenMP and single thread) and the reference-style end-to-end run of BASELINE configs[0].
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,174 +32,185 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-PEAK_F32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+# MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz
+PEAK_F32_MFMA_TFLOPS = 157.3        # v_mfma_f32_32x32x2_f32: 64 flop/clk/SIMD
+PEAK_F16_MFMA_TFLOPS = 2516.6       # v_mfma_f32_32x32x16_f16: 32 cycles per 32x32x16 -> 1024 flop/clk/SIMD (dense)
+PEAK_VALU_GINST = 614.4             # wave64 vector instructions: one per 4 cycles and SIMD (v_add / v_fma / packed f16)
+
+
+def _time_knn(oracle, X, Y, k, metric, threads, budget_s):
+    oracle.knn(X[:32], Y, k, metric, 0.25, nthreads=threads)
+    t0 = time.perf_counter()
+    oracle.knn(X, Y, k, metric, 0.25, nthreads=threads)
+    dt = time.perf_counter() - t0
+    reps = int(max(1, min(64, budget_s / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.knn(X, Y, k, metric, 0.25, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return reps, dt
 
 
 def cpu_baseline(d, k, metric=0):
-    """The oracle (bit-equal port of the reference's CPU arithmetic + selection), all host
-    cores, on a bounded sample of the same workload."""
+    """The oracle (bit-equal port of the reference's CPU arithmetic + ordered selection, kind "port") on a bounded
+    sample of the same workload: all host cores of this box's share (OpenMP), and ONE thread -- the reference itself is
+    single-core numba (nabo/_mapping.py:16,29).  ~12 s of CPU work each."""
     import oracle
     from nabo_amd._synth import pca_like
     cores = max(1, min(os.cpu_count() or 1, 16))      # the GPU box's CPU share for one GPU
-    n_s, m_s = 100000, 1024
+    n_s = 100000
     Y = pca_like(n_s, d, seed=1003)
-    X = pca_like(m_s, d, seed=2003)
-    oracle.knn(X[:64], Y, k, metric, nthreads=cores)          # warm up threads / page in
-    t0 = time.perf_counter()
-    oracle.knn(X, Y, k, metric, nthreads=cores)
-    dt = time.perf_counter() - t0
-    # scale the sample towards ~10-20 s of CPU work
-    reps = int(max(1, min(16, 12.0 / max(dt, 1e-3))))
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        oracle.knn(X, Y, k, metric, nthreads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": reps * m_s * n_s / dt, "unit": "cell-pair distances/s", "cores": cores, "kind": "port",
-            "sample": "%d x (%d targets x %d refs), d=%d, k=%d, float64 sequential + ordered top-k, OpenMP"
-                      % (reps, m_s, n_s, d, k)}
+    X = pca_like(1024, d, seed=2003)
+    reps, dt = _time_knn(oracle, X, Y, k, metric, cores, 12.0)
+    out = {"value": reps * X.shape[0] * n_s / dt, "unit": "cell-pair distances/s", "cores": cores, "kind": "port",
+           "sample": "%d x (%d targets x %d refs), d=%d, k=%d, float64 sequential + ordered top-k, OpenMP; %.1f s of CPU work"
+                     % (reps, X.shape[0], n_s, d, k, dt)}
+    X1 = X[:128]
+    reps, dt = _time_knn(oracle, X1, Y, k, metric, 1, 12.0)
+    out["single_thread"] = {"value": reps * X1.shape[0] * n_s / dt, "unit": "cell-pair distances/s", "cores": 1, "kind": "port",
+                            "sample": "%d x (%d targets x %d refs), same arithmetic, 1 thread (the reference's numba kernels "
+                                      "are single-core); %.1f s of CPU work" % (reps, X1.shape[0], n_s, dt)}
+    out["extrapolated_1Mx1M_seconds"] = {"cores_%d" % cores: 1e12 / out["value"], "cores_1": 1e12 / out["single_thread"]["value"],
+                                         "note": "extrapolated from the samples, never measured"}
+    return out
+
+
+def c1_end_to_end(gpu):
+    """BASELINE configs[0] in the reference's own per-cell HDF5 layout on the host (oracle/c1_end_to_end.py) next to
+    nabo_amd.Mapping on the same files; needs an interpreter with h5py."""
+    for py in (sys.executable, "/opt/conda/bin/python3.9", "/opt/conda/bin/python"):
+        if not os.path.exists(py):
+            continue
+        if subprocess.run([py, "-c", "import h5py, numpy"], stdout=subprocess.PIPE, stderr=subprocess.PIPE).returncode:
+            continue
+        cmd = [py, os.path.join(REPO, "oracle", "c1_end_to_end.py")] + (["--gpu"] if gpu else [])
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
+        if r.returncode == 0:
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        return {"error": r.stderr[-400:]}
+    return {"skipped": "no interpreter with h5py"}
+
+
+def pmc_record(kind, workload, so_digest):
+    """HBM-side bytes / instruction counts of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc.json, collected with tools/pmc_round.sh in runs of their own).  Only a record taken on THIS build of
+    the library (same .so digest) and workload is reported as a number; anything else is a pointer, never a value."""
+    try:
+        rec = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))[kind][workload]
+    except Exception:       # noqa: BLE001
+        return None
+    return rec if rec.get("so_digest") == so_digest else {"stale": True, "source": rec.get("source"),
+                                                          "so_digest_of_record": rec.get("so_digest")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--targets", dest="m", type=int, default=1000000)
     ap.add_argument("--refs", dest="n", type=int, default=1000000)
     ap.add_argument("--dims", dest="d", type=int, default=50)
     ap.add_argument("--neighbors", dest="k", type=int, default=15)
-    ap.add_argument("--metric", choices=["euclidean", "cosine"], default="euclidean",
-                    help="cosine is an extension (BASELINE configs[4]); the headline workload is euclidean")
+    ap.add_argument("--metric", choices=["euclidean", "cosine", "canberra"], default="euclidean",
+                    help="cosine is an extension (BASELINE configs[4]); canberra is the reference's target<->reference "
+                         "metric; the headline workload is euclidean")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the canberra / alt / C1 blocks (profiling runs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    use_dist = world > 1 or os.environ.get("NABO_BENCH_FORCE_DIST") == "1"    # rehearsal of the N>1 code on 1 GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
+    if world > 1:
         a.gpus = world
-    if use_dist:
-        # torch bundles its own HIP runtime: it must be loaded BEFORE libnabo_knn.so so that the
-        # process ends up with ONE libamdhip64 (the library then binds to torch's copy)
-        import torch  # noqa: F401
     import nabo_amd
-    from nabo_amd import _knn
-    from nabo_amd._dist import shard_bounds
+    from nabo_amd import _knn, _lib, _sharded
+    from nabo_amd._sharded import shard_bounds
     from nabo_amd._synth import pca_like
     if nabo_amd.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
 
     m, n, d, k = a.m, a.n, a.d, a.k
-    backend = os.environ.get("NABO_BENCH_BACKEND", "nccl")     # "gloo": N ranks rehearsed on ONE GPU
-    dev = local_rank if (world > 1 and backend == "nccl") else 0
-    lo, hi = shard_bounds(n, world, rank)
-    Y = pca_like(n, d, seed=1003)[lo:hi]
+    dev = local_rank if world > 1 else 0
+    loop = int(os.environ.get("NABO_BENCH_LOOPBACK", "0"))     # rehearsal: N shard-ranks as threads on ONE GPU
+    metric_id = {"euclidean": nabo_amd.EUCLIDEAN, "cosine": nabo_amd.COSINE, "canberra": nabo_amd.MOD_CANBERRA}[a.metric]
+    Yfull = pca_like(n, d, seed=1003)
     X = pca_like(m, d, seed=2003)
+    force_comm = os.environ.get("NABO_BENCH_FORCE_COMM") == "1"      # rehearsal: the N>1 code path with one rank
+    comm = _sharded.Comm.from_env(dev) if (world > 1 or force_comm) else None
+    lo, hi = shard_bounds(n, world, rank)
+    dX = _knn.DeviceBuffer(X.nbytes, dev).upload(X)
+    dY = _knn.DeviceBuffer((hi - lo) * d * 8, dev).upload(np.ascontiguousarray(Yfull[lo:hi]))
+    dI = _knn.DeviceBuffer(m * k * 8, dev)
+    dD = _knn.DeviceBuffer(m * k * 8, dev)
+    index = nabo_amd.KnnIndex(hi - lo, d, metric=metric_id, dist_factor=0.25, ref_index_base=lo, device=dev)
+    stats, xstats = [], []
 
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        from nabo_amd._dist import ShardedKnn, gpu_callables
-        torch.cuda.set_device(dev)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group(backend)
-        # build the communicators before anything is timed (RCCL creates them lazily, per collective kind)
-        cdev = ("cuda:%d" % dev) if backend == "nccl" else "cpu"
-        w_ = dist.get_world_size()
-        a2a_s, a2a_r = torch.zeros(w_ * 4, dtype=torch.float64, device=cdev), torch.zeros(w_ * 4, dtype=torch.float64, device=cdev)
-        dist.all_to_all_single(a2a_r, a2a_s)
-        ag = torch.zeros(w_ * 4, dtype=torch.int64, device=cdev)
-        dist.all_gather_into_tensor(ag, torch.zeros(4, dtype=torch.int64, device=cdev))
-        dist.all_reduce(torch.zeros(1, dtype=torch.int64, device=cdev), op=dist.ReduceOp.MAX)
-        dist.barrier()
-        tX = torch.from_numpy(X).to("cuda:%d" % dev)
-        tY = torch.from_numpy(np.ascontiguousarray(Y)).to("cuda:%d" % dev)
-        torch.cuda.synchronize()
-        x_ptr, y_ptr = tX.data_ptr(), tY.data_ptr()
-    else:
-        dX = _knn.DeviceBuffer(X.nbytes, dev).upload(X)
-        dY = _knn.DeviceBuffer(Y.nbytes, dev).upload(np.ascontiguousarray(Y))
-        dI = _knn.DeviceBuffer(m * k * 8, dev)
-        dD = _knn.DeviceBuffer(m * k * 8, dev)
-        x_ptr, y_ptr = dX.ptr, dY.ptr
-
-    metric_id = nabo_amd.COSINE if a.metric == "cosine" else nabo_amd.EUCLIDEAN
-    index = nabo_amd.KnnIndex(hi - lo, d, metric=metric_id, ref_index_base=lo, device=dev)
-    stats = []
-
-    if use_dist:
-        lk, mg, lc = gpu_callables(index, dev)
-        if os.environ.get("NABO_DIST_LOCAL_CERT") == "1":      # A/B: every shard certifies its own top-k'
-            lc = None
-        sk = ShardedKnn(dist, lk, mg, torch.device("cuda", dev), local_cand=lc)
+    if loop > 1:
+        group = _sharded.LoopbackGroup(loop, dev, n, d, metric_id, Yfull)
 
         def step():
-            index.set_ref(y_device_ptr=y_ptr)
-            out = sk.query(tX, m, k, False)
-            stats.append(index.last_stats())
-            return out
+            group.set_ref()
+            group.query_device(dX.ptr, m, k, False, dI.ptr, dD.ptr)
+            stats.append(group.indices[0].last_stats())
+            xstats.append(group.last_stats(0))
+    elif comm is not None:
+        sk = _sharded.ShardedIndex(comm, index, os.environ.get("NABO_BENCH_PROTOCOL", "global" if force_comm and a.metric != "canberra" else "auto"))
 
-        def sync():
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        def step():
+            index.set_ref(y_device_ptr=dY.ptr)
+            sk.query_device(dX.ptr, m, k, False, dI.ptr, dD.ptr)
+            stats.append(index.last_stats())
+            xstats.append(sk.last_stats())
     else:
         def step():
-            index.set_ref(y_device_ptr=y_ptr)
-            index.query_device(x_ptr, m, k, False, dI.ptr, dD.ptr)
+            index.set_ref(y_device_ptr=dY.ptr)
+            index.query_device(dX.ptr, m, k, False, dI.ptr, dD.ptr)
             stats.append(index.last_stats())
 
-        def sync():
-            _knn._lib.check(_knn._lib.lib().nabo_dev_synchronize(dev))
+    def sync():
+        _lib.check(_lib.lib().nabo_dev_synchronize(dev))
+        if comm is not None:
+            comm.barrier()                     # RCCL all-reduce on the communicator's stream + host wait
+            _lib.check(_lib.lib().nabo_dev_synchronize(dev))
 
     for _ in range(a.warmup):
         step()
     stats.clear()
+    xstats.clear()
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
-    if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % dev) if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    if comm is not None:
+        dt = comm.allreduce_max(dt)            # MAX over ranks
 
-    # light self-check outside the timed region (rank 0): sorted rows, valid indices
-    if not use_dist and not os.environ.get("NABO_DEBUG_ABLATE"):
+    # light self-check outside the timed region: sorted rows, valid indices
+    gi = gd = None
+    if not os.environ.get("NABO_DEBUG_ABLATE"):
         gi = dI.download((m, k), np.int64)
         gd = dD.download((m, k), np.float64)
         assert gi.min() >= 0 and gi.max() < n and (np.diff(gd[:: max(1, m // 4096)], axis=1) >= 0).all()
-
-    if use_dist and os.environ.get("NABO_BENCH_CHECK") == "1":
+    if os.environ.get("NABO_BENCH_CHECK") == "1" and (comm is not None or loop > 1):
         # rehearsal check: the sharded result must equal one unsharded index on the same data
-        full = pca_like(n, d, seed=1003)
-        ref_ix = nabo_amd.KnnIndex(n, d, metric=metric_id, device=dev).set_ref(full)
+        ref_ix = nabo_amd.KnnIndex(n, d, metric=metric_id, dist_factor=0.25, device=dev).set_ref(Yfull)
         ri, rd = ref_ix.query(X, k)
         ref_ix.close()
-        oi, od = step()
-        same = bool((oi.cpu().numpy() == ri).all() and (od.cpu().numpy() == rd).all())
+        same = bool(np.array_equal(gi, ri) and np.array_equal(gd, rd))
         print("rank %d sharded == unsharded: %s" % (rank, same), flush=True)
         assert same
+
     if rank == 0:
+        shards = max(world, loop, 1)
+        so = _lib.so_digest()
+        kern = index.last_kernel() if loop <= 1 else group.indices[0].last_kernel()
         ms_step = dt / a.steps * 1e3
-        t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events, kernel's own stream
-        flops = 2.0 * m * (hi - lo) * d                                       # algorithmic: the -2XY^T term
-        achieved = flops / t_kernel / 1e12
-        traffic, traffic_note = None, None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "traffic.json")))
-            wl = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, world)
-            if wl in tj and not os.environ.get("NABO_L2_MODE"):
-                # bytes per step (= the two launches of the dominant kernel), gfx950 FETCH_SIZE correction applied
-                traffic = (2.0 * tj[wl]["fetch_kb"] + tj[wl]["write_kb"]) * 1024
-                traffic_note = "bytes per step from " + tj[wl]["source"]
-        except Exception:
-            traffic, traffic_note = None, None
+        t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events on the kernel's own stream
+        n_shard = (hi - lo) if loop <= 1 else shard_bounds(n, loop, 0)[1]
+        workload = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, shards)
         line = {
             "metric": "cell-pair distances/s (k-NN build, 1Mx1M d=50 k=15)" if (m, n, d, k) == (1000000, 1000000, 50, 15)
                       else "cell-pair distances/s (k-NN build)",
@@ -197,48 +218,122 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "knn_build_s": dt / a.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way"
-                                   % (n // 1000, m // 1000, d, k, a.metric, world),
-                       "parallelism": "ref-shard%d" % world,
-                       "arithmetic": "fp32 MFMA score filter, float64 re-evaluation: indices and distances equal the "
-                                     "reference's float64 path"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_bytes": 4.0 * d * (m + (hi - lo)) + 12.0 * k * m,      # fp32 operands + (i32, f64) results
-                         "kernel": "l2_topk_kernel (v_mfma_f32_32x32x2_f32)", "kernel_ms": t_kernel * 1e3},
+            "dtype": "f32" if "f32_32x32x2" in kern else ("f16" if "f16" in kern else "f64"), "data": "synthetic",
+            "config": {"workload": workload, "parallelism": "ref-shard%d" % shards,
+                       "arithmetic": "low-precision score filter on the matrix pipe, float64 re-evaluation + certification: "
+                                     "indices and distances equal the reference's float64 path"},
             "phases_ms": {key: float(np.mean([s[key] for s in stats])) for key in
                           ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
             "fallback_rows": int(np.max([s["fallback_rows"] for s in stats])),
+            "so_digest": so,
         }
-        if world == 1 and not use_dist and not os.environ.get("NABO_L2_MODE") and not os.environ.get("NABO_DEBUG_ABLATE") \
-                and os.environ.get("NABO_BENCH_ALT", "1") == "1" and d <= 64 and a.metric == "euclidean":
-            # informational, NOT the headline: the same step with the filter on the f16 matrix pipe
-            # (3-product hi/lo split), outside the timed region; results must be the same bits
-            os.environ["NABO_L2_MODE"] = "f16x3"
-            alt = nabo_amd.KnnIndex(n, d, metric=nabo_amd.EUCLIDEAN, device=dev)
-            del os.environ["NABO_L2_MODE"]
-            aI, aD = _knn.DeviceBuffer(m * k * 8, dev), _knn.DeviceBuffer(m * k * 8, dev)
-            ts = []
-            for _ in range(3):
-                sync()
-                t0 = time.perf_counter()
-                alt.set_ref(y_device_ptr=y_ptr)
-                alt.query_device(x_ptr, m, k, False, aI.ptr, aD.ptr)
-                sync()
-                ts.append(time.perf_counter() - t0)
-            st = alt.last_stats()
-            same = bool(np.array_equal(aI.download((m, k), np.int64), gi) and np.array_equal(aD.download((m, k), np.float64), gd))
-            alt.close()
-            line["alt_f16x3"] = {"ms_per_step": min(ts[1:]) * 1e3, "value": m * n / min(ts[1:]), "kernel_ms": st["ms_topk"],
-                                 "fallback_rows": st["fallback_rows"], "same_bits_as_f32_path": same,
-                                 "note": "opt-in NABO_L2_MODE=f16x3; 3x v_mfma_f32_32x32x16_f16 per K-slab"}
-        if not a.no_cpu_baseline and world == 1 and not use_dist:
+        if a.metric != "canberra":
+            flops = 2.0 * m * n_shard * d                                     # algorithmic: the -2XY^T term
+            achieved = flops / t_kernel / 1e12
+            f16 = "f16" in kern
+            peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
+            rec = pmc_record("traffic", workload, so)
+            line["roofline"] = {
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "peak_dtype": "f16 dense MFMA" if f16 else "f32 MFMA",
+                "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of_f16_mfma_peak": achieved / PEAK_F16_MFMA_TFLOPS,
+                "traffic": (rec or {}).get("bytes_per_step"), "traffic_record": rec,
+                "algorithmic_bytes": 4.0 * d * (m + n_shard) + 12.0 * k * m,      # fp32 operands + (i32, f64) results
+                "kernel": kern, "kernel_ms": t_kernel * 1e3,
+                "matrix_pipe_busy": (rec or {}).get("matrix_pipe_busy")}
+        else:
+            rec = pmc_record("canberra", workload, so)
+            line["roofline"] = canberra_roofline(rec, t_kernel, kern)
+        if xstats:
+            line["sharded"] = {"world": world, "loopback_ranks": loop if loop > 1 else None,
+                               "exchange_ms": float(np.mean([x["ms_exchange"] for x in xstats])),
+                               "merge_ms": float(np.mean([x["ms_merge"] for x in xstats])),
+                               "gather_ms": float(np.mean([x["ms_gather"] for x in xstats])),
+                               "second_round_ms": float(np.mean([x["ms_second"] for x in xstats])),
+                               "local_query_ms": float(np.mean([x["ms_local"] for x in xstats])),
+                               "candidates_per_shard": int(xstats[-1]["candidates"]),
+                               "last_uncertified": int(max(x["uncertified"] for x in xstats)),
+                               "rank0_ms_topk": t_kernel * 1e3}
+        extras = comm is None and loop <= 1 and not a.no_extras and not os.environ.get("NABO_DEBUG_ABLATE")
+        if extras and a.metric == "euclidean" and not os.environ.get("NABO_L2_MODE"):
+            line["alt"] = alt_block(nabo_amd, _knn, index, kern, dev, n, m, d, k, dY, dX, gi, gd, sync)
+        if extras and a.metric == "euclidean" and (m, n) == (1000000, 1000000):
+            line["canberra"] = canberra_block(nabo_amd, _knn, dev, n, m, d, k, dY, dX, X, Yfull, so, sync)
+        if not a.no_cpu_baseline and comm is None and loop <= 1:
             line["cpu_baseline"] = cpu_baseline(d, k, metric_id)
+            if extras:
+                line["cpu_baseline"]["c1_end_to_end"] = c1_end_to_end(gpu=True)
         print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
+
+
+def canberra_roofline(rec, t_kernel, kern):
+    """The mod-Canberra filter is vector-ALU work (no contraction): the bound is the chip's vector ISSUE rate, and what
+    is priced against it is the number of vector instructions the kernel ACTUALLY issued (SQ_INSTS_VALU of a
+    rocprofv3 --pmc pass on this build), so the fraction cannot exceed 1."""
+    insts = (rec or {}).get("valu_insts_per_step")
+    ach = insts / t_kernel / 1e9 if insts else None
+    return {"bound": "valu-issue", "achieved": ach, "peak": PEAK_VALU_GINST, "unit": "G wave-instructions/s",
+            "frac": ach / PEAK_VALU_GINST if ach else None, "valu_insts_per_step": insts, "pmc_record": rec,
+            "kernel": kern, "kernel_ms": t_kernel * 1e3}
+
+
+def canberra_block(nabo_amd, _knn, dev, n, m, d, k, dY, dX, X, Yfull, so, sync):
+    """The reference's default target<->reference metric on the same workload (outside the headline's timed region)."""
+    import oracle
+    ix = nabo_amd.KnnIndex(n, d, metric=nabo_amd.MOD_CANBERRA, dist_factor=0.25, device=dev)
+    cI, cD = _knn.DeviceBuffer(m * k * 8, dev), _knn.DeviceBuffer(m * k * 8, dev)
+    ts, st = [], None
+    for it in range(3):
+        sync()
+        t0 = time.perf_counter()
+        ix.set_ref(y_device_ptr=dY.ptr)
+        ix.query_device(dX.ptr, m, k, False, cI.ptr, cD.ptr)
+        sync()
+        ts.append(time.perf_counter() - t0)
+        st = ix.last_stats()
+    kern = ix.last_kernel()
+    ix.close()
+    gi, gd = cI.download((m, k), np.int64), cD.download((m, k), np.float64)
+    cI.free(); cD.free()
+    rows = np.random.default_rng(11).choice(m, 32, replace=False)
+    oi, od = oracle.knn(X[rows], Yfull, k, oracle.MOD_CANBERRA, 0.25, nthreads=max(1, min(os.cpu_count() or 1, 16)))
+    same = bool(np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od))
+    best = min(ts[1:])
+    workload = "%dk ref x %dk target, d=%d, k=%d, canberra, refs sharded 1-way" % (n // 1000, m // 1000, d, k)
+    return {"workload": "1M ref x 1M target, d=50, k=15, modified Canberra (nabo/_mapping.py:29-45), dist_factor 0.25",
+            "ms_per_step": best * 1e3, "value": m * n / best, "unit": "cell-pair distances/s",
+            "phases_ms": {key: st[key] for key in ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
+            "fallback_rows": st["fallback_rows"], "sampled_rows_equal_oracle": same,
+            "roofline": canberra_roofline(pmc_record("canberra", workload, so), st["ms_topk"] * 1e-3, kern)}
+
+
+def alt_block(nabo_amd, _knn, index, kern, dev, n, m, d, k, dY, dX, gi, gd, sync):
+    """The same step with the OTHER Euclidean filter kernel (fp32 MFMA <-> f16x3 split); results must be the same bits."""
+    other = "f32" if "f16" in kern else "f16x3"
+    os.environ["NABO_L2_MODE"] = other
+    try:
+        alt = nabo_amd.KnnIndex(n, d, metric=nabo_amd.EUCLIDEAN, device=dev)
+    finally:
+        del os.environ["NABO_L2_MODE"]
+    aI, aD = _knn.DeviceBuffer(m * k * 8, dev), _knn.DeviceBuffer(m * k * 8, dev)
+    ts = []
+    for _ in range(3):
+        sync()
+        t0 = time.perf_counter()
+        alt.set_ref(y_device_ptr=dY.ptr)
+        alt.query_device(dX.ptr, m, k, False, aI.ptr, aD.ptr)
+        sync()
+        ts.append(time.perf_counter() - t0)
+    st = alt.last_stats()
+    akern = alt.last_kernel()
+    same = bool(np.array_equal(aI.download((m, k), np.int64), gi) and np.array_equal(aD.download((m, k), np.float64), gd))
+    alt.close()
+    aI.free(); aD.free()
+    return {"mode": other, "kernel": akern, "ms_per_step": min(ts[1:]) * 1e3, "value": m * n / min(ts[1:]),
+            "kernel_ms": st["ms_topk"], "fallback_rows": st["fallback_rows"], "same_bits_as_headline_path": same}
 
 
 if __name__ == "__main__":

@@ -46,9 +46,13 @@ extern "C" {
 #define NABO_E_NODEVICE   -2   /* no HIP device / device index out of range                   */
 #define NABO_E_HIP        -3   /* a HIP runtime call failed                                   */
 #define NABO_E_NOMEM      -4   /* device or host allocation failed                            */
-#define NABO_E_UNSUPPORTED -5  /* shape outside what the kernels are instantiated for         */
+#define NABO_E_UNSUPPORTED -5  /* size outside what an entry point can address (see each one)  */
 
-/* Limits of the instantiated kernels. */
+/* Limits of the instantiated FILTER kernels -- not of the API: the reference accepts any k and use_comps
+ * (nabo/_mapping.py:495-524), and so do nabo_knn / nabo_index_query.  Beyond these limits every row is answered
+ * by the exact float64 kernels (same results, brute-force speed).  nabo_index_query_candidates (shard mode)
+ * needs g <= NABO_MAX_COMPS.  Global reference indices must stay below 2^32 - 1
+ * (ref_index_base + n_ref <= 0xFFFFFFFE, checked by nabo_index_create). */
 #define NABO_MAX_COMPS      128  /* use_comps (g) for the Euclidean / cosine MFMA kernel      */
 #define NABO_MAX_K           56  /* k + drop_first (candidate lists hold 32 or 64 entries)     */
 
@@ -118,6 +122,10 @@ int nabo_index_query_candidates(nabo_index *ix, const double *X, int32_t x_on_de
  * counters[0] rows re-solved by the exact fallback, counters[1] candidate lists per row (S),
  * counters[2] candidates per list (L), counters[3] workgroups of the dominant kernel. */
 int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4]);
+/* Name of the dominant kernel the LAST query on this index ran (NUL-terminated into buf[n]): which filter the
+ * launch logic picked -- the f16x3 split on the f16 matrix pipe (default where instantiated: g < 64 and
+ * k + drop_first <= 28), the fp32-MFMA kernel (NABO_L2_MODE=f32 pins it), the Canberra filter, or the exact kernels. */
+int nabo_index_last_kernel(const nabo_index *ix, char *buf, size_t n);
 
 /* ---- shard merge (reference rows sharded over GPUs) ---------------
  * parts_idx / parts_dist: [n_parts, m, kp] DEVICE arrays, each row sorted by the canonical
@@ -128,6 +136,55 @@ int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4
 int nabo_merge_topk(int32_t device, const int64_t *parts_idx, const double *parts_dist,
                     int32_t n_parts, int64_t m, int32_t kp, int32_t k, int32_t drop_first,
                     int64_t *out_idx, double *out_dist);
+
+/* ---- reference rows sharded over the GPUs of one node ------------------------------------
+ * The reference has no multi-device path; the call site served is Mapping.calc_dist (nabo/_mapping.py:441-444).
+ * Rank r of N holds reference rows [base_r, base_r + n_r) in its own nabo_index (ref_index_base = base_r, at least
+ * k + drop_first rows) and sees ALL m target rows; after the call every rank holds the full [m,k] result, which
+ * equals the unsharded index bit for bit.  Transport: RCCL over xGMI (librccl.so is loaded on first use); no torch,
+ * no MPI.  A communicator owns a HIP stream and is used by one host thread at a time.
+ *
+ *   one process per GPU:    rank 0 calls nabo_comm_unique_id, hands the NABO_COMM_ID_BYTES bytes to the other ranks by
+ *                           any means (file, socket, launcher), every rank calls nabo_comm_create (collective);
+ *   one process, n devices: nabo_comm_create_all fills comms[n] (ncclCommInitAll); the caller drives every rank from
+ *                           its own host thread (collectives block until all ranks have entered);
+ *   loopback:               n ranks as host threads of ONE process exchanging through device-to-device copies instead
+ *                           of RCCL -- devices may repeat, so N shards can be run on a single GPU (tests, rehearsal).
+ */
+#define NABO_COMM_ID_BYTES 128
+typedef struct nabo_comm nabo_comm;
+
+int nabo_comm_unique_id(void *id /* NABO_COMM_ID_BYTES */);
+int nabo_comm_create(nabo_comm **out, int32_t device, int32_t rank, int32_t world, const void *id);
+int nabo_comm_create_all(nabo_comm **comms /* [n] */, const int32_t *devices, int32_t n);
+int nabo_comm_create_loopback(nabo_comm **comms /* [n] */, const int32_t *devices, int32_t n);
+int nabo_comm_destroy(nabo_comm *c);
+int nabo_comm_rank(const nabo_comm *c);
+int nabo_comm_world(const nabo_comm *c);
+/* Collective helpers for a host that has no other communication layer (bench.py's timing bracket):
+ * barrier, and MAX over ranks of one non-negative host double (in place). */
+int nabo_comm_barrier(nabo_comm *c);
+int nabo_comm_allreduce_max_f64(nabo_comm *c, double *value);
+
+/* Entries each shard emits under global certification: the smallest list length that leaves an expected < 0.1 rows
+ * of an m-row batch for the second round, world * m * P[Bin(kk, 1/world) >= Ls] < 0.1, within [ceil(kk/world), kk+1]
+ * and <= 32.  kk = k + drop_first. */
+int32_t nabo_candidates_per_shard(int32_t kk, int32_t world, int64_t m);
+
+/* The sharded query (collective: every rank calls it with the same m, k, drop_first, protocol and the same X).
+ * X [m,g], out_idx [m,k], out_dist [m,k]: DEVICE pointers on the communicator's device.
+ * protocol 0 = automatic; 1 = global certification (Euclidean / cosine: every shard emits
+ * nabo_candidates_per_shard entries + a bound on everything else, ONE grouped exchange to the owner of each target
+ * row, merge, the owner accepts a row when its k'-th distance lies below every shard's bound; rows it refuses are
+ * re-solved exactly in a second, small round); 2 = local certification (every shard's certified first k' entries;
+ * the only form for the modified Canberra metric).  The positional drop (nabo/_mapping.py:142) is applied after
+ * the merge.  Returns after the communicator's stream has drained. */
+int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
+                       int64_t *out_idx, double *out_dist, int32_t protocol);
+/* ms: [0] local query (this rank's shard), [1] exchange, [2] merge + certificate, [3] second round, [4] slice,
+ * [5] final all-gather, [6] total on the communicator's stream.  counters: [0] rows re-solved in the second round
+ * (all ranks), [1] candidates per shard (0 under local certification), [2] unused, [3] protocol used (1 / 2). */
+int nabo_sharded_last_stats(const nabo_comm *c, double ms[8], int64_t counters[4]);
 
 /* ---- SNN edge counts on device (consumer of the top-k: nabo/_mapping.py:186-198) --------
  * t_idx [m,k], r_idx [n,k] int64 DEVICE arrays (first k of the order rows).  For every

@@ -113,6 +113,12 @@ class KnnIndex:
         return {"ms_pack": ms[0], "ms_topk": ms[1], "ms_refine": ms[2], "ms_fallback": ms[3], "ms_total": ms[4],
                 "fallback_rows": int(cn[0]), "splits": int(cn[1]), "list_len": int(cn[2]), "workgroups": int(cn[3])}
 
+    def last_kernel(self):
+        """name of the dominant kernel the last query ran (which filter the launch logic picked)"""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.lib().nabo_index_last_kernel(self._h, buf, 128))
+        return buf.value.decode("ascii", "replace")
+
     def close(self):
         if self._h is not None and self._h.value:
             _lib.lib().nabo_index_destroy(self._h)

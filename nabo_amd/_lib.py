@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libnabo_knn.so")
+# NABO_KNN_SO: load another build of the library (kernel A/B experiments, tools/ab) WITHOUT overwriting the product's
+SO_PATH = os.environ.get("NABO_KNN_SO") or os.path.join(HERE, "libnabo_knn.so")
 
 EUCLIDEAN = 0
 MOD_CANBERRA = 1
@@ -21,8 +22,11 @@ SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
     "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
     "nabo_index_query_candidates",
-    "nabo_index_last_stats", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
+    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
+    "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
+    "nabo_comm_rank", "nabo_comm_world", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
+    "nabo_sharded_query", "nabo_sharded_last_stats",
 ]
 
 
@@ -52,6 +56,7 @@ def lib():
     L.nabo_index_query.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, i32]
     L.nabo_index_query_candidates.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
     L.nabo_index_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.nabo_index_last_kernel.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.nabo_merge_topk.argtypes = [i32, vp, vp, i32, i64, i32, i32, i32, vp, vp]
     L.nabo_snn_counts.argtypes = [i32, vp, i64, vp, i64, i32, vp]
     L.nabo_dev_malloc.argtypes = [i32, C.POINTER(vp), C.c_size_t]
@@ -59,11 +64,30 @@ def lib():
     L.nabo_memcpy_h2d.argtypes = [i32, vp, vp, C.c_size_t]
     L.nabo_memcpy_d2h.argtypes = [i32, vp, vp, C.c_size_t]
     L.nabo_dev_synchronize.argtypes = [i32]
+    L.nabo_comm_unique_id.argtypes = [vp]
+    L.nabo_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
+    L.nabo_comm_create_all.argtypes = [C.POINTER(vp), C.POINTER(i32), i32]
+    L.nabo_comm_create_loopback.argtypes = [C.POINTER(vp), C.POINTER(i32), i32]
+    L.nabo_comm_destroy.argtypes = [vp]
+    L.nabo_comm_rank.argtypes = [vp]
+    L.nabo_comm_world.argtypes = [vp]
+    L.nabo_comm_barrier.argtypes = [vp]
+    L.nabo_comm_allreduce_max_f64.argtypes = [vp, C.POINTER(dbl)]
+    L.nabo_candidates_per_shard.argtypes = [i32, i32, i64]
+    L.nabo_sharded_query.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, i32]
+    L.nabo_sharded_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     for name in SYMBOLS:
         if name not in ("nabo_version", "nabo_last_error"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L
+
+
+def so_digest():
+    """sha256 (first 16 hex digits) of the library file in use: bench.py prints it with every line"""
+    import hashlib
+    with open(SO_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def check(rc):

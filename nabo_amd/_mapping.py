@@ -261,11 +261,14 @@ class Mapping:
     :param ref_pca_fn: HDF5 file with the reference PCA data (one dataset per cell)
     :param ref_pca_grp_name: Group inside ref_pca_fn holding the data
     :param overwrite: start from scratch, deleting everything saved in mapping_h5_fn
-    Extensions (keyword only, defaults = reference behaviour): device, layout, target_metric.
+    Extensions (keyword only, defaults = reference behaviour): device, devices, layout, target_metric.
+    `devices=[0, 1, ...]` shards the reference rows over several GPUs of this node (one host thread and one RCCL
+    communicator per GPU behind nabo_sharded_query, include/nabo_knn.h; results equal the one-GPU run bit for bit);
+    every shard must hold at least k+1 reference cells.
     """
 
     def __init__(self, mapping_h5_fn, ref_name, ref_pca_fn, ref_pca_grp_name, overwrite=False, *,
-                 device=0, layout="per_cell", target_metric=None):
+                 device=0, devices=None, layout="per_cell", target_metric=None, shard_transport="rccl"):
         self._h5Fn = mapping_h5_fn
         if ref_name.find("__") != -1:
             raise ValueError("ERROR: Underscores are not allowed in the value for `ref_name` parameter")
@@ -281,7 +284,9 @@ class Mapping:
         # None / 'mod_canberra' = the reference's target<->reference metric (nabo/_mapping.py:122-124)
         self._targetMetric = {None: MOD_CANBERRA, "mod_canberra": MOD_CANBERRA, "euclidean": EUCLIDEAN,
                               "cosine": COSINE}[target_metric]
-        self._device = device
+        self._devices = [int(d) for d in devices] if devices else [int(device)]
+        self._device = self._devices[0]
+        self._shardTransport = shard_transport       # "rccl", or "loopback" (device-to-device copies; devices may repeat)
         self._layout = layout
         self._check_h5(self._refPcaFn, self._refPcaGrp)
         self.refCells = []
@@ -429,9 +434,19 @@ class Mapping:
         k_store = min(self._k if self._k is not None else 1, n_ref - drop)
         if k_store < 1:
             raise ValueError("ERROR: not enough reference cells")
-        idx, dist = _knn.knn(X, ref, k_store, metric=EUCLIDEAN if intra_ref else self._targetMetric,
-                             dist_factor=float(self._distFactor), ref_mask=mask, drop_first=bool(drop),
-                             device=self._device)
+        metric = EUCLIDEAN if intra_ref else self._targetMetric
+        if len(self._devices) > 1:
+            # reference rows sharded over the GPUs (nabo/_mapping.py:441-444 is the call site this replaces)
+            from ._sharded import ShardedGroup
+            grp = ShardedGroup(self._devices, n_ref, self._useComps, metric, ref, dist_factor=float(self._distFactor),
+                               ref_mask=mask, transport=self._shardTransport)
+            try:
+                idx, dist = grp.set_ref().query(X, k_store, drop_first=bool(drop))
+            finally:
+                grp.close()
+        else:
+            idx, dist = _knn.knn(X, ref, k_store, metric=metric, dist_factor=float(self._distFactor), ref_mask=mask,
+                                 drop_first=bool(drop), device=self._device)
         with _h5py().File(self._h5Fn, mode="a") as h5:
             self._store_knn(h5, dist_grp, sorted_dist_grp, cells, idx, dist)
 

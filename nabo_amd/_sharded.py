@@ -1,0 +1,254 @@
+"""Reference rows sharded over the GPUs of one node, torch-free (include/nabo_knn.h
+`nabo_comm_*`, `nabo_sharded_query`).  See DESIGN.md section 5 for the protocol."""
+from math import comb
+
+
+def shard_bounds(n, world, rank):
+    """Contiguous, balanced reference-row partition: rows [lo, hi) for `rank`."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def candidates_per_shard(kk, world, m=None):
+    """Entries each shard emits in the globally certified protocol.  A row needs the second round when some shard
+    holds at least Ls of its global top-k'; for exchangeable shards that is world * P[Bin(k', 1/world) >= Ls] per
+    row.  With `m` (target rows) given, Ls is the smallest length that leaves an expected < 0.1 such rows in the
+    whole batch -- never more than k'+1 (a shard cannot hold more than k' of the top k') -- because a longer list
+    costs ~0.7 ms per entry and step while the second round costs ~3.5 ms plus three more collectives.  Without
+    `m`: the share k'/N with 50 % head room, +6.  (The C side restates this rule: nabo_candidates_per_shard.)"""
+    cap = min(kk + 1, 32)
+    if m is None:
+        ls = max(8, -(-3 * kk // (2 * world)) + 6, -(-kk // world))
+        return min(ls, kk + 8, 32)
+    p = 1.0 / world
+    tail = 0.0
+    ls = cap
+    for j in range(kk, 0, -1):                       # tail = P[Bin(kk, p) >= j]
+        tail += comb(kk, j) * p ** j * (1.0 - p) ** (kk - j)
+        if tail * world * m >= 0.1:
+            ls = j + 1
+            break
+        ls = j
+    return max(min(ls, cap), -(-kk // world), 1)
+
+
+# ---- communicators and the sharded query through the C ABI ------------------------------------------------------
+import ctypes as C      # noqa: E402
+import os               # noqa: E402
+import threading        # noqa: E402
+import time             # noqa: E402
+
+import numpy as np      # noqa: E402
+
+from . import _lib      # noqa: E402
+
+ID_BYTES = 128
+PROTOCOLS = {"auto": 0, "global": 1, "local": 2}
+
+
+def exchange_unique_id(rank, world, make_id, path=None, timeout=300.0):
+    """One process per GPU on ONE node: rank 0 creates the RCCL unique id (`make_id()` -> 128 bytes) and publishes it
+    through a file (written under a temporary name, then renamed: readers never see a partial file); the other ranks
+    poll for it.  The name is built from what the launcher gives every rank identically -- MASTER_PORT and the parent
+    (launcher) pid -- and rank 0 removes it when the communicator is closed.  Any other channel works as well
+    (nabo_comm_create only needs the bytes)."""
+    if path is None:
+        path = os.path.join(os.environ.get("NABO_ID_DIR", "/tmp"), "nabo_rccl_%s_%d.id"
+                            % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+    if rank == 0:
+        blob = bytes(make_id())
+        assert len(blob) == ID_BYTES
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "wb") as f:
+            f.write(blob)
+        os.replace(tmp, path)
+        return blob, path
+    t0 = time.time()
+    while True:
+        try:
+            if time.time() - os.path.getmtime(path) < 600.0:          # not a leftover of an older job
+                with open(path, "rb") as f:
+                    blob = f.read()
+                if len(blob) == ID_BYTES:
+                    return blob, path
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise _lib.NaboError("rank %d: no RCCL unique id at %s after %.0f s" % (rank, path, timeout))
+        time.sleep(0.01)
+
+
+class Comm:
+    """One rank's communicator (nabo_comm, include/nabo_knn.h).  No torch: RCCL is reached through libnabo_knn.so."""
+
+    def __init__(self, handle, device, rank, world, id_path=None):
+        self._h, self.device, self.rank, self.world, self._id_path = handle, device, rank, world, id_path
+
+    @classmethod
+    def from_env(cls, device=None):
+        """RANK / WORLD_SIZE / LOCAL_RANK as torch.distributed.run (or any launcher) exports them."""
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        L = _lib.lib()
+
+        def make_id():
+            buf = C.create_string_buffer(ID_BYTES)
+            _lib.check(L.nabo_comm_unique_id(buf))
+            return buf.raw
+
+        blob, path = exchange_unique_id(rank, world, make_id)
+        h = C.c_void_p()
+        _lib.check(L.nabo_comm_create(C.byref(h), int(device), rank, world, C.c_char_p(blob)))
+        return cls(h, int(device), rank, world, path if rank == 0 else None)
+
+    @classmethod
+    def all_devices(cls, devices):
+        """One process driving several GPUs: a communicator per device (ncclCommInitAll); call their collectives from
+        one host thread each (`ShardedGroup` does)."""
+        return cls._many(devices, "nabo_comm_create_all")
+
+    @classmethod
+    def loopback(cls, devices):
+        """N ranks in this process exchanging through device-to-device copies; devices may repeat (N shards on ONE GPU)."""
+        return cls._many(devices, "nabo_comm_create_loopback")
+
+    @classmethod
+    def _many(cls, devices, fn):
+        n = len(devices)
+        hs = (C.c_void_p * n)()
+        dv = (C.c_int32 * n)(*[int(d) for d in devices])
+        _lib.check(getattr(_lib.lib(), fn)(hs, dv, n))
+        return [cls(C.c_void_p(hs[i]), int(devices[i]), i, n) for i in range(n)]
+
+    def barrier(self):
+        _lib.check(_lib.lib().nabo_comm_barrier(self._h))
+
+    def allreduce_max(self, value):
+        v = C.c_double(float(value))
+        _lib.check(_lib.lib().nabo_comm_allreduce_max_f64(self._h, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if self._h is not None and self._h.value:
+            _lib.lib().nabo_comm_destroy(self._h)
+            self._h = C.c_void_p()
+            if self._id_path:
+                try:
+                    os.remove(self._id_path)
+                except OSError:
+                    pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
+
+
+class ShardedIndex:
+    """This rank's reference shard (a KnnIndex created with ref_index_base = its first global row) behind a
+    communicator: `query_device` is nabo_sharded_query -- collective, device pointers, full [m,k] result on every rank."""
+
+    def __init__(self, comm, index, protocol="auto"):
+        self.comm, self.index, self.protocol = comm, index, PROTOCOLS[protocol]
+
+    def query_device(self, x_ptr, m, k, drop_first, out_idx_ptr, out_dist_ptr):
+        _lib.check(_lib.lib().nabo_sharded_query(self.comm._h, self.index._h, int(x_ptr), int(m), int(k),
+                                                 int(bool(drop_first)), int(out_idx_ptr), int(out_dist_ptr), self.protocol))
+
+    def last_stats(self):
+        ms = (C.c_double * 8)()
+        cn = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().nabo_sharded_last_stats(self.comm._h, ms, cn))
+        return {"ms_local": ms[0], "ms_exchange": ms[1], "ms_merge": ms[2], "ms_second": ms[3], "ms_slice": ms[4],
+                "ms_gather": ms[5], "ms_total": ms[6], "uncertified": int(cn[0]), "candidates": int(cn[1]),
+                "protocol": {1: "global", 2: "local"}.get(int(cn[3]), "?")}
+
+
+class ShardedGroup:
+    """One process, several ranks: rank i = (device[i], shard i of the references), each driven by its own host thread
+    (the C calls release the GIL; the collectives inside nabo_sharded_query rendezvous the threads).
+    transport "rccl": one GPU per rank, ncclCommInitAll; "loopback": device-to-device copies, devices may repeat."""
+
+    def __init__(self, devices, n_ref, g, metric, Y, dist_factor=0.25, ref_mask=None, transport="rccl", protocol="auto"):
+        from ._knn import KnnIndex
+        self.devices = [int(d) for d in devices]
+        N = len(self.devices)
+        self.comms = Comm.loopback(self.devices) if transport == "loopback" else Comm.all_devices(self.devices)
+        self.indices, self._Y, self._mask = [], [], []
+        for r in range(N):
+            lo, hi = shard_bounds(n_ref, N, r)
+            self.indices.append(KnnIndex(hi - lo, g, metric=metric, dist_factor=dist_factor, ref_index_base=lo,
+                                         device=self.devices[r]))
+            self._Y.append(np.ascontiguousarray(Y[lo:hi], dtype=np.float64))
+            self._mask.append(None if ref_mask is None else np.ascontiguousarray(ref_mask[lo:hi], dtype=np.uint8))
+        self.shards = [ShardedIndex(c, ix, protocol) for c, ix in zip(self.comms, self.indices)]
+
+    def _each(self, fn):
+        errs = [None] * len(self.shards)
+
+        def run(r):
+            try:
+                fn(r)
+            except BaseException as e:      # noqa: BLE001
+                errs[r] = e
+
+        th = [threading.Thread(target=run, args=(r,)) for r in range(len(self.shards))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+
+    def set_ref(self):
+        self._each(lambda r: self.indices[r].set_ref(self._Y[r], ref_mask=self._mask[r]))
+        return self
+
+    def query_device(self, x_ptrs, m, k, drop_first, out_idx_ptrs, out_dist_ptrs):
+        """x_ptrs / out_*_ptrs: one device pointer per rank (on that rank's device), or a single pointer when every
+        rank sits on the same device (X is then shared, and every rank writes the same bytes to the same outputs --
+        pass per-rank outputs to check that)."""
+        N = len(self.shards)
+        xs = list(x_ptrs) if isinstance(x_ptrs, (list, tuple)) else [x_ptrs] * N
+        oi = list(out_idx_ptrs) if isinstance(out_idx_ptrs, (list, tuple)) else [out_idx_ptrs] * N
+        od = list(out_dist_ptrs) if isinstance(out_dist_ptrs, (list, tuple)) else [out_dist_ptrs] * N
+        self._each(lambda r: self.shards[r].query_device(xs[r], m, k, drop_first, oi[r], od[r]))
+
+    def query(self, X, k, drop_first=False):
+        """host arrays in and out (X replicated to every rank's device; rank 0's copy of the result is returned)"""
+        from ._knn import DeviceBuffer
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        m = X.shape[0]
+        bufs = {}
+        xs, oi, od = [], [], []
+        for d in self.devices:
+            if d not in bufs:
+                bufs[d] = DeviceBuffer(X.nbytes, d).upload(X)
+            xs.append(bufs[d].ptr)
+        outs = [(DeviceBuffer(m * k * 8, d), DeviceBuffer(m * k * 8, d)) for d in self.devices]
+        try:
+            self.query_device(xs, m, k, drop_first, [a.ptr for a, _ in outs], [b.ptr for _, b in outs])
+            return outs[0][0].download((m, k), np.int64), outs[0][1].download((m, k), np.float64)
+        finally:
+            for b in bufs.values():
+                b.free()
+            for a, b in outs:
+                a.free(); b.free()
+
+    def last_stats(self, r=0):
+        return self.shards[r].last_stats()
+
+    def close(self):
+        for ix in self.indices:
+            ix.close()
+        for c in self.comms:
+            c.close()
+
+
+class LoopbackGroup(ShardedGroup):
+    """bench.py / tests: N shard-ranks on ONE GPU through the loopback transport."""
+
+    def __init__(self, n_ranks, device, n_ref, g, metric, Y, **kw):
+        super().__init__([device] * n_ranks, n_ref, g, metric, Y, transport="loopback", **kw)

@@ -79,6 +79,7 @@ hipError_t cbf_pack_refs16_launch(const double *Y, int64_t n, int g, int gp, con
 hipError_t cbf_pack_targets16_launch(const double *X, int64_t m, int g, int gp, double f, const double *scale, void *xh,
                                      hipStream_t st);
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
+hipError_t iota_launch(uint32_t *out, int64_t n, hipStream_t st);
 hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
                                int64_t *out_idx, double *out_dist, hipStream_t st);
 hipError_t null_hist_launch(int64_t n_t, int P, uint64_t seed, int key_bits, const uint64_t *prefix, int done_bits,
@@ -215,7 +216,24 @@ struct nabo_index {
 
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
+    char kernel[96] = "";          // dominant kernel of the last query (nabo_index_last_kernel)
 };
+
+namespace nabo {
+// for sharded.hip (same library, other translation unit)
+int api_fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int index_device(const nabo_index *ix) { return ix->device; }
+int index_g(const nabo_index *ix) { return ix->g; }
+int index_metric(const nabo_index *ix) { return ix->metric; }
+bool index_can_emit_candidates(const nabo_index *ix) { return ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0; }
+}  // namespace nabo
 
 // Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernel.
 static int ensure_packed(nabo_index *ix, bool want_h)
@@ -279,7 +297,7 @@ static int apply_mask(nabo_index *ix, const uint8_t *ref_mask)
         for (int64_t j = 0; j < ix->n; ++j)
             if (ref_mask[j]) {
                 ++ix->n_masked;
-                if ((int)lst.size() < NABO_MAX_K) lst.push_back((uint32_t)j);
+                lst.push_back((uint32_t)j);          // all of them: the exact route serves any k (order-row tail)
             }
         if (ix->n_masked > 0) {
             if ((rc = ix->maskbuf.reserve((size_t)ix->n))) return rc;
@@ -317,9 +335,10 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
         return fail(NABO_E_INVALID, "unknown metric %d", metric);
     if (metric == NABO_METRIC_MOD_CANBERRA && !(dist_factor > 0))
         return fail(NABO_E_INVALID, "dist_factor must be > 0");          // nabo/_mapping.py:516-521
-    if (metric != NABO_METRIC_MOD_CANBERRA && g > NABO_MAX_COMPS)
-        return fail(NABO_E_UNSUPPORTED, "g=%d exceeds NABO_MAX_COMPS=%d", g, NABO_MAX_COMPS);
     if (ref_index_base < 0) return fail(NABO_E_INVALID, "ref_index_base must be >= 0");
+    // the shard merge carries global indices as 32-bit payloads (0xFFFFFFFF = absent)
+    if (ref_index_base + n_ref > 0xFFFFFFFEll)
+        return fail(NABO_E_UNSUPPORTED, "ref_index_base + n_ref = %lld exceeds 2^32 - 2", (long long)(ref_index_base + n_ref));
     int rc = use_device(device);
     if (rc) return rc;
     nabo_index *ix = new (std::nothrow) nabo_index();
@@ -331,9 +350,12 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
     ix->f = dist_factor;
     ix->base = ref_index_base;
     if (metric != NABO_METRIC_MOD_CANBERRA) {
-        ix->ksteps = pick_ksteps(g);
+        ix->ksteps = pick_ksteps(g);           // -1: g > NABO_MAX_COMPS, every query takes the exact float64 route
+        // Filter kernel: the f16x3 split on the f16 matrix pipe wherever it is instantiated (g < 64; per query also
+        // k + drop_first + 4 <= 32) -- same results, ~2x the fp32-MFMA kernel; NABO_L2_MODE=f32 pins the fp32 kernel,
+        // =f16x3 is the default spelled out.
         const char *md = getenv("NABO_L2_MODE");
-        if (md && strcmp(md, "f16x3") == 0 && nabo::l2h_pick_ks16(g) > 0) {
+        if (!(md && strcmp(md, "f32") == 0) && ix->ksteps > 0 && nabo::l2h_pick_ks16(g) > 0) {
             ix->mode = 1;
             ix->ks16 = nabo::l2h_pick_ks16(g);
         }
@@ -382,7 +404,9 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         ix->dY = ix->ybuf.as<double>();
     }
     if ((rc = apply_mask(ix, ref_mask))) return rc;
-    if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
+    if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps < 0) {
+        HIP_TRY(hipStreamSynchronize(st));             // exact route only: the float64 rows are all it needs
+    } else if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 64;      // room for split padding (+inf-norm tiles; up to 32 splits)
         ix->packed_f32 = ix->packed_f16 = false;
@@ -454,7 +478,7 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
     int rc = use_device(ix->device);
     if (rc) return rc;
     if ((rc = apply_mask(ix, ref_mask))) return rc;
-    if (ix->metric != NABO_METRIC_MOD_CANBERRA) {       // masked cells carry ||y||^2 = +inf in the packed tiles
+    if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0) {       // masked cells carry ||y||^2 = +inf in the packed tiles
         ix->packed_f32 = ix->packed_f16 = false;
         if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
     }
@@ -477,7 +501,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         return fail(NABO_E_INVALID, "k + drop_first = %d exceeds the %lld references", kk, (long long)ix->n);
     if (cand_mode && (ix->metric == NABO_METRIC_MOD_CANBERRA || !out_bound || !out_on_device || k > 32))
         return fail(NABO_E_INVALID, "candidate mode: Euclidean or cosine metric, device outputs, <= 32 candidates");
-    if (kk > NABO_MAX_K) return fail(NABO_E_UNSUPPORTED, "k + drop_first = %d exceeds NABO_MAX_K=%d", kk, NABO_MAX_K);
+    // Shapes outside the instantiated filter kernels (k' > NABO_MAX_K, g > NABO_MAX_COMPS) are answered by the exact
+    // float64 kernels for every row: the reference accepts any k / use_comps (nabo/_mapping.py:495-524).
+    const bool exact_route = kk > NABO_MAX_K || (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps < 0);
+    if (exact_route && cand_mode)
+        return fail(NABO_E_UNSUPPORTED, "candidate mode needs g <= %d (got %d)", NABO_MAX_COMPS, ix->g);
     int rc = use_device(ix->device);
     if (rc) return rc;
     hipStream_t st = ix->stream;
@@ -508,7 +536,26 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
     int64_t n_wg = 0;
     HIP_TRY(hipEventRecord(ix->ev[0], st));
 
-    if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
+    if (exact_route) {
+        uint64_t d_rows = (1ull << 30) / ((uint64_t)ix->n * sizeof(double));
+        if (d_rows < 1) d_rows = 1;
+        if (d_rows > (uint64_t)m) d_rows = (uint64_t)m;
+        if (d_rows > 65528) d_rows = 65528;
+        if (m > 0xFFFFFFF0ll) return fail(NABO_E_UNSUPPORTED, "m=%lld: fewer than 2^32-16 rows per call", (long long)m);
+        if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
+        if ((rc = ix->exact_d.reserve((size_t)d_rows * ix->n * sizeof(double)))) return rc;
+        HIP_TRY(nabo::iota_launch(ix->fails.as<uint32_t>(), m, st));
+        HIP_TRY(hipEventRecord(ix->ev[1], st));
+        HIP_TRY(hipEventRecord(ix->ev[2], st));
+        HIP_TRY(hipEventRecord(ix->ev[3], st));
+        HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
+                                        (unsigned int)m, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
+                                        d_oidx, d_odist, ix->exact_d.as<double>(), (unsigned int)d_rows, st));
+        HIP_TRY(hipEventRecord(ix->ev[4], st));
+        n_fail = (unsigned int)m;
+        S = 0;
+        snprintf(ix->kernel, sizeof(ix->kernel), "exact_dist_rows_kernel + exact_select_rows_kernel (float64 brute force)");
+    } else if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         const bool cosine = ix->metric == NABO_METRIC_COSINE;
         const double *dXp = dX;                           // what the filter packs
         if (cosine) {
@@ -545,6 +592,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             }
         }
         const int epl_launch = r1 ? -1 : epl;
+        if (!ix->wide_retry) {
+            if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,40> (3 x v_mfma_f32_32x32x16_f16, f16x3 split)", ix->ks16);
+            else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
+                          r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 40 : 80);
+        }
         if ((rc = ensure_packed(ix, use_h))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
@@ -753,10 +805,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (S < 1) S = 1;
         bool done = false;
         const int S_exact = S;
+        snprintf(ix->kernel, sizeof(ix->kernel), "canberra_topk_kernel (float64)");
         if (ix->cb_f32 && n_valid >= kk) {
             // fp32 lower-bound filter -> float64 refine + certification -> exact re-solve of uncertified rows
             float slack, plateau;
             nabo::cbf_constants(g, &slack, &plateau);
+            snprintf(ix->kernel, sizeof(ix->kernel), "cbf_filter_kernel<%d> (packed-f16 count + fp32 lower bound)", ix->cb_gp);
             // filter geometry: T rows per workgroup, 2 workgroups per CU resident; every (row, split) ends
             // with `lists` candidate lists (one per wave).  Splits fill the chip when there are few rows and
             // trim the last, partially filled round of workgroups when there are many.
@@ -945,6 +999,13 @@ int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4
     return NABO_OK;
 }
 
+int nabo_index_last_kernel(const nabo_index *ix, char *buf, size_t n)
+{
+    if (!ix || !buf || n == 0) return fail(NABO_E_INVALID, "NULL argument");
+    snprintf(buf, n, "%s", ix->kernel);
+    return NABO_OK;
+}
+
 int nabo_knn(const double *X, int64_t m, const double *Y, int64_t n, int32_t g, int32_t k, int32_t metric,
              double dist_factor, const uint8_t *ref_mask, int32_t drop_first, int64_t *out_idx, double *out_dist,
              int32_t device)
@@ -1034,6 +1095,7 @@ static int score_null_impl(int32_t device, int64_t n_ref, const int64_t *row_ptr
         if (row_ptr[0] != 0 || E < 0) return fail(NABO_E_INVALID, "row_ptr must start at 0");
         for (int64_t r = 0; r < n_ref; ++r)
             if (row_ptr[r + 1] < row_ptr[r]) return fail(NABO_E_INVALID, "row_ptr must be non-decreasing");
+        if (E > 0 && (!edge_t || !edge_w)) return fail(NABO_E_INVALID, "NULL edge arrays");
         for (int64_t e = 0; e < E; ++e)
             if (edge_t[e] < 0 || edge_t[e] >= n_t) return fail(NABO_E_INVALID, "edge_t[%lld] out of range", (long long)e);
     }

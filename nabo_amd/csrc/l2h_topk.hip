@@ -131,7 +131,12 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
 
     const int64_t t_begin = (int64_t)split * tiles_per_split;
     const int64_t t_end = t_begin + tiles_per_split;
-    auto tile_ptr = [&](int64_t t) { return Ypk + (t < t_end ? t : t_end - 1) * (int64_t)YTB; };
+    // dbg & 2 (timing experiments only, results are garbage): the stream wraps inside a 128-tile window that stays
+    // in the XCD's L2 -- the kernel's time without any L2 miss
+    auto tile_ptr = [&](int64_t t) {
+        const int64_t tc = t < t_end ? t : t_end - 1;
+        return Ypk + ((dbg & 2) ? t_begin + ((tc - t_begin) & 127) : tc) * (int64_t)YTB;
+    };
 
     HTile<KS16> y, yn;
     load_htile<KS16>(y, tile_ptr(t_begin), lane);
@@ -186,13 +191,22 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
     const bool live = cell < ncell;
     unsigned char *o = out + tile * (int64_t)htile_bytes(ks16, IS_REF);
     double ss = 0.0;
+    // cells whose scaled components leave the f16 range (targets carry a factor 2; references are scaled to
+    // 2^12) or are not finite: zero fragments + NaN norm (targets: the row cannot be certified and goes to the
+    // exact kernels) / +inf norm slot (references: out of the filter) -- as pack_tiles_kernel does for fp32
+    bool bad = false;
+    for (int k = hh; k < g && live; k += 2) {
+        const float f = (float)((V[cell * g + k] - centre[k]) * scale);
+        bad = bad || !(fabsf(f) <= 30000.0f);
+    }
+    bad = bad || (__shfl_xor((int)bad, 32, 64) != 0);
     f16x8 vh[4], vl[4];                                      // ks16 <= 4
     for (int s = 0; s < ks16; ++s) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * s + 8 * hh + j;
             float f = 0.0f;
-            if (live && k < g) f = (float)((V[cell * g + k] - centre[k]) * scale);
+            if (live && k < g && !bad) f = (float)((V[cell * g + k] - centre[k]) * scale);
             const _Float16 h = (_Float16)f;
             const _Float16 l = (_Float16)(f - (float)h);
             const double rep = (double)(float)h + (double)(float)l;
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
     float slot_hi, slot_lo = 0.0f;
     if (IS_REF) {
         float nf = __builtin_inff();
-        if (live && !(mask && mask[cell])) {
+        if (live && !bad && !(mask && mask[cell])) {
             nf = (float)ss * 3.0517578125e-05f;              // ||y~||^2 (scaled units) * 2^-15, <= 2^15
             if (hh == 0) atomicMax(norm_max_bits, __float_as_uint((float)ss));        // SCALED units (host unscales)
         }
@@ -215,7 +229,7 @@ __global__ __launch_bounds__(64) void pack_htiles_kernel(const double *__restric
         if (nf < __builtin_inff()) slot_lo = (float)(_Float16)(nf - (float)h);
     } else {
         slot_hi = live ? 32768.0f : 0.0f;                     // 2^15, NOT scaled by -2: the product is +||y||^2
-        if (hh == 0 && live) norm64[cell] = ss / (scale * scale);
+        if (hh == 0 && live) norm64[cell] = bad ? __builtin_nan("") : ss / (scale * scale);
     }
     for (int s = 0; s < ks16; ++s) {
         if (g / 16 == s && ((g % 16) >> 3) == hh) {

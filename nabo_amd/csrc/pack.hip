@@ -53,6 +53,20 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(const double *__restrict
     const bool live = cell < ncell;
     const int tile_floats = Q * 256 + (IS_REF ? 32 : 0);
     float *o = out + tile * tile_floats;
+    // The score kernel is compiled with -fno-honor-nans: its scores must be finite or +inf BY CONSTRUCTION.
+    // References are scaled to max |y~| <= 1; a target component beyond PACK_LIMIT (a target that dwarfs the
+    // references, or non-finite input) could push a partial sum of the fma chain to +-inf and the next term to
+    // inf - inf.  Such a cell gets ZERO fragments (its scores are then just ||y~||^2) and, for targets, a NaN
+    // norm: refine.hip cannot certify the row (every comparison with its bound is false) and the exact float64
+    // kernels answer it.  A reference cell with a non-finite component is taken out of the filter like a masked
+    // one (+inf norm).  2 * 128 components * PACK_LIMIT * 1 stays far inside the fp32 range.
+    constexpr float PACK_LIMIT = 1.0e30f;
+    bool bad = false;
+    for (int k = hh; k < g && live; k += 2) {
+        const float f = (float)((V[cell * g + k] - centre[k]) * scale);
+        bad = bad || !(fabsf(f) <= PACK_LIMIT);
+    }
+    bad = bad || (__shfl_xor((int)bad, 32, 64) != 0);
     double ss = 0.0;
     for (int q = 0; q < Q; ++q) {
         f32x4 v;
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(const double *__restrict
         for (int e = 0; e < 4; ++e) {
             const int k = 2 * (4 * q + e) + hh;
             float f = 0.0f;
-            if (live && k < g) {
+            if (live && k < g && !bad) {
                 f = (float)((V[cell * g + k] - centre[k]) * scale);      // scale: a power of two (exact)
                 ss += (double)f * (double)f;
             }
@@ -71,13 +85,13 @@ __global__ __launch_bounds__(64) void pack_tiles_kernel(const double *__restrict
     ss += __shfl_xor(ss, 32, 64);           // both k-halves of the cell
     if (IS_REF) {
         float nf = __builtin_inff();
-        if (live && !(mask && mask[cell])) {
+        if (live && !bad && !(mask && mask[cell])) {
             nf = (float)ss;
             if (hh == 0) atomicMax(norm_max_bits, __float_as_uint(nf));
         }
         if (hh == 0) o[Q * 256 + ((c >> 2) & 1) * 16 + (c & 3) + 4 * (c >> 3)] = nf;
     } else {
-        if (hh == 0 && live) norm64[cell] = ss / (scale * scale);        // UNSCALED units
+        if (hh == 0 && live) norm64[cell] = bad ? __builtin_nan("") : ss / (scale * scale);        // UNSCALED units
     }
 }
 

@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
             if ((kout >> 6) == r) dn = __shfl(key[r], kout & 63, 64);
         bound = fmin(bound, dn * dn * (1.0 - 1e-12));
     }
+    if (!(xnorm[row] == xnorm[row])) bound = -__builtin_inf();      // target outside the filter's range (pack.hip)
 #pragma unroll
     for (int r = 0; r < NCL; ++r) {
         const int e = r * 64 + lane;
@@ -507,6 +508,19 @@ __global__ void scatter_rows_kernel(const int64_t *__restrict__ si, const double
     const int64_t o = (int64_t)rows[e / k] * k + e % k;
     out_idx[o] = si[e];
     out_dist[o] = sd[e];
+}
+
+__global__ void iota_kernel(uint32_t *__restrict__ out, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)i;
+}
+
+hipError_t iota_launch(uint32_t *out, int64_t n, hipStream_t st)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, n);
+    return hipGetLastError();
 }
 
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st)

@@ -1,0 +1,673 @@
+// sharded.hip -- reference rows sharded over the GPUs of one node: communicators and the
+// sharded query of the C ABI (include/nabo_knn.h: nabo_comm_*, nabo_sharded_query).  No torch, no MPI.
+//
+// The reference has no multi-device path (its _calc_dist, nabo/_mapping.py:48-148, is one Python loop); the call
+// site this entry point serves is Mapping.calc_dist (nabo/_mapping.py:441-444).
+//
+// Transports
+//   * RCCL over xGMI (the product path): librccl.so is dlopen'ed on first use -- a host that never shards does not
+//     need it -- one communicator per GPU, created either per rank (one process per GPU: ncclCommInitRank with a
+//     unique id the caller passes around) or for all devices of one process (ncclCommInitAll; one host thread per
+//     device then drives its rank).  Every exchange is ONE grouped operation: the candidate lists, their distances and
+//     the bounds go out as ncclSend/ncclRecv pairs inside a single ncclGroupStart/End, the result slices as two
+//     ncclAllGather in one group.  xGMI is point to point: each peer pair moves only the m/N rows the receiver owns.
+//   * loopback: N ranks as host threads of ONE process, rendezvous through a host barrier and device-to-device
+//     copies.  Same call sequence, same buffers, same kernels -- it exists so that the whole protocol can be run (and
+//     is tested) with N shards on a single GPU; it is also a correct transport for several peer-accessible devices.
+//
+// Protocol (rank r of N holds reference rows [base_r, base_r + n_r); every rank sees all m target rows; rank r OWNS
+// target rows [r*mr, (r+1)*mr), mr = ceil(m/N)):
+//   global certification (Euclidean / cosine, k' = k + drop_first):
+//     1. nabo_index_query_candidates: the first Ls entries of the shard's order rows + a lower bound on the squared
+//        distance of everything the shard did not emit (Ls = nabo_candidates_per_shard(k', N, m));
+//     2. one exchange: owner(row) receives N lists + N bounds;
+//     3. merge by (distance, index) to k' entries; the owner accepts a row when d_k'^2 (1+1e-12) < min bound: no
+//        unreported reference anywhere can then enter or tie;
+//     4. refused rows (a shard held >= Ls of the global top-k'): MAX-all-reduce of the count; if any, all-gather of the
+//        row ids, exact local top-k' of just those rows on every shard (nabo_index_query), all-gather, merge;
+//     5. positional drop (nabo/_mapping.py:142 is positional) AFTER the merge, all-gather of the [mr,k] slices.
+//   local certification (modified Canberra, or k'/N beyond the candidate lists): every shard's certified top-k',
+//     the same exchange and merge.
+// The merge is deterministic, so N shards == 1 shard bit for bit.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <pthread.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nabo_knn.h"
+
+namespace nabo {
+hipError_t merge_parts_launch(const double *parts_d, const int64_t *parts_i, int n_parts, int64_t m, int kp, int k,
+                              int drop, int64_t *out_idx, double *out_dist, hipStream_t st);
+hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
+// api.hip
+int api_fail(int code, const char *fmt, ...);
+int index_device(const nabo_index *ix);
+int index_g(const nabo_index *ix);
+int index_metric(const nabo_index *ix);
+bool index_can_emit_candidates(const nabo_index *ix);
+}  // namespace nabo
+
+namespace {
+
+using nabo::api_fail;
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return api_fail(e__ == hipErrorOutOfMemory ? NABO_E_NOMEM : NABO_E_HIP, "%s failed: %s", \
+                            #expr, hipGetErrorString(e__));                                        \
+    } while (0)
+
+// ---- librccl.so, resolved at run time -------------------------------------------------------------------
+struct Rccl {
+    void *h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+
+Rccl g_rccl;
+pthread_mutex_t g_rccl_lock = PTHREAD_MUTEX_INITIALIZER;
+
+int load_rccl()
+{
+    pthread_mutex_lock(&g_rccl_lock);
+    if (!g_rccl.h) {
+        const char *env = getenv("NABO_RCCL_LIB");
+        const char *names[] = {env, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+        void *h = nullptr;
+        for (const char *nm : names)
+            if (nm && *nm && (h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) {
+            pthread_mutex_unlock(&g_rccl_lock);
+            return api_fail(NABO_E_UNSUPPORTED, "librccl.so could not be loaded (%s): multi-GPU sharding needs RCCL", dlerror());
+        }
+        bool ok = true;
+#define NABO_SYM(field, name)                                                    \
+    do {                                                                         \
+        g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+        ok = ok && g_rccl.field;                                                 \
+    } while (0)
+        NABO_SYM(GetUniqueId, "ncclGetUniqueId");
+        NABO_SYM(CommInitRank, "ncclCommInitRank");
+        NABO_SYM(CommInitAll, "ncclCommInitAll");
+        NABO_SYM(CommDestroy, "ncclCommDestroy");
+        NABO_SYM(AllReduce, "ncclAllReduce");
+        NABO_SYM(AllGather, "ncclAllGather");
+        NABO_SYM(Send, "ncclSend");
+        NABO_SYM(Recv, "ncclRecv");
+        NABO_SYM(GroupStart, "ncclGroupStart");
+        NABO_SYM(GroupEnd, "ncclGroupEnd");
+        NABO_SYM(GetErrorString, "ncclGetErrorString");
+#undef NABO_SYM
+        if (!ok) {
+            dlclose(h);
+            pthread_mutex_unlock(&g_rccl_lock);
+            return api_fail(NABO_E_UNSUPPORTED, "librccl.so lacks a required entry point");
+        }
+        g_rccl.h = h;
+    }
+    pthread_mutex_unlock(&g_rccl_lock);
+    return NABO_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r__ = (expr);                                                                      \
+        if (r__ != ncclSuccess) return api_fail(NABO_E_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r__)); \
+    } while (0)
+
+// ---- loopback rendezvous ---------------------------------------------------------------------------------
+struct LoopHub {
+    int n = 0;
+    int refs = 0;
+    pthread_barrier_t bar;
+    pthread_mutex_t lock = PTHREAD_MUTEX_INITIALIZER;
+    std::vector<const void *> ptr;
+    std::vector<int64_t> vals;
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return NABO_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return api_fail(NABO_E_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e)); }
+        cap = want;
+        return NABO_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace
+
+struct nabo_comm {
+    int kind = 0;                    // 0 RCCL, 1 loopback
+    int device = 0, rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;
+    LoopHub *hub = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    DevBuf ci, cd, cb, ri, rd, rb, mi, md, oi, od, fulli, fulld, cnt, bad, ids, allids, sel, xb, bi, bd, gi, gd, fi, fd, scratch;
+    double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t counters[4] = {0, 0, 0, 0};
+    int group_depth = 0;
+};
+
+namespace {
+
+// ---- collectives (device pointers, on c->stream) ----------------------------------------------------------
+int group_begin(nabo_comm *c)
+{
+    if (c->kind == 0 && c->group_depth++ == 0) RCCL_TRY(g_rccl.GroupStart());
+    return NABO_OK;
+}
+
+int group_end(nabo_comm *c)
+{
+    if (c->kind == 0 && --c->group_depth == 0) RCCL_TRY(g_rccl.GroupEnd());
+    return NABO_OK;
+}
+
+// block p of `send` (bytes each) goes to peer p; block p of `recv` comes from peer p
+int all_to_all(nabo_comm *c, const void *send, void *recv, size_t bytes)
+{
+    const int N = c->world;
+    if (bytes == 0) return NABO_OK;
+    if (c->kind == 0) {
+        int rc = group_begin(c);
+        if (rc) return rc;
+        for (int p = 0; p < N; ++p) {
+            RCCL_TRY(g_rccl.Send(static_cast<const char *>(send) + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, c->stream));
+            RCCL_TRY(g_rccl.Recv(static_cast<char *>(recv) + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, c->stream));
+        }
+        return group_end(c);
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));                 // my send buffer is final
+    c->hub->ptr[c->rank] = send;
+    pthread_barrier_wait(&c->hub->bar);
+    for (int p = 0; p < N; ++p)
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + (size_t)p * bytes,
+                               static_cast<const char *>(c->hub->ptr[p]) + (size_t)c->rank * bytes, bytes, hipMemcpyDefault,
+                               c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&c->hub->bar);                       // nobody reuses a send buffer before all have copied
+    return NABO_OK;
+}
+
+int all_gather(nabo_comm *c, const void *send, void *recv, size_t bytes)
+{
+    const int N = c->world;
+    if (bytes == 0) return NABO_OK;
+    if (c->kind == 0) {
+        RCCL_TRY(g_rccl.AllGather(send, recv, bytes, ncclUint8, c->nccl, c->stream));
+        return NABO_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hub->ptr[c->rank] = send;
+    pthread_barrier_wait(&c->hub->bar);
+    for (int p = 0; p < N; ++p)
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + (size_t)p * bytes, c->hub->ptr[p], bytes, hipMemcpyDefault, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    pthread_barrier_wait(&c->hub->bar);
+    return NABO_OK;
+}
+
+// MAX over ranks of ONE int64 living on the device (in place) -- returned on the host too
+int all_reduce_max(nabo_comm *c, int64_t *dev_val, int64_t *host_out)
+{
+    if (c->kind == 0) {
+        RCCL_TRY(g_rccl.AllReduce(dev_val, dev_val, 1, ncclInt64, ncclMax, c->nccl, c->stream));
+        HIP_TRY(hipMemcpyAsync(host_out, dev_val, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return NABO_OK;
+    }
+    int64_t mine = 0;
+    HIP_TRY(hipMemcpyAsync(&mine, dev_val, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hub->vals[c->rank] = mine;
+    pthread_barrier_wait(&c->hub->bar);
+    int64_t mx = c->hub->vals[0];
+    for (int p = 1; p < c->world; ++p) mx = std::max(mx, c->hub->vals[p]);
+    pthread_barrier_wait(&c->hub->bar);
+    *host_out = mx;
+    return NABO_OK;
+}
+
+// ---- small kernels of the protocol ------------------------------------------------------------------------
+// owner's certificate: row r of my slice is final when its k'-th merged distance lies below every shard's bound
+__global__ void certify_kernel(const int64_t *__restrict__ mi, const double *__restrict__ md, int kk,
+                               const double *__restrict__ bounds /*[N][mr]*/, int N, int64_t mr, int64_t row0, int64_t m,
+                               int64_t *__restrict__ bad_rows, unsigned long long *__restrict__ bad_count)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= mr || row0 + r >= m) return;                     // padding rows are nobody's
+    double b = bounds[r];
+    for (int s = 1; s < N; ++s) b = fmin(b, bounds[(int64_t)s * mr + r]);
+    const double dk = md[r * kk + kk - 1];
+    const bool ok = mi[r * kk + kk - 1] >= 0 && dk * dk * (1.0 + 1e-12) < b;
+    if (!ok) bad_rows[atomicAdd(bad_count, 1ull)] = row0 + r;
+}
+
+// columns [d0, d0+k) of the merged [mr, kk] rows (the positional drop comes AFTER the merge)
+__global__ void slice_kernel(const int64_t *__restrict__ mi, const double *__restrict__ md, int64_t mr, int kk, int d0,
+                             int k, int64_t *__restrict__ oi, double *__restrict__ od)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= mr * k) return;
+    const int64_t r = e / k;
+    const int c = (int)(e - r * k);
+    oi[e] = mi[r * kk + d0 + c];
+    od[e] = md[r * kk + d0 + c];
+}
+
+// second round: rows of `sel` that I own replace my merged rows
+__global__ void adopt_kernel(const uint32_t *__restrict__ sel, int64_t nb, const int64_t *__restrict__ fi,
+                             const double *__restrict__ fd, int kk, int64_t row0, int64_t mr, int64_t *__restrict__ mi,
+                             double *__restrict__ md)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nb * kk) return;
+    const int64_t b = e / kk;
+    const int64_t row = (int64_t)sel[b] - row0;
+    if (row < 0 || row >= mr) return;
+    mi[row * kk + (e - b * kk)] = fi[e];
+    md[row * kk + (e - b * kk)] = fd[e];
+}
+
+__global__ void fill_absent_kernel(int64_t *__restrict__ idx, double *__restrict__ dist, int64_t n_idx, double *__restrict__ bnd, int64_t n_bnd)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_idx) { idx[e] = -1; dist[e] = __builtin_inf(); }
+    if (bnd && e < n_bnd) bnd[e] = __builtin_inf();
+}
+
+int use_dev(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return NABO_OK;
+}
+
+int comm_alloc(nabo_comm **out, int kind, int device, int rank, int world)
+{
+    nabo_comm *c = new (std::nothrow) nabo_comm();
+    if (!c) return api_fail(NABO_E_NOMEM, "host allocation failed");
+    c->kind = kind; c->device = device; c->rank = rank; c->world = world;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
+    if (e != hipSuccess) {
+        delete c;
+        return api_fail(NABO_E_HIP, "communicator stream/event creation failed: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return NABO_OK;
+}
+
+float ev_ms(nabo_comm *c, int a, int b)
+{
+    float t = 0;
+    (void)hipEventElapsedTime(&t, c->ev[a], c->ev[b]);
+    return t;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t nabo_candidates_per_shard(int32_t kk, int32_t world, int64_t m)
+{
+    // smallest list length that leaves an expected < 0.1 rows of the batch for the second round:
+    // world * m * P[Bin(kk, 1/world) >= Ls] < 0.1 (exchangeable shards); never more than kk+1, at least ceil(kk/world)
+    if (kk < 1 || world < 1) return 0;
+    const int cap = std::min(kk + 1, 32);
+    const double p = 1.0 / world;
+    double tail = 0.0;
+    int ls = cap;
+    for (int j = kk; j >= 1; --j) {
+        double cb = 1.0;                       // C(kk, j)
+        for (int i = 1; i <= j; ++i) cb = cb * (double)(kk - j + i) / (double)i;
+        tail += cb * std::pow(p, j) * std::pow(1.0 - p, kk - j);
+        if (tail * world * (double)(m > 0 ? m : 1) >= 0.1) { ls = j + 1; break; }
+        ls = j;
+    }
+    ls = std::min(ls, cap);
+    ls = std::max(ls, (kk + world - 1) / world);
+    return std::max(ls, 1);
+}
+
+int nabo_comm_unique_id(void *id128)
+{
+    if (!id128) return api_fail(NABO_E_INVALID, "NULL argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    ncclUniqueId id;
+    RCCL_TRY(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == NABO_COMM_ID_BYTES, "unique id size");
+    memcpy(id128, &id, sizeof(id));
+    return NABO_OK;
+}
+
+int nabo_comm_create(nabo_comm **out, int32_t device, int32_t rank, int32_t world, const void *id128)
+{
+    if (!out || !id128) return api_fail(NABO_E_INVALID, "NULL argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return api_fail(NABO_E_INVALID, "rank %d of %d", rank, world);
+    int rc = load_rccl();
+    if (rc) return rc;
+    nabo_comm *c = nullptr;
+    if ((rc = comm_alloc(&c, 0, device, rank, world))) return rc;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) {
+        nabo_comm_destroy(c);
+        return api_fail(NABO_E_HIP, "ncclCommInitRank(rank %d of %d, device %d) failed: %s", rank, world, device, g_rccl.GetErrorString(r));
+    }
+    *out = c;
+    return NABO_OK;
+}
+
+int nabo_comm_create_all(nabo_comm **out, const int32_t *devices, int32_t n)
+{
+    if (!out || !devices || n < 1) return api_fail(NABO_E_INVALID, "bad argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    std::vector<ncclComm_t> comms((size_t)n);
+    std::vector<int> devs(devices, devices + n);
+    RCCL_TRY(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    for (int i = 0; i < n; ++i) {
+        nabo_comm *c = nullptr;
+        if ((rc = comm_alloc(&c, 0, devices[i], i, n))) {
+            for (int j = 0; j < n; ++j) {
+                if (out[j]) { out[j]->nccl = nullptr; nabo_comm_destroy(out[j]); out[j] = nullptr; }
+                (void)g_rccl.CommDestroy(comms[(size_t)j]);
+            }
+            return rc;
+        }
+        c->nccl = comms[(size_t)i];
+        out[i] = c;
+    }
+    return NABO_OK;
+}
+
+int nabo_comm_create_loopback(nabo_comm **out, const int32_t *devices, int32_t n)
+{
+    if (!out || !devices || n < 1) return api_fail(NABO_E_INVALID, "bad argument");
+    LoopHub *hub = new (std::nothrow) LoopHub();
+    if (!hub) return api_fail(NABO_E_NOMEM, "host allocation failed");
+    hub->n = n;
+    hub->refs = n;
+    hub->ptr.assign((size_t)n, nullptr);
+    hub->vals.assign((size_t)n, 0);
+    pthread_barrier_init(&hub->bar, nullptr, (unsigned)n);
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    for (int i = 0; i < n; ++i) {
+        nabo_comm *c = nullptr;
+        int rc = comm_alloc(&c, 1, devices[i], i, n);
+        if (rc) {
+            for (int j = 0; j < i; ++j) { out[j]->hub = nullptr; nabo_comm_destroy(out[j]); out[j] = nullptr; }
+            pthread_barrier_destroy(&hub->bar);
+            delete hub;
+            return rc;
+        }
+        c->hub = hub;
+        out[i] = c;
+    }
+    return NABO_OK;
+}
+
+int nabo_comm_destroy(nabo_comm *c)
+{
+    if (!c) return NABO_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->nccl);
+    if (c->hub) {
+        pthread_mutex_lock(&c->hub->lock);
+        const int left = --c->hub->refs;
+        pthread_mutex_unlock(&c->hub->lock);
+        if (left == 0) { pthread_barrier_destroy(&c->hub->bar); delete c->hub; }
+    }
+    DevBuf *bufs[] = {&c->ci, &c->cd, &c->cb, &c->ri, &c->rd, &c->rb, &c->mi, &c->md, &c->oi, &c->od, &c->fulli, &c->fulld, &c->cnt,
+                      &c->bad, &c->ids, &c->allids, &c->sel, &c->xb, &c->bi, &c->bd, &c->gi, &c->gd, &c->fi, &c->fd, &c->scratch};
+    for (DevBuf *b : bufs) b->release();
+    for (int i = 0; i < 8; ++i)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return NABO_OK;
+}
+
+int nabo_comm_rank(const nabo_comm *c) { return c ? c->rank : -1; }
+int nabo_comm_world(const nabo_comm *c) { return c ? c->world : -1; }
+
+int nabo_comm_allreduce_max_f64(nabo_comm *c, double *value)
+{
+    if (!c || !value) return api_fail(NABO_E_INVALID, "NULL argument");
+    int rc = use_dev(c->device);
+    if (rc) return rc;
+    if (c->world == 1) return NABO_OK;
+    if ((rc = c->scratch.reserve(64))) return rc;
+    if (c->kind == 0) {
+        HIP_TRY(hipMemcpyAsync(c->scratch.p, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        RCCL_TRY(g_rccl.AllReduce(c->scratch.p, c->scratch.p, 1, ncclFloat64, ncclMax, c->nccl, c->stream));
+        HIP_TRY(hipMemcpyAsync(value, c->scratch.p, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return NABO_OK;
+    }
+    int64_t bits;
+    memcpy(&bits, value, sizeof(bits));        // callers pass non-negative times: IEEE order == integer order
+    c->hub->vals[c->rank] = bits;
+    pthread_barrier_wait(&c->hub->bar);
+    int64_t mx = c->hub->vals[0];
+    for (int p = 1; p < c->world; ++p) mx = std::max(mx, c->hub->vals[p]);
+    pthread_barrier_wait(&c->hub->bar);
+    memcpy(value, &mx, sizeof(mx));
+    return NABO_OK;
+}
+
+int nabo_comm_barrier(nabo_comm *c)
+{
+    double z = 0.0;
+    return nabo_comm_allreduce_max_f64(c, &z);
+}
+
+int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
+                       int64_t *out_idx, double *out_dist, int32_t protocol)
+{
+    if (!c || !ix || !X || !out_idx || !out_dist) return api_fail(NABO_E_INVALID, "NULL argument");
+    if (m < 1 || k < 1) return api_fail(NABO_E_INVALID, "bad shape m=%lld k=%d", (long long)m, k);
+    if (nabo::index_device(ix) != c->device) return api_fail(NABO_E_INVALID, "index and communicator live on different devices");
+    int rc = use_dev(c->device);
+    if (rc) return rc;
+    const int N = c->world, g = nabo::index_g(ix);
+    const int d0 = drop_first ? 1 : 0, kk = k + d0;
+    const int64_t mr = (m + N - 1) / N, m_pad = mr * N, row0 = (int64_t)c->rank * mr;
+    hipStream_t st = c->stream;
+    // protocol: 0 auto, 1 global certification, 2 local certification
+    const bool can_cand = nabo::index_can_emit_candidates(ix) && (kk + N - 1) / N <= 32;
+    if (protocol == 1 && !can_cand) return api_fail(NABO_E_UNSUPPORTED, "global certification needs the Euclidean / cosine filter and k'/N <= 32");
+    const bool global = protocol == 1 || (protocol == 0 && can_cand && N > 1);
+    if ((int64_t)N * (global ? 32 : kk) > 1024 && !global) return api_fail(NABO_E_UNSUPPORTED, "N * (k + drop_first) = %d exceeds the merge width 1024", N * kk);
+    for (double &v : c->ms) v = 0.0;
+    c->counters[0] = c->counters[1] = c->counters[2] = 0;
+    c->counters[3] = global ? 1 : 2;
+    HIP_TRY(hipEventRecord(c->ev[0], st));
+    if ((rc = c->mi.reserve((size_t)mr * kk * 8)) || (rc = c->md.reserve((size_t)mr * kk * 8))) return rc;
+    const unsigned blk = 256;
+
+    if (global) {
+        const int Ls = nabo_candidates_per_shard(kk, N, m);
+        c->counters[1] = Ls;
+        const size_t li = (size_t)m_pad * Ls * 8, lb = (size_t)m_pad * 8;
+        if ((rc = c->ci.reserve(li)) || (rc = c->cd.reserve(li)) || (rc = c->cb.reserve(lb)) || (rc = c->ri.reserve(li)) ||
+            (rc = c->rd.reserve(li)) || (rc = c->rb.reserve(lb)))
+            return rc;
+        if (m_pad != m) {          // ragged tail: absent entries, +inf bounds
+            const int64_t nx = (m_pad - m) * Ls;
+            hipLaunchKernelGGL(fill_absent_kernel, dim3((unsigned)((nx + blk - 1) / blk)), dim3(blk), 0, st,
+                               c->ci.as<int64_t>() + m * Ls, c->cd.as<double>() + m * Ls, nx, c->cb.as<double>() + m, m_pad - m);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if ((rc = nabo_index_query_candidates(ix, X, 1, m, Ls, c->ci.as<int64_t>(), c->cd.as<double>(), c->cb.as<double>())))
+            return rc;
+        (void)hipSetDevice(c->device);
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        if ((rc = group_begin(c))) return rc;
+        if ((rc = all_to_all(c, c->ci.p, c->ri.p, (size_t)mr * Ls * 8))) return rc;
+        if ((rc = all_to_all(c, c->cd.p, c->rd.p, (size_t)mr * Ls * 8))) return rc;
+        if ((rc = all_to_all(c, c->cb.p, c->rb.p, (size_t)mr * 8))) return rc;
+        if ((rc = group_end(c))) return rc;
+        HIP_TRY(hipEventRecord(c->ev[2], st));
+        HIP_TRY(nabo::merge_parts_launch(c->rd.as<double>(), c->ri.as<int64_t>(), N, mr, Ls, kk, 0, c->mi.as<int64_t>(),
+                                         c->md.as<double>(), st));
+        if ((rc = c->cnt.reserve(64)) || (rc = c->bad.reserve((size_t)mr * 8))) return rc;
+        HIP_TRY(hipMemsetAsync(c->cnt.p, 0, 16, st));
+        hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((mr + blk - 1) / blk)), dim3(blk), 0, st, c->mi.as<int64_t>(),
+                           c->md.as<double>(), kk, c->rb.as<double>(), N, mr, row0, m, c->bad.as<int64_t>(),
+                           c->cnt.as<unsigned long long>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        // my count stays in cnt[0]; the MAX over ranks goes through cnt[1]
+        HIP_TRY(hipMemcpyAsync(c->cnt.as<int64_t>() + 1, c->cnt.p, 8, hipMemcpyDeviceToDevice, st));
+        int64_t nb_max = 0;
+        if ((rc = all_reduce_max(c, c->cnt.as<int64_t>() + 1, &nb_max))) return rc;
+        if (nb_max > 0) {
+            int64_t mine = 0;
+            HIP_TRY(hipMemcpyAsync(&mine, c->cnt.p, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<int64_t> ids((size_t)nb_max, -1);
+            if (mine > 0) {
+                HIP_TRY(hipMemcpyAsync(ids.data(), c->bad.p, (size_t)mine * 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                std::sort(ids.begin(), ids.begin() + mine);           // the atomics' order is not reproducible
+            }
+            if ((rc = c->ids.reserve((size_t)nb_max * 8)) || (rc = c->allids.reserve((size_t)N * nb_max * 8))) return rc;
+            HIP_TRY(hipMemcpyAsync(c->ids.p, ids.data(), (size_t)nb_max * 8, hipMemcpyHostToDevice, st));
+            if ((rc = all_gather(c, c->ids.p, c->allids.p, (size_t)nb_max * 8))) return rc;
+            std::vector<int64_t> all((size_t)N * nb_max);
+            HIP_TRY(hipMemcpyAsync(all.data(), c->allids.p, all.size() * 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::vector<uint32_t> sel;                                 // rank-major, identical on every rank
+            for (int64_t v : all)
+                if (v >= 0) sel.push_back((uint32_t)v);
+            const int64_t nb = (int64_t)sel.size();
+            c->counters[0] = nb;
+            if ((rc = c->sel.reserve((size_t)nb * 4)) || (rc = c->xb.reserve((size_t)nb * g * 8)) ||
+                (rc = c->bi.reserve((size_t)nb * kk * 8)) || (rc = c->bd.reserve((size_t)nb * kk * 8)) ||
+                (rc = c->gi.reserve((size_t)N * nb * kk * 8)) || (rc = c->gd.reserve((size_t)N * nb * kk * 8)) ||
+                (rc = c->fi.reserve((size_t)nb * kk * 8)) || (rc = c->fd.reserve((size_t)nb * kk * 8)))
+                return rc;
+            HIP_TRY(hipMemcpyAsync(c->sel.p, sel.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(nabo::gather_rows_launch(X, c->sel.as<uint32_t>(), nb, g, c->xb.as<double>(), st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if ((rc = nabo_index_query(ix, c->xb.as<double>(), 1, nb, kk, 0, c->bi.as<int64_t>(), c->bd.as<double>(), 1))) {
+                // fewer references in this shard than k': every one of them is a candidate already -- absent entries
+                return rc;
+            }
+            (void)hipSetDevice(c->device);
+            if ((rc = group_begin(c))) return rc;
+            if ((rc = all_gather(c, c->bi.p, c->gi.p, (size_t)nb * kk * 8))) return rc;
+            if ((rc = all_gather(c, c->bd.p, c->gd.p, (size_t)nb * kk * 8))) return rc;
+            if ((rc = group_end(c))) return rc;
+            HIP_TRY(nabo::merge_parts_launch(c->gd.as<double>(), c->gi.as<int64_t>(), N, nb, kk, kk, 0, c->fi.as<int64_t>(),
+                                             c->fd.as<double>(), st));
+            hipLaunchKernelGGL(adopt_kernel, dim3((unsigned)((nb * kk + blk - 1) / blk)), dim3(blk), 0, st, c->sel.as<uint32_t>(), nb,
+                               c->fi.as<int64_t>(), c->fd.as<double>(), kk, row0, mr, c->mi.as<int64_t>(), c->md.as<double>());
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(c->ev[4], st));
+    } else {
+        // local certification: every shard's own first k' order-row entries
+        const size_t li = (size_t)m_pad * kk * 8;
+        if ((rc = c->ci.reserve(li)) || (rc = c->cd.reserve(li)) || (rc = c->ri.reserve(li)) || (rc = c->rd.reserve(li))) return rc;
+        if (m_pad != m) {
+            const int64_t nx = (m_pad - m) * kk;
+            hipLaunchKernelGGL(fill_absent_kernel, dim3((unsigned)((nx + blk - 1) / blk)), dim3(blk), 0, st,
+                               c->ci.as<int64_t>() + m * kk, c->cd.as<double>() + m * kk, nx, (double *)nullptr, (int64_t)0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if ((rc = nabo_index_query(ix, X, 1, m, kk, 0, c->ci.as<int64_t>(), c->cd.as<double>(), 1))) return rc;
+        (void)hipSetDevice(c->device);
+        HIP_TRY(hipEventRecord(c->ev[1], st));
+        if (N > 1) {
+            if ((rc = group_begin(c))) return rc;
+            if ((rc = all_to_all(c, c->ci.p, c->ri.p, (size_t)mr * kk * 8))) return rc;
+            if ((rc = all_to_all(c, c->cd.p, c->rd.p, (size_t)mr * kk * 8))) return rc;
+            if ((rc = group_end(c))) return rc;
+        }
+        HIP_TRY(hipEventRecord(c->ev[2], st));
+        HIP_TRY(nabo::merge_parts_launch(N > 1 ? c->rd.as<double>() : c->cd.as<double>(), N > 1 ? c->ri.as<int64_t>() : c->ci.as<int64_t>(),
+                                         N, mr, kk, kk, 0, c->mi.as<int64_t>(), c->md.as<double>(), st));
+        HIP_TRY(hipEventRecord(c->ev[3], st));
+        HIP_TRY(hipEventRecord(c->ev[4], st));
+    }
+    // positional drop after the merge, then every rank gets every owner's slice
+    if ((rc = c->oi.reserve((size_t)mr * k * 8)) || (rc = c->od.reserve((size_t)mr * k * 8))) return rc;
+    hipLaunchKernelGGL(slice_kernel, dim3((unsigned)((mr * k + blk - 1) / blk)), dim3(blk), 0, st, c->mi.as<int64_t>(),
+                       c->md.as<double>(), mr, kk, d0, k, c->oi.as<int64_t>(), c->od.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev[5], st));
+    int64_t *fi = out_idx;
+    double *fd = out_dist;
+    if (m_pad != m) {
+        if ((rc = c->fulli.reserve((size_t)m_pad * k * 8)) || (rc = c->fulld.reserve((size_t)m_pad * k * 8))) return rc;
+        fi = c->fulli.as<int64_t>();
+        fd = c->fulld.as<double>();
+    }
+    if (N > 1) {
+        if ((rc = group_begin(c))) return rc;
+        if ((rc = all_gather(c, c->oi.p, fi, (size_t)mr * k * 8))) return rc;
+        if ((rc = all_gather(c, c->od.p, fd, (size_t)mr * k * 8))) return rc;
+        if ((rc = group_end(c))) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(fi, c->oi.p, (size_t)mr * k * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(fd, c->od.p, (size_t)mr * k * 8, hipMemcpyDeviceToDevice, st));
+    }
+    if (m_pad != m) {
+        HIP_TRY(hipMemcpyAsync(out_idx, fi, (size_t)m * k * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(out_dist, fd, (size_t)m * k * 8, hipMemcpyDeviceToDevice, st));
+    }
+    HIP_TRY(hipEventRecord(c->ev[6], st));
+    HIP_TRY(hipStreamSynchronize(st));
+    // ms: [0] local query, [1] exchange, [2] merge + certificate, [3] second round, [4] slice, [5] gather, [6] total
+    for (int i = 0; i < 6; ++i) c->ms[i] = ev_ms(c, i, i + 1);
+    c->ms[6] = ev_ms(c, 0, 6);
+    return NABO_OK;
+}
+
+int nabo_sharded_last_stats(const nabo_comm *c, double ms[8], int64_t counters[4])
+{
+    if (!c) return api_fail(NABO_E_INVALID, "NULL communicator");
+    if (ms) memcpy(ms, c->ms, sizeof(c->ms));
+    if (counters) memcpy(counters, c->counters, sizeof(c->counters));
+    return NABO_OK;
+}
+
+}  // extern "C"

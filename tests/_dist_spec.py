@@ -1,37 +1,28 @@
-"""Reference-row sharding across the GPUs of one node.
+"""The sharded protocol's EXECUTABLE SPECIFICATION over torch.distributed -- TEST HARNESS ONLY.
 
-One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  Rank r holds
-reference rows [base_r, base_r + n_r) resident in its HBM; every rank sees all target rows.
-    1. local k-NN on the shard -> first k' = k + drop_first entries per target, GLOBAL indices,
-       exact float64 distances (nabo_index_query with ref_index_base = base_r);
-    2. ONE exchange: all_to_all of the [m, k'] lists so that rank r owns target rows
-       [r*m/N, (r+1)*m/N) from every shard (each GPU receives N*k' candidates for m/N rows --
-       1/N of the bytes an all-gather of full lists would move over each xGMI link);
-    3. k-way merge by the canonical (distance, index) order on the GPU (nabo_merge_topk),
-       positional drop applied AFTER the merge (nabo/_mapping.py:142 is positional);
+The product's multi-GPU path is nabo_sharded_query in libnabo_knn.so (nabo_amd/csrc/sharded.hip: RCCL through the C
+ABI, no torch; nabo_amd/_sharded.py binds it).  This file states the same protocol in a few lines of torch with the
+two compute steps injected, so that its plumbing -- shard bounds, global index bases, the exchange layout, ragged
+target counts, the owner's certificate, the second round, the positional drop after the merge, the final gather --
+can be run with world_size 2 and 3 on the gloo backend without a GPU (tests/test_dist_gloo.py), and so that the GPU
+tests have an independent statement to compare the C implementation with.
+
+Protocol (rank r holds reference rows [base_r, base_r + n_r); every rank sees all target rows):
+    1. local k-NN on the shard -> first k' = k + drop_first entries per target, GLOBAL indices, exact float64
+       distances;
+    2. ONE exchange: all_to_all of the [m, k'] lists so that rank r owns target rows [r*m/N, (r+1)*m/N) from every
+       shard;
+    3. k-way merge by the canonical (distance, index) order, positional drop applied AFTER the merge
+       (nabo/_mapping.py:142 is positional);
     4. all_gather of the merged [m/N, k] slices -> every rank holds the full result.
-The merge is deterministic, so N shards == 1 shard bit for bit.
-
-GLOBAL certification (default when the shard can emit candidates, `local_cand`): asking every shard
-for its exact local top-k' wastes most of the work -- on average only k'/N of a shard's neighbours
-survive the merge, yet each shard maintains a k'+8 deep list for every target and re-evaluates it in
-float64.  Instead each shard emits its first Ls < k' order-row entries (exact distances) plus a BOUND
-on the squared distance of everything it did not emit (nabo_index_query_candidates); the owner of a
-target row merges the N*Ls entries and accepts the k'-th merged distance d when d^2 < min over shards
-of the bound -- then no unreported reference anywhere can enter or tie.  Rows that fail (a shard held
-more than Ls of the global top-k': Ls is chosen so that < 0.1 rows of a batch are expected to) are re-solved
-exactly in a second, tiny round with the certified local query.  Same bits, ~half the list maintenance per shard.
-
-torch is used for the process group, the collectives and (on GPU) tensor memory only; the
-compute goes through the C ABI with raw pointers.  The two compute steps are injectable so
-the exchange/merge plumbing can be exercised with the gloo backend on CPU (tests/).
+GLOBAL certification: each shard emits its first Ls < k' order-row entries plus a BOUND on the squared distance of
+everything it did not emit; the owner of a target row merges the N*Ls entries and accepts the k'-th merged distance d
+when d^2 < min over shards of the bound; rows that fail are re-solved exactly in a second, small round.
 """
 import numpy as np
 
 
-def shard_bounds(n, world, rank):
-    """Contiguous, balanced reference-row partition: rows [lo, hi) for `rank`."""
-    return (n * rank) // world, (n * (rank + 1)) // world
+from nabo_amd._sharded import shard_bounds, candidates_per_shard as _candidates_per_shard  # noqa: E402,F401
 
 
 def merge_numpy(parts_idx, parts_dist, k, drop_first):
@@ -96,29 +87,7 @@ class ShardedKnn:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
 
-    @staticmethod
-    def candidates_per_shard(kk, world, m=None):
-        """Entries each shard emits.  A row needs the second round when some shard holds at least Ls of its global
-        top-k'; for exchangeable shards that is world * P[Bin(k', 1/world) >= Ls] per row.  With `m` (target rows)
-        given, Ls is the smallest length that leaves an expected < 0.1 such rows in the whole batch -- never more
-        than k'+1 (a shard cannot hold more than k' of the top k') -- because a longer list costs ~0.7 ms per
-        entry and step while the second round costs ~3.5 ms plus three more collectives.  Without `m`: the share
-        k'/N with 50 % head room, +6."""
-        cap = min(kk + 1, 32)
-        if m is None:
-            ls = max(8, -(-3 * kk // (2 * world)) + 6, -(-kk // world))
-            return min(ls, kk + 8, 32)
-        from math import comb
-        p = 1.0 / world
-        tail = 0.0
-        ls = cap
-        for j in range(kk, 0, -1):                       # tail = P[Bin(kk, p) >= j]
-            tail += comb(kk, j) * p ** j * (1.0 - p) ** (kk - j)
-            if tail * world * m >= 0.1:
-                ls = j + 1
-                break
-            ls = j
-        return max(min(ls, cap), -(-kk // world), 1)
+    candidates_per_shard = staticmethod(_candidates_per_shard)
 
     def query(self, X, m, k, drop_first=False):
         import torch
@@ -217,7 +186,7 @@ class ShardedKnn:
 def gpu_callables(index, device_index):
     """local_knn / merge bound to a nabo_amd.KnnIndex and nabo_merge_topk (torch CUDA tensors)."""
     import torch
-    from . import _knn
+    from nabo_amd import _knn
     dev = torch.device("cuda", device_index)
 
     def local_knn(X, kk):

@@ -175,6 +175,18 @@ def run_case(tag):
             m3.make_ref_graph()
         _, edges3, _ = read_graph_like_reference(map2, "WT", "reference")
         out["columnar_same_graph"] = edges3 == edges
+        # reference rows sharded over "devices" (here 3 shard-ranks on the one GPU, loopback transport): same graphs
+        map5 = os.path.join(td, "mapping_sharded.h5")
+        with redirect_stdout(buf):
+            m6 = nabo_amd.Mapping(map5, "WT", ref_fn, "data", overwrite=True, devices=[0, 0, 0], shard_transport="loopback")
+            m6.set_parameters(uc, k, f, chunk)
+            m6.make_ref_graph()
+            tn0_, names0_, data0_, ign0_ = targets[0]
+            m6.map_target(tn0_, os.path.join(td, "t_%s.h5" % tn0_), "data", ignore_ref_cells=ign0_)
+        _, edges6, _ = read_graph_like_reference(map5, "WT", "reference")
+        _, tedges6, _ = read_graph_like_reference(map5, tn0_, "target")
+        _, tedges0, _ = read_graph_like_reference(map_fn, tn0_, "target")
+        out["sharded_devices_same_graphs"] = (edges6 == edges) and (tedges6 == tedges0)
         # dense [N, n_comps] input (rows deliberately NOT in name order) gives the same graph
         ref_dense = os.path.join(td, "ref_dense.h5")
         perm = np.random.default_rng(3).permutation(len(rn))

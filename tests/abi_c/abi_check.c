@@ -17,9 +17,13 @@ int main(int argc, char **argv)
     const void *syms[] = {(void *)nabo_version, (void *)nabo_last_error, (void *)nabo_device_count, (void *)nabo_knn,
                           (void *)nabo_pairwise, (void *)nabo_index_create, (void *)nabo_index_destroy,
                           (void *)nabo_index_set_ref, (void *)nabo_index_set_mask, (void *)nabo_index_query,
-                          (void *)nabo_index_query_candidates, (void *)nabo_index_last_stats, (void *)nabo_merge_topk,
+                          (void *)nabo_index_query_candidates, (void *)nabo_index_last_stats, (void *)nabo_index_last_kernel, (void *)nabo_merge_topk,
                           (void *)nabo_snn_counts, (void *)nabo_score_null, (void *)nabo_score_null_edges, (void *)nabo_dev_malloc, (void *)nabo_dev_free,
-                          (void *)nabo_memcpy_h2d, (void *)nabo_memcpy_d2h, (void *)nabo_dev_synchronize};
+                          (void *)nabo_memcpy_h2d, (void *)nabo_memcpy_d2h, (void *)nabo_dev_synchronize,
+                          (void *)nabo_comm_unique_id, (void *)nabo_comm_create, (void *)nabo_comm_create_all,
+                          (void *)nabo_comm_create_loopback, (void *)nabo_comm_destroy, (void *)nabo_comm_rank,
+                          (void *)nabo_comm_world, (void *)nabo_comm_barrier, (void *)nabo_comm_allreduce_max_f64,
+                          (void *)nabo_candidates_per_shard, (void *)nabo_sharded_query, (void *)nabo_sharded_last_stats};
     printf("%s: %d entry points\n", nabo_version(), (int)(sizeof(syms) / sizeof(syms[0])));
     if (argc < 2 || strcmp(argv[1], "run") != 0) return 0;
     if (nabo_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }
@@ -56,6 +60,29 @@ int main(int argc, char **argv)
     }
     /* error convention: bad argument -> NABO_E_INVALID and a message */
     if (nabo_knn(X, M, Y, N, G, N + 1, NABO_METRIC_EUCLIDEAN, 0.0, NULL, 0, gi, gd, 0) != NABO_E_INVALID || !*nabo_last_error()) return 7;
-    printf("C ABI ok: pairwise %dx%dx%d and k-NN (k=%d) bit-equal to the C restatement\n", M, N, G, K);
+    /* the sharded entry point with n_devices = 1: nabo_comm_create_all (RCCL, ncclCommInitAll) -> resident index ->
+     * nabo_sharded_query under both protocols -> the same [M,K] result as nabo_knn above */
+    {
+        nabo_comm *comm = NULL;
+        nabo_index *ix = NULL;
+        const int32_t devs[1] = {0};
+        void *dX = NULL, *dI = NULL, *dD = NULL;
+        static int64_t si[M * K];
+        static double sd[M * K];
+        if (nabo_comm_create_all(&comm, devs, 1) != NABO_OK) { fprintf(stderr, "%s\n", nabo_last_error()); return 8; }
+        if (nabo_comm_world(comm) != 1 || nabo_comm_rank(comm) != 0 || nabo_comm_barrier(comm) != NABO_OK) return 9;
+        if (nabo_index_create(&ix, 0, N, G, NABO_METRIC_EUCLIDEAN, 0.0, 0) != NABO_OK || nabo_index_set_ref(ix, Y, 0, NULL) != NABO_OK) { fprintf(stderr, "%s\n", nabo_last_error()); return 10; }
+        if (nabo_dev_malloc(0, &dX, sizeof(X)) || nabo_dev_malloc(0, &dI, sizeof(si)) || nabo_dev_malloc(0, &dD, sizeof(sd)) ||
+            nabo_memcpy_h2d(0, dX, X, sizeof(X))) return 11;
+        for (int protocol = 1; protocol <= 2; ++protocol) {
+            if (nabo_sharded_query(comm, ix, (const double *)dX, M, K, 0, (int64_t *)dI, (double *)dD, protocol) != NABO_OK) { fprintf(stderr, "%s\n", nabo_last_error()); return 12; }
+            if (nabo_memcpy_d2h(0, si, dI, sizeof(si)) || nabo_memcpy_d2h(0, sd, dD, sizeof(sd))) return 13;
+            if (memcmp(si, gi, sizeof(si)) != 0 || memcmp(sd, gd, sizeof(sd)) != 0) { fprintf(stderr, "sharded query (protocol %d) differs from nabo_knn\n", protocol); return 14; }
+        }
+        nabo_dev_free(0, dX); nabo_dev_free(0, dI); nabo_dev_free(0, dD);
+        nabo_index_destroy(ix);
+        nabo_comm_destroy(comm);
+    }
+    printf("C ABI ok: pairwise %dx%dx%d, k-NN (k=%d) and the sharded query (1 device, both protocols) bit-equal to the C restatement\n", M, N, G, K);
     return 0;
 }

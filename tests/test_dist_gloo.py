@@ -1,6 +1,6 @@
 """World-size-2 (and 3) runs of the reference-row-sharded k-NN over the gloo backend on CPU.
 The two compute steps are injected (oracle for the per-shard k-NN, merge_numpy for the merge), so
-what is exercised is exactly the product's N>1 plumbing in nabo_amd/_dist.py: shard bounds, global
+what is exercised is exactly the product's N>1 plumbing in tests/_dist_spec.py (the executable specification of nabo_sharded_query): shard bounds, global
 index bases, the all_to_all exchange layout, ragged target counts, the positional drop after the
 merge, and the final all_gather -- and that N shards == 1 shard bit for bit."""
 import os
@@ -28,7 +28,7 @@ def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir, certified=Fals
     import torch
     import torch.distributed as dist
     import oracle
-    from nabo_amd._dist import ShardedKnn, merge_numpy, shard_bounds
+    from _dist_spec import ShardedKnn, merge_numpy, shard_bounds
     from nabo_amd._synth import pca_like
     dist.init_process_group("gloo", rank=rank, world_size=world)
     Y = pca_like(n, g, seed=11)
@@ -95,7 +95,7 @@ def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric, certified
 
 
 def test_shard_bounds_cover_everything():
-    from nabo_amd._dist import shard_bounds
+    from nabo_amd._sharded import shard_bounds
     for n in (1, 7, 1000, 1000003):
         for w in (1, 2, 3, 8):
             b = [shard_bounds(n, w, r) for r in range(w)]
@@ -106,7 +106,7 @@ def test_shard_bounds_cover_everything():
 
 
 def test_merge_numpy_matches_oracle_order():
-    from nabo_amd._dist import merge_numpy
+    from _dist_spec import merge_numpy
     rng = np.random.default_rng(0)
     pi = np.stack([np.arange(0, 6)[None].repeat(4, 0), np.arange(6, 12)[None].repeat(4, 0)])
     pd = np.sort(rng.integers(0, 4, size=(2, 4, 6)).astype(np.float64), axis=2)      # many exact ties
@@ -114,21 +114,3 @@ def test_merge_numpy_matches_oracle_order():
     for r in range(4):
         allp = sorted(zip(np.concatenate([pd[0, r], pd[1, r]]), np.concatenate([pi[0, r], pi[1, r]])))
         assert [x[1] for x in allp[1:6]] == list(i[r]) and [x[0] for x in allp[1:6]] == list(d[r])
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--metric", "cosine", "--dims", "30", "--neighbors", "40"]])
-def test_bench_sharded_path_two_ranks_on_one_gpu(extra):
-    """bench.py's N>1 code (shard bounds, KnnIndex per shard with a global index base, exchange, GPU merge,
-    gather) rehearsed with 2 ranks sharing ONE GPU: collectives staged through gloo (RCCL cannot put two
-    ranks on one device).  Each rank checks its result bit-for-bit against an unsharded index."""
-    import subprocess
-    env = dict(os.environ, NABO_BENCH_BACKEND="gloo", NABO_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"),
-           "--gpus", "2", "--steps", "1", "--warmup", "1", "--targets", "20001", "--refs", "50000"] + extra
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True,
-                       timeout=600, cwd=REPO)
-    assert r.returncode == 0, r.stdout[-3000:]
-    assert r.stdout.count("sharded == unsharded: True") == 2, r.stdout[-3000:]
-    assert '"n_gpus": 2' in r.stdout

@@ -170,7 +170,7 @@ def test_reference_splits_do_not_change_results(gpu_lib):
 def test_resident_index_shard_base_and_merge(gpu_lib):
     """Reference rows sharded 3 ways on ONE device, merged with nabo_merge_topk == unsharded."""
     from nabo_amd import _knn
-    from nabo_amd._dist import shard_bounds
+    from nabo_amd._sharded import shard_bounds
     Y = pca_like(10001, 30, seed=41)
     X = pca_like(777, 30, seed=42)
     k, kk = 11, 12
@@ -374,36 +374,48 @@ def test_zero_target_rows_is_a_no_op(gpu_lib):
 @pytest.mark.parametrize("m,n,g,k,drop", [(257, 4097, 50, 15, False), (1000, 1000, 15, 11, True),
                                           (2000, 30000, 30, 20, True), (130, 5000, 64, 30, False),
                                           (64, 3000, 100, 11, False)])
-def test_f16x3_mode_gives_the_same_bits(gpu_lib, m, n, g, k, drop):
-    """Experimental NABO_L2_MODE=f16x3 (f16 split on the matrix pipe as the candidate filter): the
-    float64 refine + certification make it return exactly what the fp32-MFMA path and the oracle do.
-    Shapes outside its instantiation (g > 64 or k + drop > 24) silently use the fp32 kernel."""
+def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
+    """The Euclidean filter runs on the f16 matrix pipe (f16x3 split, the default where it is instantiated:
+    g < 64 and k + drop + 4 <= 32) or on the fp32 MFMA (everything else, or NABO_L2_MODE=f32): the float64 refine +
+    certification make both return exactly what the oracle does."""
     Y = pca_like(n, g, seed=1000 + n + g)
     X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
-    os.environ["NABO_L2_MODE"] = "f16x3"
+    oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
+    kernels = {}
+    for mode in ("f16x3", "f32", None):
+        if mode:
+            os.environ["NABO_L2_MODE"] = mode
+        try:
+            ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+            gi, gd = ix.query(X, k, drop_first=drop)
+            st = ix.last_stats()
+            kernels[mode] = ix.last_kernel()
+            ix.close()
+        finally:
+            os.environ.pop("NABO_L2_MODE", None)
+        _check(gi, gd, oi, od)
+        assert st["fallback_rows"] == 0
+    assert "l2_topk_kernel" in kernels["f32"]
+    assert kernels[None] == kernels["f16x3"]                       # f16x3 is the default
+    assert ("l2h_topk_kernel" in kernels["f16x3"]) == (g < 64 and k + drop + 4 <= 32)
+
+
+@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3", 274)])
+def test_tail_round_split_rows_are_exact(gpu_lib, mode, full_round):
+    """More target workgroups than resident slots: the last, partially filled round is launched with its
+    own reference split (api.hip "tail round").  Rows of BOTH launches must match the oracle."""
+    m, n = 140000, 20000     # fp32 kernel: 547 workgroups of 256 rows on 512 slots; f16x3: 274 of 512 rows on 256 slots
+    Y = pca_like(n, 50, seed=71)
+    X = pca_like(m, 50, seed=72)
+    os.environ["NABO_L2_MODE"] = mode
     try:
-        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
-        gi, gd = ix.query(X, k, drop_first=drop)
+        ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, 15)
         st = ix.last_stats()
         ix.close()
     finally:
         del os.environ["NABO_L2_MODE"]
-    oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
-    _check(gi, gd, oi, od)
-    assert st["fallback_rows"] == 0
-
-
-def test_tail_round_split_rows_are_exact(gpu_lib):
-    """More target workgroups than resident slots: the last, partially filled round is launched with its
-    own reference split (api.hip "tail round").  Rows of BOTH launches must match the oracle."""
-    m, n = 140000, 20000               # 547 workgroups of 256 rows on 512 slots -> 35-workgroup tail
-    Y = pca_like(n, 50, seed=71)
-    X = pca_like(m, 50, seed=72)
-    ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
-    gi, gd = ix.query(X, 15)
-    st = ix.last_stats()
-    ix.close()
-    assert st["workgroups"] > 547            # the tail really was split
+    assert st["workgroups"] > full_round     # the tail really was split
     rows = np.concatenate([np.arange(0, 300), np.arange(131072 - 150, 131072 + 150), np.arange(m - 300, m)])
     oi, od = oracle.knn(X[rows], Y, 15, 0, nthreads=8)
     _check(gi[rows], gd[rows], oi, od)
@@ -697,3 +709,77 @@ def test_canberra_plateau_with_window_edge_candidates(gpu_lib):
     oi, od = oracle.knn(X, Y, k, 1, 0.25)
     assert (od[0] == 2.0).all() and list(oi[0]) == list(range(15))
     _check(gi, gd, oi, od)
+
+
+@pytest.mark.parametrize("metric,m,n,g,k,drop", [(0, 150, 3000, 30, 100, True), (0, 120, 2500, 200, 15, False),
+                                                  (1, 100, 2000, 20, 100, False), (2, 90, 2000, 200, 60, True),
+                                                  (1, 60, 1500, 200, 11, False), (0, 70, 900, 129, 57, True)])
+def test_no_cliff_beyond_the_filter_kernels_limits(gpu_lib, metric, m, n, g, k, drop):
+    """The reference accepts any k and use_comps (nabo/_mapping.py:495-524).  Past the instantiated filter kernels
+    (k + drop_first > 56, g > 128) every row is answered by the exact float64 kernels: same results as the oracle."""
+    Y = pca_like(n, g, seed=3000 + n + g)
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=4000 + m + g)
+    ix = gpu_lib.KnnIndex(n, g, metric=metric, dist_factor=0.25).set_ref(Y)
+    gi, gd = ix.query(X, k, drop_first=drop)
+    st = ix.last_stats()
+    ix.close()
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, drop_first=drop, nthreads=8)
+    _check(gi, gd, oi, od)
+    if k + drop > 56 or (g > 128 and metric != 1):
+        assert st["fallback_rows"] == m
+
+
+def test_no_cliff_masked_tail_longer_than_any_list(gpu_lib):
+    """k larger than the un-ignored references: the order row continues with ALL ignored references by ascending
+    index (numpy.ma's NaN-fill, nabo/_mapping.py:135-144) -- also past the 56 entries the filter path can emit."""
+    Y = pca_like(150, 12, seed=81)
+    X = pca_like(40, 12, seed=82)
+    mask = np.zeros(150, np.uint8)
+    mask[np.random.default_rng(2).choice(150, 70, replace=False)] = 1
+    for metric in (0, 1):
+        gi, gd = gpu_lib.knn(X, Y, 140, metric=metric, ref_mask=mask)
+        oi, od = oracle.knn(X, Y, 140, metric, ref_mask=mask)
+        _check(gi, gd, oi, od)
+        assert np.array_equal(gi[:, 80:], np.tile(np.nonzero(mask)[0][:60], (40, 1)))
+
+
+@pytest.mark.parametrize("splits", ["1", "3"])
+def test_partly_overflowing_targets_never_reach_the_filter_as_nan(gpu_lib, splits):
+    """The fp32 score kernel is compiled with -fno-honor-nans, so NaN must not occur in it: targets whose scaled
+    components leave the safe range (here only SOME components of SOME rows) are zeroed at pack time and carry a NaN
+    norm, which refine.hip can never certify -- the exact kernels answer those rows, the others stay on the fast
+    path; with reference splits (several lists per row) and in candidate (shard) mode the same holds."""
+    n, g, k = 4000, 24, 9
+    Y = pca_like(n, g, seed=91)
+    X = pca_like(300, g, seed=92)
+    big = np.array([3, 64, 65, 127, 128, 255, 299])
+    X[big[:3], 5] *= 1e42                    # one component
+    X[big[3:5], ::2] *= -1e45                # every other component, negative
+    X[big[5:], :] *= 1e60                    # the whole row
+    os.environ["NABO_SPLITS"] = splits
+    try:
+        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, k)
+        st = ix.last_stats()
+        # shard mode: the bound of such a row must be -inf (unknown), never a number
+        dx = _knn_buf(gpu_lib, X)
+        di, dd, db = (_knn_mod().DeviceBuffer(300 * 12 * 8), _knn_mod().DeviceBuffer(300 * 12 * 8),
+                      _knn_mod().DeviceBuffer(300 * 8))
+        ix.query_candidates_device(dx.ptr, 300, 12, di.ptr, dd.ptr, db.ptr)
+        cb = db.download((300,), np.float64)
+        ix.close()
+    finally:
+        del os.environ["NABO_SPLITS"]
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    _check(gi, gd, oi, od)
+    assert st["fallback_rows"] == big.size
+    assert np.isneginf(cb[big]).all() and np.isfinite(np.delete(cb, big)).all()
+
+
+def _knn_mod():
+    from nabo_amd import _knn
+    return _knn
+
+
+def _knn_buf(gpu_lib, arr):
+    return _knn_mod().DeviceBuffer(arr.nbytes).upload(arr)

@@ -1,0 +1,175 @@
+"""Reference rows sharded over GPUs behind the C ABI (nabo_comm_*, nabo_sharded_query; no torch).
+
+CPU side: the list-length rule (C vs Python), the unique-id hand-off between ranks, and that the product never imports
+torch.  GPU side (one MI355X): the whole protocol with N = 2, 3, 8 shard-ranks on one GPU through the loopback
+transport (same call sequence, buffers and kernels as the RCCL transport), the RCCL transport itself with one rank
+(dlopen, unique id, communicator, grouped send/recv, all-gather, all-reduce), bench.py's N>1 code path, and the
+launcher hand-off under torch.distributed.run.  RCCL with N > 1 ranks needs N GPUs: the driver's scaling run."""
+import itertools
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from nabo_amd import _lib, _sharded
+from nabo_amd._synth import pca_like
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_list_length_rule_c_equals_python():
+    L = _lib.lib()
+    for kk, w, m in itertools.product([1, 2, 5, 11, 15, 16, 24, 31, 51, 56], [1, 2, 3, 4, 8, 16], [1, 1000, 1000000, 5000000]):
+        assert _sharded.candidates_per_shard(kk, w, m) == L.nabo_candidates_per_shard(kk, w, m), (kk, w, m)
+    # the values DESIGN.md section 5 quotes (k' = 15, 1M rows)
+    assert [_sharded.candidates_per_shard(15, n, 1000000) for n in (8, 4, 2)] == [12, 15, 16]
+    assert _sharded.candidates_per_shard(50, 8, 5000000) == 24
+
+
+def test_unique_id_reaches_every_rank_through_a_file(tmp_path):
+    world = 5
+    path = str(tmp_path / "id")
+    want = bytes(range(128))
+    got = [None] * world
+
+    def run(r):
+        got[r] = _sharded.exchange_unique_id(r, world, lambda: want, path=path, timeout=20)[0]
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world - 1, -1, -1)]      # readers first
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == [want] * world
+    with pytest.raises(_lib.NaboError):
+        _sharded.exchange_unique_id(1, 2, None, path=str(tmp_path / "never"), timeout=0.05)
+
+
+def test_product_and_bench_never_import_torch():
+    """torch is the LAUNCHER (python -m torch.distributed.run) and the gloo test harness (tests/_dist_spec.py), not the
+    product: nothing under nabo_amd/, nor bench.py, nor the driver entry points may import it."""
+    files = [os.path.join(REPO, "bench.py"), os.path.join(REPO, "__graft_entry__.py")]
+    for root, _, fs in os.walk(os.path.join(REPO, "nabo_amd")):
+        files += [os.path.join(root, f) for f in fs if f.endswith(".py")]
+    for f in files:
+        for ln in open(f).read().splitlines():
+            code = ln.split("#")[0]
+            assert "import torch" not in code and "from torch" not in code, (f, ln)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+CASES = [
+    # N, m, n, g, k, drop, metric, protocol, sorted refs
+    (2, 1001, 6000, 20, 11, False, 0, "auto", False),
+    (3, 500, 4001, 30, 15, True, 0, "auto", False),           # ragged rows and shards, positional drop after the merge
+    (8, 4000, 40000, 50, 15, False, 0, "auto", False),
+    (8, 3000, 40000, 50, 15, False, 0, "global", True),       # neighbours in ONE shard: the second round must repair
+    (4, 700, 5000, 25, 23, True, 2, "auto", False),           # cosine (extension)
+    (2, 300, 3000, 16, 9, False, 1, "auto", False),           # modified Canberra: local certification only
+    (3, 257, 2000, 12, 40, False, 0, "local", False),         # k' beyond the candidate lists of a shard
+    (2, 64, 900, 8, 5, True, 0, "global", False),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,m,n,g,k,drop,metric,protocol,sorted_refs", CASES)
+def test_sharded_query_on_one_gpu_equals_unsharded_and_oracle(gpu_lib, N, m, n, g, k, drop, metric, protocol, sorted_refs):
+    Y = pca_like(n, g, seed=400 + n)
+    if sorted_refs:
+        Y = np.ascontiguousarray(Y[np.argsort(Y[:, 0], kind="stable")])
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=500 + m)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, metric, Y, protocol=protocol).set_ref()
+    gi, gd = grp.query(X, k, drop_first=drop)
+    st = [grp.last_stats(r) for r in range(N)]
+    grp.close()
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, drop_first=drop, nthreads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    want = "local" if (metric == 1 or protocol == "local") else "global"
+    assert all(s["protocol"] == want for s in st)
+    if sorted_refs:
+        assert st[0]["uncertified"] > 0                          # the second round really ran
+    assert len({s["uncertified"] for s in st}) == 1              # every rank saw the same second round
+
+
+@pytest.mark.gpu
+def test_every_rank_ends_with_the_same_full_result(gpu_lib):
+    from nabo_amd import _knn
+    N, m, n, g, k = 4, 1234, 9000, 24, 10
+    Y, X = pca_like(n, g, seed=61), pca_like(m, g, seed=62)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, 0, Y).set_ref()
+    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
+    outs = [(_knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)) for _ in range(N)]
+    grp.query_device(dx.ptr, m, k, False, [a.ptr for a, _ in outs], [b.ptr for _, b in outs])
+    res = [(a.download((m, k), np.int64), b.download((m, k), np.float64)) for a, b in outs]
+    grp.close()
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    for ri, rd in res:
+        assert np.array_equal(ri, oi) and np.array_equal(rd, od)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("protocol", ["global", "local"])
+def test_rccl_transport_with_one_rank(gpu_lib, protocol):
+    """librccl.so through the C ABI: unique id, ncclCommInitRank, the grouped send/recv exchange (to self), all-reduce,
+    all-gather -- every RCCL call of the protocol, with the only world size one GPU allows."""
+    import ctypes as C
+    from nabo_amd import _knn
+    L = _lib.lib()
+    buf = C.create_string_buffer(128)
+    _lib.check(L.nabo_comm_unique_id(buf))
+    h = C.c_void_p()
+    _lib.check(L.nabo_comm_create(C.byref(h), 0, 0, 1, buf))
+    comm = _sharded.Comm(h, 0, 0, 1)
+    assert comm.allreduce_max(3.25) == 3.25
+    comm.barrier()
+    m, n, g, k = 999, 8000, 20, 12
+    Y, X = pca_like(n, g, seed=71), pca_like(m, g, seed=72)
+    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    sk = _sharded.ShardedIndex(comm, ix, protocol)
+    dx, di, dd = _knn.DeviceBuffer(X.nbytes).upload(X), _knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)
+    sk.query_device(dx.ptr, m, k, True, di.ptr, dd.ptr)
+    st = sk.last_stats()
+    gi, gd = di.download((m, k), np.int64), dd.download((m, k), np.float64)
+    ix.close()
+    comm.close()
+    oi, od = oracle.knn(X, Y, k, 0, drop_first=True, nthreads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert st["protocol"] == protocol
+
+
+@pytest.mark.gpu
+def test_bench_sharded_code_path_with_loopback_ranks():
+    """bench.py's N>1 step (per-shard index with a global index base, nabo_sharded_query, stats in the line) with 4
+    shard-ranks on ONE GPU; the result is compared with an unsharded index inside bench.py (NABO_BENCH_CHECK)."""
+    env = dict(os.environ, NABO_BENCH_LOOPBACK="4", NABO_BENCH_CHECK="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--targets", "20001",
+           "--refs", "50000", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "sharded == unsharded: True" in r.stdout and '"candidates_per_shard"' in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_under_the_launcher_creates_its_communicator_without_torch():
+    """The driver's launch line (python -m torch.distributed.run ... bench.py --gpus N) with the one rank a single
+    GPU allows: RANK / WORLD_SIZE / LOCAL_RANK from the launcher, the unique id through the file, ncclCommInitRank,
+    nabo_sharded_query under global certification, barrier and max-over-ranks through nabo_comm_*."""
+    env = dict(os.environ, NABO_BENCH_FORCE_COMM="1", NABO_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--targets", "20001", "--refs", "50000", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "sharded == unsharded: True" in r.stdout and '"sharded"' in r.stdout, r.stdout[-3000:]

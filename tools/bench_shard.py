@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, ".")
 from nabo_amd import _knn, _lib
 from nabo_amd._synth import pca_like
-from nabo_amd._dist import ShardedKnn, shard_bounds
+from nabo_amd._sharded import shard_bounds, candidates_per_shard
 candidates_per_shard = ShardedKnn.candidates_per_shard
 
 m, n, g, k = (int(a) for a in (sys.argv[1:5] or (1000000, 1000000, 50, 15)))

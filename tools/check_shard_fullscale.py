@@ -10,7 +10,7 @@ import numpy as np  # noqa: E402
 
 import nabo_amd  # noqa: E402
 from nabo_amd import _knn  # noqa: E402
-from nabo_amd._dist import ShardedKnn, shard_bounds  # noqa: E402
+from nabo_amd._sharded import shard_bounds, candidates_per_shard  # noqa: E402
 from nabo_amd._synth import pca_like  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -20,7 +20,7 @@ X = pca_like(m, d, seed=2003)
 ix = nabo_amd.KnnIndex(n, d, metric=0).set_ref(Y)
 ri, rd = ix.query(X, k)
 ix.close()
-Ls = ShardedKnn.candidates_per_shard(k, N, m)
+Ls = candidates_per_shard(k, N, m)
 dx = _knn.DeviceBuffer(X.nbytes).upload(X)
 pi = np.empty((N, m, Ls), dtype=np.int64)
 pd = np.empty((N, m, Ls), dtype=np.float64)

@@ -14,7 +14,7 @@ import numpy as np  # noqa: E402
 
 import nabo_amd  # noqa: E402
 from nabo_amd import _knn  # noqa: E402
-from nabo_amd._dist import ShardedKnn, shard_bounds  # noqa: E402
+from nabo_amd._sharded import shard_bounds, candidates_per_shard  # noqa: E402
 from nabo_amd._synth import pca_like  # noqa: E402
 
 a = [int(v) for v in sys.argv[1:]]
@@ -24,7 +24,7 @@ t0 = time.perf_counter()
 Y = pca_like(n, d, seed=1004)
 X = pca_like(m, d, seed=2004)
 print("synthetic PCA embeddings: %.0f s" % (time.perf_counter() - t0), flush=True)
-Ls = ShardedKnn.candidates_per_shard(k, N, m)
+Ls = candidates_per_shard(k, N, m)
 out = {"config": {"workload": "%d ref x %d target, d=%d, k=%d, cosine, rank 0 of %d" % (n, m, d, k, N)},
        "candidates_per_shard": Ls}
 

@@ -12,7 +12,7 @@ import nabo_amd  # noqa: E402
 import oracle  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 from nabo_amd import _knn  # noqa: E402
-from nabo_amd._dist import ShardedKnn, merge_numpy, shard_bounds  # noqa: E402
+from _dist_spec import ShardedKnn, merge_numpy, shard_bounds  # noqa: E402
 from nabo_amd._synth import pca_like  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
@@ -72,7 +72,7 @@ for case in range(n_cases):
             mask = (rng.random(n) < rng.choice([0.1, 0.6])).astype(np.uint8)
             if int((mask == 0).sum()) < kk:
                 mask = None
-        Ls = ShardedKnn.candidates_per_shard(kk, N, m)
+        Ls = candidates_per_shard(kk, N, m)
         dx = _knn.DeviceBuffer(X.nbytes).upload(X)
         pi, pd, pb = [], [], []
         for r in range(N):
