@@ -43,7 +43,7 @@ def _time_knn(oracle, X, Y, k, metric, threads, budget_s):
     t0 = time.perf_counter()
     oracle.knn(X, Y, k, metric, 0.25, nthreads=threads)
     dt = time.perf_counter() - t0
-    reps = int(max(1, min(64, budget_s / max(dt, 1e-3))))
+    reps = int(max(1, min(256, budget_s / max(dt, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
         oracle.knn(X, Y, k, metric, 0.25, nthreads=threads)

@@ -366,7 +366,13 @@ class Mapping:
     def set_parameters(self, use_comps, k, dist_factor, chunk_size):
         """use_comps: leading input dimensions to use; k: neighbours; dist_factor: window of the
         modified Canberra distance (> 0); chunk_size: kept for API compatibility -- the GPU
-        path streams tiles from HBM and does not need a host-side chunk size."""
+        path streams tiles from HBM and does not need a host-side chunk size.
+
+        Storage note: calc_dist keeps the first k entries of every order row (and their distances), not the
+        reference's full rows (nabo/_mapping.py:102-103,145 -- 16 TB at 1M x 1M).  `use_stored_distances=True`
+        therefore works for the k the distances were computed with or a smaller one; after RAISING k call
+        make_ref_graph() / map_target(..., overwrite=True) without use_stored_distances to recompute (calc_snn
+        raises a ValueError that says so when the stored lists are too short)."""
         self._useComps = use_comps
         self._k = k
         try:

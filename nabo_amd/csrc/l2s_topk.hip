@@ -1,0 +1,314 @@
+// l2s_topk.hip -- Euclidean score + top-L filter on the f16 matrix pipe, reference tiles SHARED per workgroup
+// through an LDS ring (gfx950).  Same contract as l2_topk.hip / l2h_topk.hip: per target row the L references with
+// the smallest score  s = ||y||^2 - 2 x.y  and the threshold below which nothing was dropped; refine.hip
+// re-evaluates the candidates in the reference's float64 arithmetic (nabo/_mapping.py:16-26) and certifies the row
+// with the error bound of the split, so the results are the same bits as every other path.
+//
+// What is different from l2h_topk.hip (per-wave streaming, one wave per SIMD):
+//   * K-CONCATENATED f16x3 split.  v = hi + lo (two f16, 22 significant bits).  Instead of three separate products
+//     per 16-component slab (12 MFMAs at g = 50), reference cells are packed as ONE vector [hi | lo | hi] of
+//     3 (g+1) slots and targets as [hi | hi | lo] (x -2), so  <ref, tgt> = hi.hi + lo.hi + hi.lo  in
+//     KC = ceil(3 (g+1) / 16) steps of v_mfma_f32_32x32x16_f16: 10 MFMAs at g = 50.  Slot g of every segment carries
+//     the norm term (||y~||^2 2^-15 as hi + lo against the constant 2^15), so a chain starts from C = 0.
+//   * ONE copy of each reference tile per CU.  A workgroup is 8 waves (two per SIMD); every wave owns R = 2 row-blocks
+//     (64 target rows, B operands resident in VGPRs).  Reference tiles (KC KiB) arrive by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR staging) into a 3-deep ring: per tile the CU fetches KC KiB instead of
+//     4 waves x 8 KiB, and L2 / fabric traffic drops accordingly.  One barrier per tile: tile t+3's DMA is issued,
+//     the wave runs its two chains on tile t (A operands in registers) while reading tile t+1's A operands from the
+//     ring into a second register set, waits for ITS OWN pieces of tile t+2 with a counted s_waitcnt vmcnt, barrier.
+//   * Two waves per SIMD: the f16 matrix pipe overlaps with another wave's vector / LDS work, so one wave's filter,
+//     hit path (topk_lists.h) and waits are covered by its partner's MFMAs.
+//   * Candidate lists: 32 entries per row (kept k'+8, the rest pending), wave-private, 128 KiB; ring 3 x KC KiB.
+#include <cstdlib>
+
+#include <hip/hip_fp16.h>
+
+#include "knn_common.h"
+#include "topk_lists.h"
+
+namespace nabo {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int L2S_WAVES = 8;        // waves per workgroup (two per SIMD)
+constexpr int L2S_R = 2;            // row-blocks per wave
+constexpr int L2S_NBUF = 3;         // ring depth (tiles)
+
+__host__ __device__ constexpr int l2s_row_entries(int kc) { return kc <= 10 ? 32 : 30; }   // list entries per row: LDS budget
+
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + lane * 16 (cdna_hip_programming.md,
+// "What hipcc does not do": M0 written in the statement that reads it; hipcc does not count this load).
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int KC>
+__device__ __forceinline__ f32x16 cchain(const f16x8 (&a)[KC], const f16x8 (&b)[KC])
+{
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < KC; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+
+// Grid: x = target super-blocks (8 waves x 2 tiles of 32 rows = 512 rows), y = reference splits.
+template <int KC, int EPL, int ROWN>
+__global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *__restrict__ Xpk,
+                                                          const unsigned char *__restrict__ Ypk, int tiles_per_split,
+                                                          int64_t tile_off, int lkeep, uint32_t *__restrict__ cand_idx,
+                                                          float *__restrict__ cand_key, float *__restrict__ cand_tau,
+                                                          int dbg)
+{
+    constexpr int R = L2S_R, NW = L2S_WAVES, NBUF = L2S_NBUF;
+    constexpr int ROW = ListCfg<EPL, ROWN>::ROW;
+    constexpr int TB = KC * 1024;                      // bytes per packed tile (targets and references alike)
+    constexpr int PPW = (KC + NW - 1) / NW;            // LDS-DMA pieces every wave issues per tile (uniform: counted waits)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint2 *lists = reinterpret_cast<uint2 *>(smem_raw + NBUF * TB);
+
+    const int lane = lane_id();
+    const int hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int split = blockIdx.y;
+    const int S = gridDim.y;
+    const int64_t ltile0 = ((int64_t)blockIdx.x * NW + wave) * R;
+    const int64_t ttile0 = tile_off + ltile0;
+
+    // resident target fragments
+    f16x8 xb[R][KC];
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(Xpk + (ttile0 + rb) * TB);
+#pragma unroll
+        for (int s = 0; s < KC; ++s) xb[rb][s] = p[s * 64 + lane];
+    }
+    RowState st[R];
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb) {
+        st[rb].tau = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
+        st[rb].pc = 0;
+        st[rb].kc = 0;
+    }
+    uint2 *wbuf = lists + (size_t)wave * R * 32 * ROW;
+
+    const int t_begin = split * tiles_per_split;
+    const int t_end = t_begin + tiles_per_split;
+    const uint32_t ring = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)smem_raw);
+
+    // this wave's PPW pieces of tile t -> ring buffer `buf`; a piece index past KC repeats one of the wave's own
+    // (same bytes to the same place), so every wave issues the same number of loads per tile
+    auto dma = [&](int t, int buf) {
+        int tc = t < t_end ? t : t_end - 1;
+        if (dbg & 2) tc = t_begin + ((tc - t_begin) & 127);         // timing experiments: L2-resident window (garbage results)
+        const unsigned char *src = Ypk + (int64_t)tc * TB + lane * 16;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            int p = wave + NW * i;
+            if (p >= KC) p = (KC >= NW) ? p - NW : wave % KC;
+            glds16(src + p * 1024, ring + (uint32_t)(buf * TB + p * 1024));
+        }
+    };
+    auto read_tile = [&](f16x8(&a)[KC], int buf) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(smem_raw + buf * TB);
+#pragma unroll
+        for (int s = 0; s < KC; ++s) a[s] = p[s * 64 + lane];
+    };
+
+    // The target fragments must have ARRIVED before the loop: hipcc waits for a load at its first use, which would be
+    // inside the loop -- a counted vmcnt in front of every MFMA, every iteration, draining the LDS-DMA it cannot see.
+    // Passing each register through an empty asm makes "first use" happen here.
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb)
+#pragma unroll
+        for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(xb[rb][s]));
+    // prologue: tiles t_begin, +1, +2 in flight; A0 <- tile t_begin; tile t_begin+1 published
+    dma(t_begin, 0);
+    dma(t_begin + 1, 1);
+    dma(t_begin + 2, 2);
+    wait_vmcnt<2 * PPW>();
+    __syncthreads();
+    f16x8 a0[KC], a1[KC];
+    read_tile(a0, 0);
+    wait_vmcnt<PPW>();
+    __syncthreads();                                              // (lgkmcnt(0) inside: every wave has copied tile t_begin)
+
+    f32x16 accP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accP[r] = __builtin_inff();       // inf < tau is false: nothing pending
+
+    // one step: tile t is in `cur`; tile t+1 is published in ring buffer b1; tile t+2 is landing; buffer b0 is free
+    int b0 = 0;                                                    // ring buffer of tile t
+    auto step = [&](f16x8(&cur)[KC], f16x8(&nxt)[KC], int t) {
+        const int b1 = b0 == NBUF - 1 ? 0 : b0 + 1;
+        dma(t + 3, b0);
+        read_tile(nxt, b1);
+        f32x16 accA = cchain<KC>(cur, xb[0]);
+        filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+        accP = cchain<KC>(cur, xb[1]);
+        filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)t * 32u + 4u * (uint32_t)hh, lkeep);
+        wait_vmcnt<PPW>();                                          // my pieces of tile t+2 have landed (t+3's may be in flight)
+        __syncthreads();                                            // tile t+2 published; every wave has copied tile t+1
+        b0 = b1;
+    };
+    for (int t = t_begin; t < t_end; t += 2) {
+        step(a0, a1, t);
+        if (t + 1 < t_end) step(a1, a0, t + 1);
+    }
+    filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // drain the look-ahead DMA before the epilogue's stores
+
+#pragma unroll
+    for (int rb = 0; rb < R; ++rb)
+        flush_block<EPL, ROWN>(st[rb], wbuf + rb * 32 * ROW, (ltile0 + rb) * 32, split, S, lkeep, cand_idx, cand_key, cand_tau);
+}
+
+// ---- packing ------------------------------------------------------------------------------
+// One wave per 32-cell tile; lane l supplies cell l & 31, slots 16 s + 8 (l >> 5) + j of the concatenated vector.
+// Slot p: segment p / (g+1), entry e = p % (g+1); e < g: component e, e == g: the norm slot.
+//   references  [hi | lo | hi],  norm slots (nh, nl, 0) with nh + nl = ||y~||^2 2^-15 (+inf when masked / padding)
+//   targets     [-2hi | -2hi | -2lo],  norm slots (2^15, 2^15, 0)
+// v = (V - centre) * scale; hi = f16(v), lo = f16(v - hi).  norm64 (targets): ||hi+lo||^2 in UNSCALED units.
+template <bool IS_REF>
+__global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restrict__ V, int64_t ncell, int g,
+                                                         const double *__restrict__ centre, double scale, int kc,
+                                                         int64_t ntiles_total, const uint8_t *__restrict__ mask,
+                                                         unsigned char *__restrict__ out, double *__restrict__ norm64,
+                                                         unsigned int *__restrict__ norm_max_bits)
+{
+    const int64_t tile = blockIdx.x;
+    if (tile >= ntiles_total) return;
+    const int lane = threadIdx.x;
+    const int c = lane & 31, hh = lane >> 5;
+    const int64_t cell = tile * 32 + c;
+    const bool live = cell < ncell;
+    const int g1 = g + 1;
+    unsigned char *o = out + tile * (int64_t)kc * 1024;
+    // whole-row pass: range check and ||rep||^2 (both lane halves of a cell compute the same)
+    bool bad = false;
+    double ss = 0.0;
+    for (int e = 0; e < g && live; ++e) {
+        const float f = (float)((V[cell * g + e] - centre[e]) * scale);
+        bad = bad || !(fabsf(f) <= 30000.0f);                 // f16 range (targets carry a factor 2); NaN / inf input
+        const _Float16 h = (_Float16)f;
+        const _Float16 l = (_Float16)(f - (float)h);
+        const double rep = (double)(float)h + (double)(float)l;
+        ss += rep * rep;
+    }
+    float nh = 0.0f, nl = 0.0f;
+    if (IS_REF) {
+        float nf = __builtin_inff();
+        if (live && !bad && !(mask && mask[cell])) {
+            nf = (float)ss * 3.0517578125e-05f;                // ||y~||^2 (scaled units) * 2^-15
+            if (hh == 0) atomicMax(norm_max_bits, __float_as_uint((float)ss));
+        }
+        const _Float16 h = (_Float16)nf;
+        nh = (float)h;
+        if (nf < __builtin_inff()) nl = (float)(_Float16)(nf - (float)h);
+    } else {
+        nh = nl = live ? 32768.0f : 0.0f;                      // segments 0 and 1; NOT scaled by -2: the product is +||y||^2
+        if (hh == 0 && live) norm64[cell] = bad ? __builtin_nan("") : ss / (scale * scale);
+    }
+    for (int s = 0; s < kc; ++s) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int p = 16 * s + 8 * hh + j;
+            const int seg = p / g1, e = p - seg * g1;
+            float val = 0.0f;
+            if (seg < 3) {
+                if (e == g) {
+                    val = seg == 0 ? nh : seg == 1 ? nl : 0.0f;
+                } else if (live && !bad) {
+                    const float f = (float)((V[cell * g + e] - centre[e]) * scale);
+                    const _Float16 h = (_Float16)f;
+                    const float lo = (float)(_Float16)(f - (float)h);
+                    const bool want_lo = IS_REF ? seg == 1 : seg == 2;
+                    val = want_lo ? lo : (float)h;
+                    if (!IS_REF) val *= -2.0f;
+                }
+            }
+            v[j] = (_Float16)val;
+        }
+        reinterpret_cast<f16x8 *>(o)[s * 64 + lane] = v;
+    }
+}
+
+hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
+                            int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
+                            hipStream_t st)
+{
+    hipLaunchKernelGGL((pack_ctiles_kernel<true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre, scale, kc,
+                       ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
+    return hipGetLastError();
+}
+
+hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
+                              int64_t ntiles_total, unsigned char *out, double *xnorm, hipStream_t st)
+{
+    hipLaunchKernelGGL((pack_ctiles_kernel<false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre, scale, kc,
+                       ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
+    return hipGetLastError();
+}
+
+template <int KC>
+static hipError_t slaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                              int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                              hipStream_t st)
+{
+    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    constexpr int ROWN = l2s_row_entries(KC);
+    constexpr size_t lds = (size_t)L2S_NBUF * KC * 1024 + (size_t)L2S_WAVES * L2S_R * 32 * ROWN * sizeof(uint2);
+    static_assert(lds <= 163840, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2s_topk_kernel<KC, 1, ROWN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid(gx, S), block(64 * L2S_WAVES);
+    hipLaunchKernelGGL((l2s_topk_kernel<KC, 1, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
+                       cand_idx, cand_key, cand_tau, dbg);
+    return hipGetLastError();
+}
+
+// steps of 16 slots for g components: 3 (g+1) slots, instantiated values only
+int l2s_pick_kc(int g)
+{
+    const int need = (3 * (g + 1) + 15) / 16;
+    const int inst[] = {2, 4, 6, 8, 10};          // 12 (g <= 63) does not fit 256 VGPRs with two A-operand sets
+    for (int v : inst)
+        if (need <= v) return v;
+    return -1;          // g >= 53: l2h_topk.hip (g < 64) or the fp32 kernel
+}
+
+void l2s_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
+{
+    *rows_per_wg = L2S_WAVES * L2S_R * 32;
+    *wg_per_cu = 1;
+    *lkeep_max = l2s_row_entries(kc) - 4;
+}
+
+hipError_t l2s_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
+{
+    switch (kc) {
+    case 2: return slaunch_one<2>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+    case 4: return slaunch_one<4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+    case 6: return slaunch_one<6>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+    case 8: return slaunch_one<8>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+    case 10: return slaunch_one<10>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace nabo

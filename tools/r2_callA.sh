@@ -1,6 +1,6 @@
 # round 2, GPU call A: the whole -m gpu suite, the default bench line, the counter list (run from the repo root on the GPU box)
 set -e
-O=$PWD/gpurun_out/r2a; rm -rf $O; mkdir -p $O
+O=$PWD/gpurun_out/${TAG:-r2a}_a; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 ( time timeout -k 10 850 python -m pytest tests -m gpu -q --durations=15 ) > $O/pytest.log 2>&1 || { tail -40 $O/pytest.log; exit 1; }
 tail -25 $O/pytest.log
