@@ -185,8 +185,14 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
+    rank_max = {}
     if comm is not None:
         dt = comm.allreduce_max(dt)            # MAX over ranks
+        # the slowest rank's phases (every rank enters these collectives; rank 0 prints): a first N>1 record must
+        # show where the time went without a second run
+        for key, src in (("ms_topk", stats), ("ms_total", stats), ("ms_local", xstats), ("ms_exchange", xstats),
+                         ("ms_merge", xstats), ("ms_second", xstats), ("ms_gather", xstats)):
+            rank_max[key] = comm.allreduce_max(float(np.mean([x[key] for x in src])))
 
     # light self-check outside the timed region: sorted rows, valid indices
     gi = gd = None
@@ -253,7 +259,8 @@ def main():
                                "local_query_ms": float(np.mean([x["ms_local"] for x in xstats])),
                                "candidates_per_shard": int(xstats[-1]["candidates"]),
                                "last_uncertified": int(max(x["uncertified"] for x in xstats)),
-                               "rank0_ms_topk": t_kernel * 1e3}
+                               "rank0_ms_topk": t_kernel * 1e3,
+                               "max_over_ranks_ms": rank_max or None}
         extras = comm is None and loop <= 1 and not a.no_extras and not os.environ.get("NABO_DEBUG_ABLATE")
         if extras and a.metric == "euclidean" and not os.environ.get("NABO_L2_MODE"):
             line["alt"] = alt_block(nabo_amd, _knn, index, kern, dev, n, m, d, k, dY, dX, gi, gd, sync)

@@ -378,7 +378,10 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
         if (!(md && strcmp(md, "f32") == 0) && ix->ksteps > 0 && nabo::l2h_pick_ks16(g) > 0) {
             ix->mode = 1;
             ix->ks16 = nabo::l2h_pick_ks16(g);
-            ix->kc = (md && strcmp(md, "f16x3h") == 0) ? 0 : nabo::l2s_pick_kc(g);     // f16x3h: the per-wave kernel (A/B)
+            // which f16x3 kernel: NABO_L2_MODE=f16x3s the shared-tile one (l2s_topk.hip), =f16x3h the per-wave one
+            // (l2h_topk.hip); unset / f16x3: whichever measured faster at 1M x 1M
+            const bool want_s = md ? strcmp(md, "f16x3s") == 0 : false;
+            ix->kc = want_s ? nabo::l2s_pick_kc(g) : 0;
             if (ix->kc < 0) ix->kc = 0;
         }
     }

@@ -101,13 +101,25 @@ __device__ __forceinline__ uint32_t cbf_f16_up(double v)          // smallest f1
     return b;
 }
 
-// per-dimension max |y| (bits of a non-negative float order like unsigned integers)
-__global__ void cbf_colmax_kernel(const double *__restrict__ Y, int64_t n, int g, unsigned int *__restrict__ colmax)
+// per-dimension max |y| (bits of a non-negative float order like unsigned integers).  A block reduces 256 rows in LDS
+// and issues one global atomic per column (one per ELEMENT took 37 ms at 1M x 50: 1 % of a mod-Canberra step).
+constexpr int CBF_COLMAX_ROWS = 256;
+__global__ __launch_bounds__(256) void cbf_colmax_kernel(const double *__restrict__ Y, int64_t n, int g,
+                                                         unsigned int *__restrict__ colmax)
 {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n * g) return;
-    const float v = fabsf((float)Y[e]);
-    if (v > 0.0f) atomicMax(&colmax[e % g], __float_as_uint(v < 3e38f ? v : 3e38f));
+    extern __shared__ unsigned int smax[];
+    for (int k = threadIdx.x; k < g; k += blockDim.x) smax[k] = 0u;
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * CBF_COLMAX_ROWS * g;
+    int64_t cnt = (n - (int64_t)blockIdx.x * CBF_COLMAX_ROWS) * g;
+    if (cnt > (int64_t)CBF_COLMAX_ROWS * g) cnt = (int64_t)CBF_COLMAX_ROWS * g;
+    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const float v = fabsf((float)Y[e0 + i]);
+        if (v > 0.0f) atomicMax(&smax[(e0 + i) % g], __float_as_uint(v < 3e38f ? v : 3e38f));
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < g; k += blockDim.x)
+        if (smax[k]) atomicMax(&colmax[k], smax[k]);
 }
 
 // refs: ych[chunk][p][64] = half2(y'_{2p}, y'_{2p+1}); targets: xh[row][p] = (half2 x', half2 thr')
@@ -332,15 +344,14 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
     int64_t c_end = c_begin + chunks_per_split;
     if (c_end > n_chunks) c_end = n_chunks;
     const cbf_h2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
-    const float gf = (float)g;
     for (int64_t chunk0 = c_begin; chunk0 < c_end; chunk0 += NCH) {
         cbf_h2 yv[NCH][GH];
-        bool valid[NCH];
+        uint64_t vmask[NCH];                                    // live (in range, not ignored) references of each chunk
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int64_t chunk = chunk0 + c;
             const int64_t j = chunk * 64 + lane;
-            valid[c] = (chunk < c_end) && (j < n) && !(mask && mask[j]);
+            vmask[c] = __builtin_amdgcn_ballot_w64((chunk < c_end) && (j < n) && !(mask && mask[j]));
 #pragma unroll
             for (int p = 0; p < GH; ++p)
                 yv[c][p] = __builtin_bit_cast(cbf_h2, (chunk < c_end) ? ych[(chunk * GH + p) * 64 + lane] : 0u);
@@ -367,26 +378,42 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_fdot2(ind[c], one2, acc[c], false);
             }
+            // Survivor test, ONE compare per chunk.  acc <= proven-out dimensions (fp32 sum of g terms in [0,1],
+            // rounding < 1e-3), so the pair's distance is >= acc - 1e-3; the list key of a pair is
+            //     pre = (acc == g) ? plateau : min(acc - 1e-3 - slack, below_plateau)
+            // and the pair can be dropped when pre >= tau.  `acc < t1` with t1 = tau + 1e-3 + slack (+2e-5 for the
+            // roundings of the subtraction chain, rounded up) keeps a SUPERSET of {pre < tau} (acc == g: pre < tau
+            // means tau > g - slack, so t1 > g; acc != g: either acc - 1e-3 - slack < tau, or tau > below_plateau and
+            // then t1 > g >= acc): a few pairs on the boundary survive needlessly, pass 2 evaluates their exact key
+            // and applies `key < tau` itself.  The per-chunk form (select, subtract, min, compare, and, ballot, branch)
+            // cost 27 % of this kernel's vector instructions (rocprofv3 SQ_INSTS_VALU, profiles/).
             const float tau_t = tau[t];
+            float t1 = tau_t + (1e-3f + 2e-5f + slack);
+            t1 = __uint_as_float(__float_as_uint(t1) + (t1 < __builtin_inff() ? 1u : 0u));       // next float up (tau_t > 0)
+            uint64_t sm[NCH];
+            uint64_t any = 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                // acc <= proven-out dimensions (fp32 sum of g terms in [0,1]: rounding < 1e-3).  acc == g exactly
-                // only when every dimension counted fully: then the distance is exactly g (plateau key).
-                const float pre = (acc[c] == gf) ? plateau : fminf(acc[c] - 1e-3f - slack, below_plateau);
-                const bool surv = valid[c] && (pre < tau_t) && !(dbg & 1);
-                const uint64_t bm = __builtin_amdgcn_ballot_w64(surv);
-                if (bm != 0) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                    if (surv) {
-                        const int slot = (wl_head + wl_n + rank) & (WLN - 1);
-                        wl[slot] = (uint32_t)((chunk0 + c) * 64 + lane);
-                        wl_t[slot] = (unsigned char)t;
-                    }
-                    wl_n += __popcll(bm);
-                }
+                sm[c] = __builtin_amdgcn_ballot_w64(acc[c] < t1) & vmask[c];
+                any |= sm[c];
             }
-            while (wl_n >= 64) drain(64);
+            if (any != 0 && !(dbg & 1)) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const uint64_t bm = sm[c];
+                    if (bm != 0) {
+                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        if ((bm >> lane) & 1ull) {
+                            const int slot = (wl_head + wl_n + rank) & (WLN - 1);
+                            wl[slot] = (uint32_t)((chunk0 + c) * 64 + lane);
+                            wl_t[slot] = (unsigned char)t;
+                        }
+                        wl_n += __popcll(bm);
+                    }
+                }
+                while (wl_n >= 64) drain(64);
+            }
         }
     }
     while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);
@@ -477,8 +504,8 @@ int cbf_rows_per_wg(int epl) { return epl == 1 ? cbf_t_rows(1) : cbf_t_rows(2); 
 
 hipError_t cbf_colmax_launch(const double *Y, int64_t n, int g, unsigned int *colmax, hipStream_t st)
 {
-    const int64_t tot = n * g;
-    hipLaunchKernelGGL(cbf_colmax_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Y, n, g, colmax);
+    const int64_t blocks = (n + CBF_COLMAX_ROWS - 1) / CBF_COLMAX_ROWS;
+    hipLaunchKernelGGL(cbf_colmax_kernel, dim3((unsigned)blocks), dim3(256), (size_t)g * sizeof(unsigned int), st, Y, n, g, colmax);
     return hipGetLastError();
 }
 

@@ -65,7 +65,16 @@ __device__ __forceinline__ f32x16 cchain(const f16x8 (&a)[KC], const f16x8 (&b)[
 }
 
 // Grid: x = target super-blocks (8 waves x 2 tiles of 32 rows = 512 rows), y = reference splits.
-template <int KC, int EPL, int ROWN>
+//
+// SYNC = 0: one workgroup barrier per tile.  SYNC = 1: no barriers -- two monotonic LDS counters per ring slot:
+//   full[s]  += 1 per wave once ITS pieces of the tile bound for slot s have landed (8 per fill),
+//   free[s]  += 1 per wave once it has copied the tile in slot s into its registers (8 per tile).
+// A wave in step u (tile u in registers) waits only for events of step u-1 of the other waves (everyone has copied
+// tile u out of its slot before tile u+3 is DMA'ed into it; everyone's pieces of tile u+1 have landed before it is
+// read), and it signals its own events at the START of the step, ahead of its filters: a wave that falls into the hit
+// path (topk_lists.h, hundreds of cycles) no longer stops the other seven at the next barrier -- they run up to a
+// step ahead.  No wait ever depends on an event of the same step, so the slowest wave can always proceed.
+template <int KC, int EPL, int ROWN, int SYNC>
 __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *__restrict__ Xpk,
                                                           const unsigned char *__restrict__ Ypk, int tiles_per_split,
                                                           int64_t tile_off, int lkeep, uint32_t *__restrict__ cand_idx,
@@ -78,6 +87,8 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
     constexpr int PPW = (KC + NW - 1) / NW;            // LDS-DMA pieces every wave issues per tile (uniform: counted waits)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint2 *lists = reinterpret_cast<uint2 *>(smem_raw + NBUF * TB);
+    uint32_t *sync_full = reinterpret_cast<uint32_t *>(lists + (size_t)NW * R * 32 * ROW);      // [NBUF], then free [NBUF]
+    uint32_t *sync_free = sync_full + NBUF;
 
     const int lane = lane_id();
     const int hh = lane >> 5;
@@ -87,6 +98,10 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
     const int64_t ltile0 = ((int64_t)blockIdx.x * NW + wave) * R;
     const int64_t ttile0 = tile_off + ltile0;
 
+    if (SYNC == 1) {
+        if (threadIdx.x < 2 * NBUF) sync_full[threadIdx.x] = 0;
+        __syncthreads();
+    }
     // resident target fragments
     f16x8 xb[R][KC];
 #pragma unroll
@@ -126,6 +141,15 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int s = 0; s < KC; ++s) a[s] = p[s * 64 + lane];
     };
+    // counter protocol (SYNC = 1): one lane adds; everybody polls the same word (an LDS broadcast)
+    auto signal = [&](uint32_t *ctr) {
+        if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto await = [&](uint32_t *ctr, uint32_t need) {
+        while ((uint32_t)__builtin_amdgcn_readfirstlane(
+                   (int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need)
+            __builtin_amdgcn_s_sleep(1);
+    };
 
     // The target fragments must have ARRIVED before the loop: hipcc waits for a load at its first use, which would be
     // inside the loop -- a counted vmcnt in front of every MFMA, every iteration, draining the LDS-DMA it cannot see.
@@ -135,32 +159,66 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(xb[rb][s]));
     // prologue: tiles t_begin, +1, +2 in flight; A0 <- tile t_begin; tile t_begin+1 published
+    f16x8 a0[KC], a1[KC];
     dma(t_begin, 0);
     dma(t_begin + 1, 1);
     dma(t_begin + 2, 2);
     wait_vmcnt<2 * PPW>();
-    __syncthreads();
-    f16x8 a0[KC], a1[KC];
-    read_tile(a0, 0);
-    wait_vmcnt<PPW>();
-    __syncthreads();                                              // (lgkmcnt(0) inside: every wave has copied tile t_begin)
+    if (SYNC == 0) {
+        __syncthreads();
+        read_tile(a0, 0);
+        wait_vmcnt<PPW>();
+        __syncthreads();                                          // (lgkmcnt(0) inside: every wave has copied tile t_begin)
+    } else {
+        signal(&sync_full[0]);
+        await(&sync_full[0], NW);
+        read_tile(a0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(a0[s]));   // the copy is complete before slot 0 is declared free
+        signal(&sync_free[0]);
+        wait_vmcnt<PPW>();
+        signal(&sync_full[1]);
+    }
 
     f32x16 accP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accP[r] = __builtin_inff();       // inf < tau is false: nothing pending
 
-    // one step: tile t is in `cur`; tile t+1 is published in ring buffer b1; tile t+2 is landing; buffer b0 is free
-    int b0 = 0;                                                    // ring buffer of tile t
+    // one step: tile t is in `cur`; ring slot b0 held it.  SYNC 0: tile t+1 is published in slot b1, tile t+2 is landing.
+    int b0 = 0;                                                    // ring slot of tile t
+    uint32_t need0 = NW;                                           // NW * (fills of slot b0 so far): tile t is its need0/NW-th tile
+    uint32_t need1 = NW, need2 = NW;                               // the same for slots b1 (tile t+1) and b2 (tile t+2)
     auto step = [&](f16x8(&cur)[KC], f16x8(&nxt)[KC], int t) {
         const int b1 = b0 == NBUF - 1 ? 0 : b0 + 1;
-        dma(t + 3, b0);
-        read_tile(nxt, b1);
-        f32x16 accA = cchain<KC>(cur, xb[0]);
-        filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, lkeep);
-        accP = cchain<KC>(cur, xb[1]);
-        filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)t * 32u + 4u * (uint32_t)hh, lkeep);
-        wait_vmcnt<PPW>();                                          // my pieces of tile t+2 have landed (t+3's may be in flight)
-        __syncthreads();                                            // tile t+2 published; every wave has copied tile t+1
+        const int b2 = b1 == NBUF - 1 ? 0 : b1 + 1;
+        if (SYNC == 0) {
+            dma(t + 3, b0);
+            read_tile(nxt, b1);
+            f32x16 accA = cchain<KC>(cur, xb[0]);
+            filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+            accP = cchain<KC>(cur, xb[1]);
+            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)t * 32u + 4u * (uint32_t)hh, lkeep);
+            wait_vmcnt<PPW>();                                      // my pieces of tile t+2 have landed (t+3's may be in flight)
+            __syncthreads();                                        // tile t+2 published; every wave has copied tile t+1
+        } else {
+            wait_vmcnt<0>();                                        // my pieces of tile t+2 (issued a whole step ago)
+            signal(&sync_full[b2]);
+            await(&sync_free[b0], need0);                           // every wave has copied tile t out of slot b0
+            dma(t + 3, b0);
+            await(&sync_full[b1], need1);                           // every wave's pieces of tile t+1 have landed
+            read_tile(nxt, b1);
+            f32x16 accA = cchain<KC>(cur, xb[0]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(nxt[s]));
+            signal(&sync_free[b1]);                                 // tile t+1 is in my registers
+            filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+            accP = cchain<KC>(cur, xb[1]);
+            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)t * 32u + 4u * (uint32_t)hh, lkeep);
+            const uint32_t n0 = need0 + NW;                         // slot b0 now awaits its next tile
+            need0 = need1; need1 = need2; need2 = n0;
+        }
         b0 = b1;
     };
     for (int t = t_begin; t < t_end; t += 2) {
@@ -263,22 +321,33 @@ hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *c
     return hipGetLastError();
 }
 
+template <int KC, int SYNC>
+static hipError_t slaunch_sync(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                               hipStream_t st)
+{
+    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    constexpr int ROWN = l2s_row_entries(KC);
+    constexpr size_t lds = (size_t)L2S_NBUF * KC * 1024 + (size_t)L2S_WAVES * L2S_R * 32 * ROWN * sizeof(uint2) + 64;
+    static_assert(lds <= 163840, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2s_topk_kernel<KC, 1, ROWN, SYNC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid(gx, S), block(64 * L2S_WAVES);
+    hipLaunchKernelGGL((l2s_topk_kernel<KC, 1, ROWN, SYNC>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
+                       cand_idx, cand_key, cand_tau, dbg);
+    return hipGetLastError();
+}
+
 template <int KC>
 static hipError_t slaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               hipStream_t st)
 {
-    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
-    constexpr int ROWN = l2s_row_entries(KC);
-    constexpr size_t lds = (size_t)L2S_NBUF * KC * 1024 + (size_t)L2S_WAVES * L2S_R * 32 * ROWN * sizeof(uint2);
-    static_assert(lds <= 163840, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2s_topk_kernel<KC, 1, ROWN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    dim3 grid(gx, S), block(64 * L2S_WAVES);
-    hipLaunchKernelGGL((l2s_topk_kernel<KC, 1, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
-                       cand_idx, cand_key, cand_tau, dbg);
-    return hipGetLastError();
+    // NABO_L2S_SYNC=0: one barrier per tile (A/B); default: the counter protocol
+    static const int sync = getenv("NABO_L2S_SYNC") ? atoi(getenv("NABO_L2S_SYNC")) : 1;
+    return sync == 0 ? slaunch_sync<KC, 0>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st)
+                     : slaunch_sync<KC, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
 }
 
 // steps of 16 slots for g components: 3 (g+1) slots, instantiated values only

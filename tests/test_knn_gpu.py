@@ -382,7 +382,7 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
     oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
     kernels = {}
-    for mode in ("f16x3", "f16x3h", "f32", None):
+    for mode in ("f16x3", "f16x3h", "f16x3s", "f32", None):
         if mode:
             os.environ["NABO_L2_MODE"] = mode
         try:
@@ -397,14 +397,15 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
         assert st["fallback_rows"] == 0
     assert "l2_topk_kernel" in kernels["f32"]
     assert kernels[None] == kernels["f16x3"]                       # f16x3 is the default
-    # shared-tile kernel (l2s) for g <= 52 and k' + 4 <= 28, per-wave kernel (l2h) up to g < 64 / k' + 4 <= 32
+    # per-wave kernel (l2h) for g < 64 and k' + 4 <= 32; shared-tile kernel (l2s) for g <= 52 and k' + 4 <= 28
     kk = k + drop
-    want = "l2s_topk" if (g <= 52 and kk + 4 <= 28) else "l2h_topk" if (g < 64 and kk + 4 <= 32) else "l2_topk"
-    assert kernels["f16x3"].startswith(want), kernels
-    assert kernels["f16x3h"].startswith("l2h_topk" if (g < 64 and kk + 4 <= 32) else "l2_topk"), kernels
+    h_ok, s_ok = (g < 64 and kk + 4 <= 32), (g <= 52 and kk + 4 <= 28)
+    assert kernels["f16x3h"].startswith("l2h_topk" if h_ok else "l2_topk"), kernels
+    assert kernels["f16x3s"].startswith("l2s_topk" if s_ok else "l2h_topk" if (h_ok and g > 52) else "l2_topk"), kernels
+    assert kernels["f16x3"].startswith(("l2h_topk", "l2s_topk") if h_ok else "l2_topk"), kernels
 
 
-@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3", 274), ("f16x3h", 274)])
+@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3s", 274), ("f16x3h", 274)])
 def test_tail_round_split_rows_are_exact(gpu_lib, mode, full_round):
     """More target workgroups than resident slots: the last, partially filled round is launched with its
     own reference split (api.hip "tail round").  Rows of BOTH launches must match the oracle."""
