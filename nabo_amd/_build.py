@@ -58,9 +58,23 @@ def _compile(args):
     return obj
 
 
-def build(force=False, verbose=False, extra=None):
+def build(force=False, verbose=False, extra=None, out=None):
+    """out: build a VARIANT of the library (extra compiler flags) into another file, with its own object directory --
+    tools/ab/*.sh load it through NABO_KNN_SO; the product's libnabo_knn.so is never touched by experiments."""
     extra = list(extra or [])
+    global SO
+    so_saved = SO
     objdir = os.path.join(CSRC, "build")
+    if out:
+        SO = os.path.abspath(out)
+        objdir = os.path.join(CSRC, "build_" + os.path.splitext(os.path.basename(out))[0])
+    try:
+        return _build(force, verbose, extra, objdir)
+    finally:
+        SO = so_saved
+
+
+def _build(force, verbose, extra, objdir):
     os.makedirs(objdir, exist_ok=True)
     jobs, objs = [], []
     for s in SOURCES:
@@ -81,5 +95,8 @@ def build(force=False, verbose=False, extra=None):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
-    print(SO)
+    # python -m nabo_amd._build [--force] [--verbose] [--out tools/ab/x.so -DFLAG ...]
+    args = sys.argv[1:]
+    out = args[args.index("--out") + 1] if "--out" in args else None
+    extra = [a for a in args if a.startswith("-D") or a.startswith("-mllvm=")]
+    print(build(force="--force" in args, verbose="--verbose" in args, extra=extra, out=out))

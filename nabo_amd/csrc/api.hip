@@ -24,16 +24,11 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
 void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu);
 // f16x3 variant (l2h_topk.hip)
 hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st);
-hipError_t pack_href_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int ks16,
-                            int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
-                            hipStream_t st);
-hipError_t pack_hquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int ks16,
-                              int64_t ntiles_total, unsigned char *out, double *xnorm, hipStream_t st);
-hipError_t l2h_topk_launch(int ks16, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+hipError_t l2h_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            hipStream_t st);
-void l2h_topk_geometry(int ks16, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
-int l2h_pick_ks16(int g);
+void l2h_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
+int l2h_pick_kc(int g);
 // f16x3 variant with K-concatenated operands and reference tiles shared per workgroup through an LDS ring (l2s_topk.hip)
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
@@ -200,18 +195,19 @@ struct nabo_index {
     int64_t n_masked = 0;
     int n_masked_list = 0;
 
-    // Euclidean / cosine filter.  mode 0: fp32 MFMA only (l2_topk.hip); mode 1: f16x3 split on the f16 matrix pipe where
-    // a kernel is instantiated -- kc > 0: l2s_topk.hip (K-concatenated operands, shared LDS tile ring; g <= 52),
-    // else ks16 > 0: l2h_topk.hip (per-wave streaming; g < 64) -- and the fp32 kernel for everything else
+    // Euclidean / cosine filter.  mode 0: fp32 MFMA only (l2_topk.hip); mode 1: f16x3 split on the f16 matrix pipe
+    // (K-concatenated operands, kc steps of 16 slots; g < 64): l2h_topk.hip (per-wave streaming) or, when shared is set
+    // and kc <= 10, l2s_topk.hip (reference tiles shared through an LDS ring) -- and the fp32 kernel for everything else
     int mode = 0;
-    int ks16 = 0, kc = 0;
+    int kc = 0;
+    bool shared = false;
     double hscale = 1.0;
     double fscale = 1.0;           // power-of-two input scale of the fp32 path: max |y~| * fscale in (1/2, 1]
     int ksteps = 0;
-    DevBuf centre, ypk, yhpk, ycpk, normmax;
-    bool packed_f32 = false, packed_f16 = false, packed_c16 = false;
+    DevBuf centre, ypk, ycpk, normmax;
+    bool packed_f32 = false, packed_c16 = false;
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
-    double ymax_sqrt = 0.0, ymax_sqrt_h = 0.0, ymax_sqrt_c = 0.0;
+    double ymax_sqrt = 0.0, ymax_sqrt_c = 0.0;
     // Canberra path: exact kernel operands (yt) and the fp32 lower-bound filter's (ycf)
     DevBuf yt, ycf, yrow, cbflag, ych, cbscale, xh;    // ych/xh: packed f16 operands of the counting pass, cbscale [g] doubles
     int cb_gp = 0;
@@ -247,11 +243,10 @@ int index_metric(const nabo_index *ix) { return ix->metric; }
 bool index_can_emit_candidates(const nabo_index *ix) { return ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0; }
 }  // namespace nabo
 
-// Pack the resident references for the fp32-MFMA kernel (kind 0), the per-wave f16x3 kernel (1) or the shared-tile one (2).
-static int ensure_packed(nabo_index *ix, int kind)
+// Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernels (K-concatenated f16 tiles).
+static int ensure_packed(nabo_index *ix, bool want_h)
 {
-    const bool want_h = kind != 0;
-    if (kind == 0 ? ix->packed_f32 : kind == 1 ? ix->packed_f16 : ix->packed_c16) return NABO_OK;
+    if (want_h ? ix->packed_c16 : ix->packed_f32) return NABO_OK;
     hipStream_t st = ix->stream;
     int rc;
     // normmax: [0] = max ||y~||^2 (float bits, SCALED units), [2..3] = max |y~ component| (double bits)
@@ -271,19 +266,12 @@ static int ensure_packed(nabo_index *ix, int kind)
     if (e2 > 480) e2 = 480;                                  // scale^2 must stay finite in float64
     if (e2 < -480) e2 = -480;
     double scale;
-    if (kind == 2) {
+    if (want_h) {
         if ((rc = ix->ycpk.reserve((size_t)ix->ref_tiles_alloc * ix->kc * 1024 + 128))) return rc;
-        ix->hscale = scale = std::ldexp(1.0, e2 + 12);       // |v| <= 2^12 after scaling, as below
-        HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc,
-                                       ix->ref_tiles_alloc, ix->dmask, ix->ycpk.as<unsigned char>(),
-                                       ix->normmax.as<unsigned int>(), st));
-    } else if (want_h) {
-        const size_t tile_bytes = (size_t)2 * ix->ks16 * 1024 + 128;
-        if ((rc = ix->yhpk.reserve((size_t)ix->ref_tiles_alloc * tile_bytes))) return rc;
         // |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
         ix->hscale = scale = std::ldexp(1.0, e2 + 12);
-        HIP_TRY(nabo::pack_href_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->ks16,
-                                       ix->ref_tiles_alloc, ix->dmask, ix->yhpk.as<unsigned char>(),
+        HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc,
+                                       ix->ref_tiles_alloc, ix->dmask, ix->ycpk.as<unsigned char>(),
                                        ix->normmax.as<unsigned int>(), st));
     } else {
         const int Q = (ix->ksteps + 3) / 4;
@@ -298,8 +286,7 @@ static int ensure_packed(nabo_index *ix, int kind)
     float fmax;
     memcpy(&fmax, &bits[0], sizeof(fmax));
     const double v = std::sqrt((double)fmax) / scale * (1.0 + 1e-6);      // unscaled units
-    if (kind == 2) { ix->ymax_sqrt_c = v; ix->packed_c16 = true; }
-    else if (kind == 1) { ix->ymax_sqrt_h = v; ix->packed_f16 = true; }
+    if (want_h) { ix->ymax_sqrt_c = v; ix->packed_c16 = true; }
     else { ix->ymax_sqrt = v; ix->packed_f32 = true; }
     return NABO_OK;
 }
@@ -375,14 +362,12 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
         // k + drop_first + 4 <= 32) -- same results, ~2x the fp32-MFMA kernel; NABO_L2_MODE=f32 pins the fp32 kernel,
         // =f16x3 is the default spelled out.
         const char *md = getenv("NABO_L2_MODE");
-        if (!(md && strcmp(md, "f32") == 0) && ix->ksteps > 0 && nabo::l2h_pick_ks16(g) > 0) {
+        // NABO_L2_MODE=f16x3s selects the shared-tile kernel (l2s_topk.hip) where it is instantiated, =f16x3h / unset
+        // the per-wave one (l2h_topk.hip), which measured faster at 1M x 1M
+        if (!(md && strcmp(md, "f32") == 0) && ix->ksteps > 0 && nabo::l2h_pick_kc(g) > 0) {
             ix->mode = 1;
-            ix->ks16 = nabo::l2h_pick_ks16(g);
-            // which f16x3 kernel: NABO_L2_MODE=f16x3s the shared-tile one (l2s_topk.hip), =f16x3h the per-wave one
-            // (l2h_topk.hip); unset / f16x3: whichever measured faster at 1M x 1M
-            const bool want_s = md ? strcmp(md, "f16x3s") == 0 : false;
-            ix->kc = want_s ? nabo::l2s_pick_kc(g) : 0;
-            if (ix->kc < 0) ix->kc = 0;
+            ix->kc = nabo::l2h_pick_kc(g);
+            ix->shared = md && strcmp(md, "f16x3s") == 0 && nabo::l2s_pick_kc(g) == ix->kc;
         }
     }
     int cus = 0;
@@ -403,7 +388,7 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->yhpk, &ix->ycpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d, &ix->fails2,
+    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->ycpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d, &ix->fails2,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
     for (DevBuf *b : bufs) b->release();
@@ -434,7 +419,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
     } else if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 64;      // room for split padding (+inf-norm tiles; up to 32 splits)
-        ix->packed_f32 = ix->packed_f16 = ix->packed_c16 = false;
+        ix->packed_f32 = ix->packed_c16 = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
         if (ix->metric == NABO_METRIC_COSINE) {
             // cosine: the filter sees unit-length rows, NOT centred (a shift changes angles)
@@ -446,7 +431,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
             HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
             ix->dYp = ix->dY;
         }
-        if ((rc = ensure_packed(ix, ix->mode == 1 ? (ix->kc > 0 ? 2 : 1) : 0))) return rc;
+        if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
     } else {
         const int64_t chunks = (ix->n + 63) / 64;
         if ((rc = ix->yt.reserve((size_t)chunks * 64 * ix->g * sizeof(double)))) return rc;
@@ -504,8 +489,8 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
     if (rc) return rc;
     if ((rc = apply_mask(ix, ref_mask))) return rc;
     if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0) {       // masked cells carry ||y||^2 = +inf in the packed tiles
-        ix->packed_f32 = ix->packed_f16 = ix->packed_c16 = false;
-        if ((rc = ensure_packed(ix, ix->mode == 1 ? (ix->kc > 0 ? 2 : 1) : 0))) return rc;
+        ix->packed_f32 = ix->packed_c16 = false;
+        if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
     }
     return NABO_OK;
 }
@@ -591,10 +576,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = L;
         bool use_h = false, use_c = false;                   // use_h: an f16x3 kernel runs; use_c: the shared-tile one
         if (ix->mode == 1 && epl == 1) {
-            if (ix->kc > 0) nabo::l2s_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            else nabo::l2h_topk_geometry(ix->ks16, &rows_per_wg, &wg_per_cu, &lkeep_max);
+            if (ix->shared) {
+                nabo::l2s_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
+                use_c = (cand_mode ? kk : kk + 4) <= lkeep_max;
+            }
+            if (!use_c) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
-            use_c = use_h && ix->kc > 0;
         }
         // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
         // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
@@ -621,11 +608,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         const int epl_launch = r1 ? -1 : epl;
         if (!ix->wide_retry) {
             if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
-            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,40> (3 x v_mfma_f32_32x32x16_f16, f16x3 split)", ix->ks16);
+            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,36> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
             else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
                           r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 40 : 80);
         }
-        if ((rc = ensure_packed(ix, use_c ? 2 : use_h ? 1 : 0))) return rc;
+        if ((rc = ensure_packed(ix, use_h))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
         const int64_t rows_pad = gx * rows_per_wg;
@@ -654,7 +641,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 int64_t s_hi = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
                 if (s_hi > 1024 / L) s_hi = 1024 / L;
                 // ms per reference tile and workgroup, measured: 105 ms / 31250 tiles (fp32, 256 rows, 25 k-steps); 1.2 us f16x3
-                const double t_tile = use_c ? 0.7e-3 * ix->kc / 10.0 : use_h ? 1.2e-3 * ix->ks16 / 4.0
+                const double t_tile = use_c ? 0.7e-3 * ix->kc / 10.0 : use_h ? 1.1e-3 * ix->kc / 10.0
                                                                         : 3.36e-3 * (rows_per_wg / 256.0) * (ix->ksteps / 25.0);
                 double best = 1e30;
                 for (int s2 = 1; s2 <= (int)s_hi; ++s2) {
@@ -683,7 +670,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
             return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
         const int64_t rows_main = gx_main * rows_per_wg, rows_tail = gx_tail * rows_per_wg;
-        const size_t xtile_bytes = use_c ? (size_t)ix->kc * 1024 : use_h ? (size_t)2 * ix->ks16 * 1024 : (size_t)Q * 256 * sizeof(float);
+        const size_t xtile_bytes = use_h ? (size_t)ix->kc * 1024 : (size_t)Q * 256 * sizeof(float);
         if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * xtile_bytes))) return rc;
         if ((rc = ix->xnorm.reserve((size_t)m * sizeof(double)))) return rc;
         if ((rc = ix->cand_idx.reserve((size_t)rows_main * S * L * sizeof(uint32_t) + 16))) return rc;
@@ -695,11 +682,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
         if ((rc = ix->failcnt.reserve(sizeof(unsigned int)))) return rc;
         HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
-        if (use_c)
+        if (use_h)
             HIP_TRY(nabo::pack_cquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->kc, rows_pad / 32,
-                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), st));
-        else if (use_h)
-            HIP_TRY(nabo::pack_hquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->ks16, rows_pad / 32,
                                              ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), st));
         else
             HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->fscale, ix->ksteps, rows_pad / 32,
@@ -716,11 +700,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                               ix->cand_tau2.as<float>(), st));
         } else if (use_h) {
             if (gx_main > 0)
-                HIP_TRY(nabo::l2h_topk_launch(ix->ks16, ix->xpk.as<unsigned char>(), ix->yhpk.as<unsigned char>(),
+                HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
                                               (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
                                               ix->cand_tau.as<float>(), st));
             if (gx_tail > 0)
-                HIP_TRY(nabo::l2h_topk_launch(ix->ks16, ix->xpk.as<unsigned char>(), ix->yhpk.as<unsigned char>(),
+                HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
                                               (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(), st));
         } else {
@@ -745,13 +729,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             return NABO_OK;
         }
         // rounding-error coefficient of the filter score, relative to (||x|| + max||y||)^2
-        // (f16x3: one fp32 accumulation per product term -- 48 per 16-component slab in l2h, 16 per step in l2s -- plus
-        // the dropped lo*lo term and the representation error of the hi + lo split)
-        const double err_coef = use_c   ? 1.05 * ((16.0 * ix->kc + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
-                                : use_h ? 1.05 * ((48.0 * ix->ks16 + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
-                                        : 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
+        // (f16x3: one fp32 accumulation per product term, 16 per step, plus the dropped lo*lo term and the
+        // representation error of the hi + lo split)
+        const double err_coef = use_h ? 1.05 * ((16.0 * ix->kc + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
+                                      : 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
         const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0 / (ix->fscale * ix->fscale);
-        const double ymax_sqrt = use_c ? ix->ymax_sqrt_c : use_h ? ix->ymax_sqrt_h : ix->ymax_sqrt;
+        const double ymax_sqrt = use_h ? ix->ymax_sqrt_c : ix->ymax_sqrt;
         const int64_t m_main = rows_main < m ? rows_main : m;
         if (cand_mode) {
             HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(),

@@ -37,9 +37,34 @@ __device__ __forceinline__ bool kv_less(K ka, uint32_t va, K kb, uint32_t vb)
     return (ka < kb) || (ka == kb && va < vb);
 }
 
-__device__ __forceinline__ float shfl_xor_t(float v, int m) { return __shfl_xor(v, m, 64); }
-__device__ __forceinline__ uint32_t shfl_xor_t(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
-__device__ __forceinline__ double shfl_xor_t(double v, int m) { return __shfl_xor(v, m, 64); }
+// Lane exchange with lane ^ m for the sorting networks.  __shfl_xor is ds_bpermute_b32: an LDS round trip (~120 cycles)
+// per exchange, and a bitonic sort is a chain of 21 DEPENDENT exchanges -- a 64-entry sort measured 5400 cycles
+// (tools: -DNABO_LISTS_PROF), almost all of it waiting.  For m < 32 the data-parallel-primitive forms are used instead
+// (a VALU operand modifier: no LDS, no address register): quad_perm for m = 1, 2; two bank-masked row shifts for
+// m = 4; row_ror:8 for m = 8; ds_swizzle (bit-mask mode, crossbar only) for m = 16; m = 32 keeps the permute.
+// `m` must be a compile-time constant after unrolling (the dpp controls are immediates).
+__device__ __forceinline__ int xor_lane_i32(int v, int m)
+{
+    switch (m) {
+    case 1: return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);                    // quad_perm:[1,0,3,2]
+    case 2: return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);                    // quad_perm:[2,3,0,1]
+    case 4: {
+        int t = __builtin_amdgcn_update_dpp(v, v, 0x104, 0xF, 0x5, false);               // row_shl:4 into banks 0, 2
+        return __builtin_amdgcn_update_dpp(t, v, 0x114, 0xF, 0xA, false);                // row_shr:4 into banks 1, 3
+    }
+    case 8: return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);                   // row_ror:8
+    case 16: return __builtin_amdgcn_ds_swizzle(v, 0x401F);                              // and 0x1F, or 0, xor 0x10
+    default: return __shfl_xor(v, m, 64);
+    }
+}
+__device__ __forceinline__ float shfl_xor_t(float v, int m) { return __builtin_bit_cast(float, xor_lane_i32(__builtin_bit_cast(int, v), m)); }
+__device__ __forceinline__ uint32_t shfl_xor_t(uint32_t v, int m) { return (uint32_t)xor_lane_i32((int)v, m); }
+__device__ __forceinline__ double shfl_xor_t(double v, int m)
+{
+    const uint64_t b = __builtin_bit_cast(uint64_t, v);
+    const uint32_t lo = (uint32_t)xor_lane_i32((int)(uint32_t)b, m), hi = (uint32_t)xor_lane_i32((int)(uint32_t)(b >> 32), m);
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
 
 // Wave-wide bitonic sort of N = 64*EPL (key, val) pairs, ascending in the canonical order.
 // Element index e = r*64 + lane (r = register slot).  After the call element e holds rank e.

@@ -159,6 +159,8 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
 // cand_idx/cand_key: [rows_launch][S][LMAX], cand_tau: [rows_launch][S] (rows local to the launch).
 // Two waves per SIMD need <= 256 VGPRs; that holds while the resident target fragments
 // (R*KSTEPS registers) stay <= 64 -- larger shapes run one wave per SIMD without spilling.
+constexpr int L2_NREC = 20;         // staging records per wave (topk_lists.h)
+
 template <int KSTEPS, int R, int EPL, int ROWN>
 __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kernel(const float *__restrict__ Xpk,
                                                                                   const float *__restrict__ Ypk,
@@ -169,11 +171,10 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS
                                                                                   float *__restrict__ cand_tau,
                                                                                   int dbg /* ablation, 0 in production */)
 {
-    constexpr int ROW = ListCfg<EPL, ROWN>::ROW;
+    using C = ListCfg<EPL, ROWN, R, L2_NREC>;
     constexpr int QTF = qtile_floats(KSTEPS);
     constexpr int RTF = rtile_floats(KSTEPS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint2 *smem = reinterpret_cast<uint2 *>(smem_raw);
 
     const int lane = lane_id();
     const int hh = lane >> 5;
@@ -196,14 +197,13 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS
                 if (4 * q + e < KSTEPS) xb[rb][4 * q + e] = v[e];
         }
     }
-    RowState st[R];
+    unsigned char *wl = smem_raw + (size_t)wave * C::BYTES;          // this wave's lists (topk_lists.h)
+    float tauv[R];
+    const float tau0 = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
-    for (int rb = 0; rb < R; ++rb) {
-        st[rb].tau = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
-        st[rb].pc = 0;
-        st[rb].kc = 0;
-    }
-    uint2 *wbuf = smem + (size_t)wave * R * 32 * ROW;
+    for (int rb = 0; rb < R; ++rb) tauv[rb] = tau0;
+    uint32_t scnt = 0;
+    lists_init<C>(wl, lkeep, tau0);
 
     // tile counters are 32-bit (n_ref < 2^32 - 16 => < 2^27 tiles): the loop test stays on the scalar unit
     const int t_begin = split * tiles_per_split;
@@ -221,25 +221,22 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS
         for (int t = t_begin; t < t_end; ++t) {
             const int tn = (t + 1 < t_end) ? t + 1 : t;
             f32x16 accA = mfma_chain<KSTEPS, false>(y, xb[0], nullptr, lane);
-            filter_and_append<EPL, ROWN>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, ((uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh), lkeep);
+            filter_and_stage<C, EPL, R, L2_NREC>(accP, R - 1, ((uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh), wl, scnt, lkeep, tauv);
             accP = mfma_chain<KSTEPS, true>(y, xb[R - 1], ybase + (int64_t)tn * RTF, lane);
-            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, ((uint32_t)t * 32u + 4u * (uint32_t)hh), lkeep);
+            filter_and_stage<C, EPL, R, L2_NREC>(accA, 0, ((uint32_t)t * 32u + 4u * (uint32_t)hh), wl, scnt, lkeep, tauv);
         }
-        filter_and_append<EPL, ROWN>(accP, st[R - 1], wbuf + (R - 1) * 32 * ROW, ((uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh), lkeep);
+        filter_and_stage<C, EPL, R, L2_NREC>(accP, R - 1, ((uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh), wl, scnt, lkeep, tauv);
     } else {
         for (int t = t_begin; t < t_end; ++t) {
             const int tn = (t + 1 < t_end) ? t + 1 : t;
             f32x16 accA = mfma_chain<KSTEPS, true>(y, xb[0], ybase + (int64_t)tn * RTF, lane);
-            filter_and_append<EPL, ROWN>(accP, st[0], wbuf, ((uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh), lkeep);
+            filter_and_stage<C, EPL, R, L2_NREC>(accP, 0, ((uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh), wl, scnt, lkeep, tauv);
             accP = accA;
         }
-        filter_and_append<EPL, ROWN>(accP, st[0], wbuf, ((uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh), lkeep);
+        filter_and_stage<C, EPL, R, L2_NREC>(accP, 0, ((uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh), wl, scnt, lkeep, tauv);
     }
 
-#pragma unroll
-    for (int rb = 0; rb < R; ++rb)
-        flush_block<EPL, ROWN>(st[rb], wbuf + rb * 32 * ROW, (ltile0 + rb) * 32, split, S, lkeep, cand_idx, cand_key,
-                             cand_tau);
+    lists_flush<C, EPL, R>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }
 
 // ---- launch wrapper -------------------------------------------------------------------
@@ -248,7 +245,7 @@ static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_s
                              int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
     static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
-    const size_t lds = (size_t)4 * R * 32 * ListCfg<EPL, ROWN>::ROW * sizeof(uint2);
+    const size_t lds = (size_t)4 * ListCfg<EPL, ROWN, R, L2_NREC>::BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL, ROWN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -268,7 +265,7 @@ void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu)
 }
 
 // ksteps must be one of the instantiated values; epl 1 -> lists of <= 32 (R=2), 2 -> <= 64 (R=1).
-// Row lists take 40 (80) entries: two workgroups (2 x 80 KB) per CU.
+// Rows take 36 (72) entries + the per-wave staging area: two workgroups (2 x 80 KB) per CU.
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st)
@@ -278,9 +275,9 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
         if (epl == -1)                                                                                                \
             return launch_one<KS, 1, 1, 40>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,      \
                                             cand_tau, st);                                                            \
-        return epl == 1 ? launch_one<KS, 2, 1, 40>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+        return epl == 1 ? launch_one<KS, 2, 1, 36>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st)                                                       \
-                        : launch_one<KS, 1, 2, 80>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+                        : launch_one<KS, 1, 2, 72>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st);
     switch (ksteps) {
         NABO_CASE(8)

@@ -18,7 +18,8 @@
 //     ring into a second register set, waits for ITS OWN pieces of tile t+2 with a counted s_waitcnt vmcnt, barrier.
 //   * Two waves per SIMD: the f16 matrix pipe overlaps with another wave's vector / LDS work, so one wave's filter,
 //     hit path (topk_lists.h) and waits are covered by its partner's MFMAs.
-//   * Candidate lists: 32 entries per row (kept k'+8, the rest pending), wave-private, 128 KiB; ring 3 x KC KiB.
+//   * Candidate lists: 28 entries per row (kept k'+8, the rest pending) + a staging area per wave (topk_lists.h),
+//     wave-private, 127 KiB; ring 3 x KC KiB.
 #include <cstdlib>
 
 #include <hip/hip_fp16.h>
@@ -34,7 +35,8 @@ constexpr int L2S_WAVES = 8;        // waves per workgroup (two per SIMD)
 constexpr int L2S_R = 2;            // row-blocks per wave
 constexpr int L2S_NBUF = 3;         // ring depth (tiles)
 
-__host__ __device__ constexpr int l2s_row_entries(int kc) { return kc <= 10 ? 32 : 30; }   // list entries per row: LDS budget
+constexpr int L2S_NREC = 20;        // staging records per wave (topk_lists.h)
+__host__ __device__ constexpr int l2s_row_entries(int kc) { (void)kc; return 28; }   // list entries per row: LDS budget
 
 // LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + lane * 16 (cdna_hip_programming.md,
 // "What hipcc does not do": M0 written in the statement that reads it; hipcc does not count this load).
@@ -82,12 +84,12 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
                                                           int dbg)
 {
     constexpr int R = L2S_R, NW = L2S_WAVES, NBUF = L2S_NBUF;
-    constexpr int ROW = ListCfg<EPL, ROWN>::ROW;
+    using C = ListCfg<EPL, ROWN, L2S_R, L2S_NREC>;
     constexpr int TB = KC * 1024;                      // bytes per packed tile (targets and references alike)
     constexpr int PPW = (KC + NW - 1) / NW;            // LDS-DMA pieces every wave issues per tile (uniform: counted waits)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint2 *lists = reinterpret_cast<uint2 *>(smem_raw + NBUF * TB);
-    uint32_t *sync_full = reinterpret_cast<uint32_t *>(lists + (size_t)NW * R * 32 * ROW);      // [NBUF], then free [NBUF]
+    unsigned char *lists = smem_raw + NBUF * TB;
+    uint32_t *sync_full = reinterpret_cast<uint32_t *>(lists + (size_t)NW * C::BYTES);          // [NBUF], then free [NBUF]
     uint32_t *sync_free = sync_full + NBUF;
 
     const int lane = lane_id();
@@ -110,14 +112,13 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int s = 0; s < KC; ++s) xb[rb][s] = p[s * 64 + lane];
     }
-    RowState st[R];
+    unsigned char *wl = lists + (size_t)wave * C::BYTES;             // this wave's lists (topk_lists.h)
+    float tauv[R];
+    const float tau0 = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
 #pragma unroll
-    for (int rb = 0; rb < R; ++rb) {
-        st[rb].tau = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
-        st[rb].pc = 0;
-        st[rb].kc = 0;
-    }
-    uint2 *wbuf = lists + (size_t)wave * R * 32 * ROW;
+    for (int rb = 0; rb < R; ++rb) tauv[rb] = tau0;
+    uint32_t scnt = 0;
+    lists_init<C>(wl, lkeep, tau0);
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
@@ -164,7 +165,10 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
     dma(t_begin + 1, 1);
     dma(t_begin + 2, 2);
     wait_vmcnt<2 * PPW>();
-    if (SYNC == 0) {
+    if (SYNC == 2) {
+        wait_vmcnt<0>();                                          // (tile t_begin+2's DMA is re-issued by step 0: drain it here)
+        __syncthreads();
+    } else if (SYNC == 0) {
         __syncthreads();
         read_tile(a0, 0);
         wait_vmcnt<PPW>();
@@ -192,13 +196,25 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
     auto step = [&](f16x8(&cur)[KC], f16x8(&nxt)[KC], int t) {
         const int b1 = b0 == NBUF - 1 ? 0 : b0 + 1;
         const int b2 = b1 == NBUF - 1 ? 0 : b1 + 1;
-        if (SYNC == 0) {
+        if (SYNC == 2) {
+            // ONE A-operand register set (KC = 10: two sets + the staging code do not fit 256 VGPRs without spills,
+            // and a scratch reload in the MFMA loop makes hipcc wait vmcnt(0), i.e. for the LDS-DMA in flight):
+            // tile t is read from the ring at the top of its own step; tile t+2's DMA goes into the slot tile t-1 left.
+            dma(t + 2, b2);
+            read_tile(cur, b0);
+            f32x16 accA = cchain<KC>(cur, xb[0]);
+            filter_and_stage<C, EPL, R, L2S_NREC>(accP, 1, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
+            accP = cchain<KC>(cur, xb[1]);
+            filter_and_stage<C, EPL, R, L2S_NREC>(accA, 0, (uint32_t)t * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
+            wait_vmcnt<PPW>();                                      // my pieces of tile t+1 have landed (t+2's may be in flight)
+            __syncthreads();                                        // tile t+1 published; every wave is done with tile t
+        } else if (SYNC == 0) {
             dma(t + 3, b0);
             read_tile(nxt, b1);
             f32x16 accA = cchain<KC>(cur, xb[0]);
-            filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+            filter_and_stage<C, EPL, R, L2S_NREC>(accP, 1, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
             accP = cchain<KC>(cur, xb[1]);
-            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)t * 32u + 4u * (uint32_t)hh, lkeep);
+            filter_and_stage<C, EPL, R, L2S_NREC>(accA, 0, (uint32_t)t * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
             wait_vmcnt<PPW>();                                      // my pieces of tile t+2 have landed (t+3's may be in flight)
             __syncthreads();                                        // tile t+2 published; every wave has copied tile t+1
         } else {
@@ -213,24 +229,26 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
 #pragma unroll
             for (int s = 0; s < KC; ++s) asm volatile("" : "+v"(nxt[s]));
             signal(&sync_free[b1]);                                 // tile t+1 is in my registers
-            filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+            filter_and_stage<C, EPL, R, L2S_NREC>(accP, 1, (uint32_t)(t - 1) * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
             accP = cchain<KC>(cur, xb[1]);
-            filter_and_append<EPL, ROWN>(accA, st[0], wbuf, (uint32_t)t * 32u + 4u * (uint32_t)hh, lkeep);
+            filter_and_stage<C, EPL, R, L2S_NREC>(accA, 0, (uint32_t)t * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
             const uint32_t n0 = need0 + NW;                         // slot b0 now awaits its next tile
             need0 = need1; need1 = need2; need2 = n0;
         }
         b0 = b1;
     };
-    for (int t = t_begin; t < t_end; t += 2) {
-        step(a0, a1, t);
-        if (t + 1 < t_end) step(a1, a0, t + 1);
+    if (SYNC == 2) {
+        for (int t = t_begin; t < t_end; ++t) step(a0, a0, t);
+    } else {
+        for (int t = t_begin; t < t_end; t += 2) {
+            step(a0, a1, t);
+            if (t + 1 < t_end) step(a1, a0, t + 1);
+        }
     }
-    filter_and_append<EPL, ROWN>(accP, st[1], wbuf + 32 * ROW, (uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh, lkeep);
+    filter_and_stage<C, EPL, R, L2S_NREC>(accP, 1, (uint32_t)(t_end - 1) * 32u + 4u * (uint32_t)hh, wl, scnt, lkeep, tauv);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // drain the look-ahead DMA before the epilogue's stores
 
-#pragma unroll
-    for (int rb = 0; rb < R; ++rb)
-        flush_block<EPL, ROWN>(st[rb], wbuf + rb * 32 * ROW, (ltile0 + rb) * 32, split, S, lkeep, cand_idx, cand_key, cand_tau);
+    lists_flush<C, EPL, R>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }
 
 // ---- packing ------------------------------------------------------------------------------
@@ -328,7 +346,7 @@ static hipError_t slaunch_sync(const unsigned char *Xpk, const unsigned char *Yp
 {
     static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
     constexpr int ROWN = l2s_row_entries(KC);
-    constexpr size_t lds = (size_t)L2S_NBUF * KC * 1024 + (size_t)L2S_WAVES * L2S_R * 32 * ROWN * sizeof(uint2) + 64;
+    constexpr size_t lds = (size_t)L2S_NBUF * KC * 1024 + (size_t)L2S_WAVES * ListCfg<1, ROWN, L2S_R, L2S_NREC>::BYTES + 64;
     static_assert(lds <= 163840, "LDS budget");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2s_topk_kernel<KC, 1, ROWN, SYNC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -344,10 +362,12 @@ static hipError_t slaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               hipStream_t st)
 {
-    // NABO_L2S_SYNC=0: one barrier per tile (A/B); default: the counter protocol
-    static const int sync = getenv("NABO_L2S_SYNC") ? atoi(getenv("NABO_L2S_SYNC")) : 1;
-    return sync == 0 ? slaunch_sync<KC, 0>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st)
-                     : slaunch_sync<KC, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+    // NABO_L2S_SYNC: 0 = barrier per tile, two A-operand register sets; 1 = LDS counters instead of barriers;
+    // 2 (default) = barrier per tile, ONE A-operand set read at the top of the step (no spills at KC = 10)
+    static const int sync = getenv("NABO_L2S_SYNC") ? atoi(getenv("NABO_L2S_SYNC")) : 2;
+    return sync == 0   ? slaunch_sync<KC, 0>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st)
+           : sync == 1 ? slaunch_sync<KC, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st)
+                       : slaunch_sync<KC, 2>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
 }
 
 // steps of 16 slots for g components: 3 (g+1) slots, instantiated values only

@@ -1,184 +1,315 @@
-// topk_lists.h -- wave-private candidate lists in LDS shared by the Euclidean top-L kernels.
+// topk_lists.h -- wave-private candidate lists in LDS shared by the Euclidean top-L kernels (l2_topk.hip,
+// l2h_topk.hip, l2s_topk.hip): STAGED hits, BATCHED appends.
 //
-// Accumulator convention (v_mfma_f32_32x32x*): lane l holds, for target row (l & 31) of the wave's
-// row-block, 16 scores a[r]; register r of lane half h = l >> 5 belongs to reference
-// jb + cd_row(r, 0) where jb = first reference of the tile + 4*h.
+// Accumulator convention (v_mfma_f32_32x32x*): lane l holds, for target row (l & 31) of a row-block, 16 scores a[i];
+// register i of lane half h = l >> 5 belongs to reference jb + cd_row(i, 0) where jb = first reference of the tile + 4 h.
+//
+// A chain's filter is 8 v_min3 + 1 v_cmp against the row's threshold tau (one VGPR, lane = row).  What happens on a hit
+// used to be the largest non-MFMA item of these kernels: the hitting lanes -- one or two of 64 -- searched their 16
+// registers, appended, knocked out and looked again while the whole wave waited (~70 vector instructions and two
+// scalar round trips per episode, 255 episodes per row over 1M references).  Now:
+//   * STAGE (the episode, ~20 instructions, no loop): every hitting lane copies its 16 scores into a record of the
+//     wave's staging area (4 ds_write_b128) with a header (row, first reference).  Nothing is searched.
+//   * DRAIN (when the staging area is full, every ~15 episodes): ONE LANE PER RECORD.  Each lane compares its record's
+//     16 scores with the row's current threshold (from LDS: the authoritative copy), reserves slots in the row's
+//     pending list with one LDS atomic add and writes the qualifying (score, reference) pairs -- up to 64 records
+//     in parallel instead of one hit at a time.  Scores >= the row's threshold are dropped (the threshold only ever
+//     decreases, so they stay outside the final list).  Entries that find the pending list full stay flagged in their
+//     record and are retried after the compaction below.
+//   * COMPACT (rows whose pending list is full): wave-wide bitonic sort of kept + pending entries, keep the lkeep
+//     smallest, threshold := lkeep-th key.
+// The VGPR copy of a threshold is refreshed after every drain; between drains it is stale (too large), which only
+// stages a few scores that the drain then drops.
+// Kept lists start as lkeep sentinel entries (+inf, 0xFFFFFFFF): no separate "kept count", and a row that never sees
+// lkeep real candidates ends with threshold +inf (= nothing was dropped), as before.
 #pragma once
 #include "knn_common.h"
 
 namespace nabo {
 
-// Candidate-list geometry (per target row, ROW entries in the owning wave's LDS slice), with
-// ph = (ROW - 2 - lkeep) / 2 pending slots per lane half (whatever the kept list does not need):
-//   [0, lkeep)                      kept entries (the lkeep smallest seen so far, sorted)
-//   [lkeep, lkeep+ph]               pending slots of lane half 0 (+1 scratch slot at index ph)
-//   [lkeep+ph+1, lkeep+2ph+1]       pending slots of lane half 1 (+1 scratch slot)
-// The second template parameter of everything below is ROW (entries per row in LDS).
-template <int EPL, int ROWN>
+// EPL: registers per lane in a wave-wide sort (lists of <= 64 * EPL entries); ROWN: entries per row in LDS (kept +
+// pending); NB: row-blocks per wave; NREC: staging records per wave.
+template <int EPL, int ROWN, int NB, int NREC>
 struct ListCfg {
     static constexpr int LMAX = 32 * EPL;                // stride of the emitted candidate lists
     static constexpr int ROW = ROWN;
-    static_assert(ROW - 2 <= 64 * EPL, "a row must fit one wave-wide sort");
-    __device__ static int ph(int lkeep) { return (ROW - 2 - lkeep) >> 1; }     // needs lkeep <= ROW - 4
+    static constexpr int NROWS = NB * 32;
+    static_assert(ROW <= 64 * EPL, "a row must fit one wave-wide sort");
+    static_assert(NREC <= 64 && NREC % 2 == 0, "one lane per staged record");
+    // per-wave LDS block (16-byte aligned; BYTES is a multiple of 16):
+    //   srec [NREC][16] f32 | rows [NROWS][ROW] uint2 | shdr [NREC] uint2 | pcnt [NROWS] u32 | tauL [NROWS] f32
+    static constexpr int OFF_ROWS = NREC * 64;
+    static constexpr int OFF_SHDR = OFF_ROWS + NROWS * ROW * 8;
+    static constexpr int OFF_PCNT = OFF_SHDR + NREC * 8;
+    static constexpr int OFF_TAU = OFF_PCNT + NROWS * 4;
+#ifdef NABO_LISTS_PROF
+    static constexpr int OFF_PROF = OFF_TAU + NROWS * 4;     // 16 u32 event counters / cycle sums (profiling builds only)
+    static constexpr int BYTES = OFF_PROF + 64;
+    __device__ static uint32_t *prof(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_PROF); }
+#else
+    static constexpr int BYTES = OFF_TAU + NROWS * 4;
+#endif
+    static_assert(BYTES % 16 == 0, "per-wave list block must keep 16-byte alignment");
+    __device__ static float *srec(unsigned char *w) { return reinterpret_cast<float *>(w); }
+    __device__ static uint2 *rows(unsigned char *w) { return reinterpret_cast<uint2 *>(w + OFF_ROWS); }
+    __device__ static uint2 *shdr(unsigned char *w) { return reinterpret_cast<uint2 *>(w + OFF_SHDR); }
+    __device__ static uint32_t *pcnt(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_PCNT); }
+    __device__ static float *tauL(unsigned char *w) { return reinterpret_cast<float *>(w + OFF_TAU); }
 };
 
-struct RowState {           // per lane; lanes l and l+32 hold the same tau / kc, their own pc
-    float tau;              // nothing with score >= tau can still enter the kept list
-    uint32_t pc;            // pending entries of this lane half
-    uint32_t kc;            // kept entries
-};
+// Profiling builds (-DNABO_LISTS_PROF, tools only): per-wave event counts and shader-clock sums in LDS, added to a
+// global array by lists_flush and printed by the launch wrapper: [0] episodes [1] cycles staging [2] drains
+// [3] cycles draining (compactions included) [4] compactions [5] cycles compacting [6] records [7] entries appended.
+#ifdef NABO_LISTS_PROF
+static __device__ unsigned long long nabo_lists_prof[8];
+#define NABO_PROF_ADD(w, i, v)                                                    \
+    do {                                                                          \
+        if (lane_id() == 0) atomicAdd(&C::prof(w)[i], (uint32_t)(v));            \
+    } while (0)
+#define NABO_PROF_T0() const uint64_t prof_t0 = __builtin_readcyclecounter()
+#define NABO_PROF_DT() (uint32_t)(__builtin_readcyclecounter() - prof_t0)
+#else
+#define NABO_PROF_ADD(w, i, v) do { } while (0)
+#define NABO_PROF_T0() do { } while (0)
+#define NABO_PROF_DT() 0u
+#endif
 
-// Sort kept + both pending lists of one row, keep the lkeep smallest.  Returns the new kept
-// count; `tau_out` is the key of rank lkeep-1 when at least lkeep entries exist.
-template <int EPL, int ROWN>
-__device__ __forceinline__ uint32_t compact_row(uint2 *rowbuf, uint32_t kc, uint32_t pa, uint32_t pb, int lkeep,
-                                                float &tau_io, float (&key)[EPL], uint32_t (&val)[EPL])
+// Sentinel kept lists, empty pending lists, thresholds +inf (tau0 = -inf: "no hits" timing experiments).
+template <typename C>
+__device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float tau0)
 {
-    const int ph = ListCfg<EPL, ROWN>::ph(lkeep);
     const int lane = lane_id();
-    const uint32_t total = kc + pa + pb;
+    uint2 *rows = C::rows(w);
+    for (int e = lane; e < C::NROWS * lkeep; e += 64) {
+        const int r = e / lkeep, s = e - r * lkeep;
+        rows[r * C::ROW + s] = make_uint2(__float_as_uint(__builtin_inff()), 0xFFFFFFFFu);
+    }
+    for (int r = lane; r < C::NROWS; r += 64) {
+        C::pcnt(w)[r] = 0u;
+        C::tauL(w)[r] = tau0;
+    }
+#ifdef NABO_LISTS_PROF
+    if (lane < 16) C::prof(w)[lane] = 0u;
+#endif
+}
+
+// Sort kept + pending entries of one row (wave-wide), keep the lkeep smallest, publish the new threshold.
+// Returns with key/val holding the sorted entries (element e = r * 64 + lane).
+template <typename C, int EPL>
+__device__ __forceinline__ void compact_row(unsigned char *w, int row, int lkeep, float (&key)[EPL], uint32_t (&val)[EPL])
+{
+    const int lane = lane_id();
+    uint2 *rowbuf = C::rows(w) + row * C::ROW;
+    const int P = C::ROW - lkeep;
+    uint32_t np = C::pcnt(w)[row];                      // wave-uniform (same address in every lane)
+    np = np < (uint32_t)P ? np : (uint32_t)P;            // reservations past the end were never written
+    const uint32_t total = (uint32_t)lkeep + np;
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
         const uint32_t e = (uint32_t)(r * 64 + lane);
         key[r] = __builtin_inff();
         val[r] = 0xFFFFFFFFu;
         if (e < total) {
-            uint32_t src = e;                                         // kept
-            if (e >= kc) src = lkeep + (e - kc);                      // pending, half 0
-            if (e >= kc + pa) src = lkeep + (ph + 1) + (e - kc - pa); // pending, half 1
-            uint2 v = rowbuf[src];
+            const uint2 v = rowbuf[e];
             key[r] = __uint_as_float(v.x);
             val[r] = v.y;
         }
     }
     wave_bitonic_sort<EPL, float>(key, val);
-    const uint32_t nk = total < (uint32_t)lkeep ? total : (uint32_t)lkeep;
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
         const uint32_t e = (uint32_t)(r * 64 + lane);
-        if (e < nk) rowbuf[e] = make_uint2(__float_as_uint(key[r]), val[r]);
+        if (e < (uint32_t)lkeep) rowbuf[e] = make_uint2(__float_as_uint(key[r]), val[r]);
     }
-    if (total >= (uint32_t)lkeep) {
-        const int e = lkeep - 1;
-        float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[0]), e & 63));
-        if (EPL > 1 && e >= 64)
-            t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[EPL - 1]), e & 63));
-        tau_io = t;
+    const int e = lkeep - 1;
+    float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[0]), e & 63));
+    if (EPL > 1 && e >= 64) t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[EPL - 1]), e & 63));
+    if (lane == 0) {
+        C::tauL(w)[row] = t;
+        C::pcnt(w)[row] = 0u;
     }
-    return nk;
 }
 
-// Hit path.  lane l: target row (l & 31) of this row-block; register r of lane half h is
-// reference jb + cd_row(r, 0) (jb already contains 4*h).  Per iteration every hitting lane appends
-// its smallest outstanding score to its own pending list (one unconditional ds_write: lanes
-// without a hit write their scratch slot), knocks that register out and looks again; rows whose
-// pending list is full are compacted first.  No per-register branches: a VALU->SALU round trip
-// costs more than the ~80 VALU instructions of an iteration.
-template <int EPL, int ROWN>
-__device__ __forceinline__ void slow_append(f32x16 a, float m, RowState &st, uint2 *blockbuf, uint32_t jb, int lkeep)
+// Batched appends: one lane per staged record (see the header comment).  Written to need few registers: a record's
+// 16 scores are read from LDS four at a time, once to count the qualifying ones and once more to write them.
+template <typename C, int EPL>
+__device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt, int lkeep)
 {
-    constexpr int ROW = ListCfg<EPL, ROWN>::ROW;
-    const int ph = ListCfg<EPL, ROWN>::ph(lkeep);
     const int lane = lane_id();
-    const int tl = lane & 31, hh = lane >> 5;
-    uint2 *sub = blockbuf + tl * ROW + lkeep + hh * (ph + 1);
-    bool hit = m < st.tau;
-    if (EPL == 1) {
-        // (Short lists only: with 64-entry lists -- k' > 24 -- several hits per lane and full rows are common enough
-        // that the test costs more than it saves: cosine d=100, k=50 at 1M x 1M 1680 vs 1660 ms.)
-        // Fast path (nearly every episode): every hitting lane has exactly ONE score below its threshold and room for
-        // it.  One compare per register finds the register (per lane) and, through the scalar unit, the number of
-        // hits in the wave; if that equals the number of hitting lanes nothing else can be pending, and the
-        // knock-out / second look of the general loop below (40 of its ~80 vector instructions) is not needed.
-        // On gfx950 vector-ALU instructions are not hidden behind the fp32 MFMAs of the SIMD's other wave.
-        uint32_t rs = 0;
-        int total = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool below = a[r] < st.tau;
-            total += __builtin_popcountll(__builtin_amdgcn_ballot_w64(below));
-            rs = below ? (uint32_t)r : rs;
-        }
-        const uint64_t hm = __builtin_amdgcn_ballot_w64(hit);
-        const uint64_t full = __builtin_amdgcn_ballot_w64(hit && st.pc >= (uint32_t)ph);
-        if (total == __builtin_popcountll(hm) && full == 0) {
-            const uint32_t slot = hit ? st.pc : (uint32_t)ph;
-            sub[slot] = make_uint2(__float_as_uint(m), jb + (rs & 3u) + 8u * (rs >> 2));
-            st.pc += hit ? 1u : 0u;
-            return;
-        }
+    const int P = C::ROW - lkeep;
+    uint2 *rows = C::rows(w);
+    uint32_t *pcnt = C::pcnt(w);
+    float *tauL = C::tauL(w);
+    const bool mine = (uint32_t)lane < scnt;
+    uint32_t row = 0, qm = 0, jb = 0;
+    const f32x4 *rp = reinterpret_cast<const f32x4 *>(C::srec(w) + (mine ? lane : 0) * 16);
+    if (mine) {
+        const uint2 h = C::shdr(w)[lane];
+        row = h.x & 0xFFu;
+        qm = h.x >> 8;
+        jb = h.y;
     }
     for (;;) {
-        const uint64_t fm = __builtin_amdgcn_ballot_w64(hit && st.pc >= (uint32_t)ph);
-        if (fm != 0) {
-            uint32_t rows = (uint32_t)fm | (uint32_t)(fm >> 32);
-            while (rows) {
-                const int row = __builtin_ctz(rows);
-                rows &= rows - 1;
-                const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)st.kc, row);
-                const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row);
-                const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row + 32);
-                float nt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.tau), row));
+        // which of my record's scores still qualify, and how many pending slots they need
+        uint32_t q = 0;
+        if (qm != 0) {
+            const float t = tauL[row];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = rp[q4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) q |= (v[e] < t) ? (1u << (4 * q4 + e)) : 0u;
+            }
+            q &= qm;
+        }
+        const int c = __builtin_popcount(q);
+        uint32_t slot = 0;
+        if (c > 0) slot = __hip_atomic_fetch_add(&pcnt[row], (uint32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t left = 0;
+#ifdef NABO_LISTS_PROF
+        if (c > 0) atomicAdd(&C::prof(w)[7], (uint32_t)c);
+#endif
+        if (c > 0) {
+            uint2 *pend = rows + row * C::ROW + lkeep;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 v = rp[q4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q4 + e;
+                    if ((q >> i) & 1u) {
+                        if (slot < (uint32_t)P) pend[slot] = make_uint2(__float_as_uint(v[e]), jb + (uint32_t)((i & 3) + 8 * (i >> 2)));
+                        else left |= 1u << i;
+                        ++slot;
+                    }
+                }
+            }
+        }
+        qm = left;                                       // qualified but found the row full: again after its compaction
+        // rows whose pending list is full (or over-reserved): compact, one row at a time, the whole wave sorting
+#pragma unroll
+        for (int base = 0; base < C::NROWS; base += 64) {
+            uint64_t fm = __builtin_amdgcn_ballot_w64(base + lane < C::NROWS && pcnt[base + lane < C::NROWS ? base + lane : 0] >= (uint32_t)P);
+            while (fm != 0) {
+                const int rr = base + __builtin_ctzll(fm);
+                fm &= fm - 1;
                 float key[EPL];
                 uint32_t val[EPL];
-                const uint32_t nk = compact_row<EPL, ROWN>(blockbuf + row * ROW, kc, pa, pb, lkeep, nt, key, val);
-                if (tl == row) { st.tau = nt; st.pc = 0; st.kc = nk; }
+                NABO_PROF_T0();
+                compact_row<C, EPL>(w, rr, lkeep, key, val);
+                NABO_PROF_ADD(w, 4, 1);
+                NABO_PROF_ADD(w, 5, NABO_PROF_DT() >> 4);
             }
-            hit = m < st.tau;
-            if (__builtin_amdgcn_ballot_w64(hit) == 0) break;
-            continue;
         }
-        // register holding the lane minimum
-        uint32_t rs = 0;
-#pragma unroll
-        for (int r = 15; r >= 1; --r) rs = (a[r] == m) ? (uint32_t)r : rs;
-        const uint32_t slot = hit ? st.pc : (uint32_t)ph;
-        sub[slot] = make_uint2(__float_as_uint(m), jb + (rs & 3u) + 8u * (rs >> 2));
-        st.pc += hit ? 1u : 0u;
-        // knock it out, look for another hit in the same lane
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a[r] = (hit && rs == (uint32_t)r) ? __builtin_inff() : a[r];
-        m = a[0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) m = fminf(m, a[r]);
-        hit = m < st.tau;
-        if (__builtin_amdgcn_ballot_w64(hit) == 0) break;
+        if (__builtin_amdgcn_ballot_w64(qm != 0) == 0) break;
     }
 }
 
-template <int EPL, int ROWN>
-__device__ __forceinline__ void filter_and_append(const f32x16 &acc, RowState &st, uint2 *blockbuf, uint32_t jb,
-                                                  int lkeep)
+// NABO_DRAIN_CALL (defined by the including kernel file): the drain as a REAL function call on the wave's LDS offset
+// (the callee still uses ds_ instructions) instead of an inlined copy at every filter site -- for kernels whose MFMA
+// loop leaves no registers for the drain's temporaries.
+typedef __attribute__((address_space(3))) unsigned char lds_byte;
+
+template <typename C, int EPL>
+__device__ __noinline__ void lists_drain_fn(uint32_t w_off, uint32_t scnt, int lkeep)
+{
+    lists_drain_body<C, EPL>((unsigned char *)(lds_byte *)(uintptr_t)w_off, scnt, lkeep);
+}
+
+// drain + refresh of the register copies of the thresholds (lane = row of its row-block)
+template <typename C, int EPL, int NB>
+__device__ __forceinline__ void lists_drain(unsigned char *w, uint32_t scnt, int lkeep, float (&tauv)[NB])
+{
+    NABO_PROF_T0();
+#ifdef NABO_DRAIN_CALL
+    lists_drain_fn<C, EPL>((uint32_t)(uintptr_t)w, scnt, lkeep);
+#else
+    lists_drain_body<C, EPL>(w, scnt, lkeep);
+#endif
+    NABO_PROF_ADD(w, 2, 1);
+    NABO_PROF_ADD(w, 3, NABO_PROF_DT() >> 4);
+    NABO_PROF_ADD(w, 6, scnt);
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) tauv[rb] = C::tauL(w)[rb * 32 + (lane_id() & 31)];
+}
+
+// The episode: hitting lanes park their 16 scores; the staging area is drained when it is full.
+template <typename C, int EPL, int NB, int NREC>
+__device__ __forceinline__ void stage_hits(const f32x16 &a, float m, int rb, uint32_t jb, unsigned char *w, uint32_t &scnt,
+                                           int lkeep, float (&tauv)[NB])
+{
+    const int lane = lane_id();
+    bool hit = m < tauv[rb];
+    for (;;) {
+        const uint64_t bm = __builtin_amdgcn_ballot_w64(hit);
+        if (bm == 0) return;
+        const uint32_t room = (uint32_t)NREC - scnt;
+        if (room == 0) {
+            lists_drain<C, EPL, NB>(w, scnt, lkeep, tauv);
+            scnt = 0;
+            hit = hit && (m < tauv[rb]);                 // the threshold may have come down
+            continue;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+        const bool take = hit && rank < room;
+        if (take) {
+            const uint32_t p = scnt + rank;
+            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                f32x4 v;
+                v[0] = a[4 * q4]; v[1] = a[4 * q4 + 1]; v[2] = a[4 * q4 + 2]; v[3] = a[4 * q4 + 3];
+                rp[q4] = v;
+            }
+            C::shdr(w)[p] = make_uint2((uint32_t)(rb * 32 + (lane & 31)) | (0xFFFFu << 8), jb);
+        }
+        const uint32_t n = (uint32_t)__builtin_popcountll(bm);
+        scnt += n < room ? n : room;
+        hit = hit && !take;
+    }
+}
+
+// A chain's filter: lane minimum of the 16 scores against the row's threshold; a wave-uniform branch on "any hit".
+template <typename C, int EPL, int NB, int NREC>
+__device__ __forceinline__ void filter_and_stage(const f32x16 &acc, int rb, uint32_t jb, unsigned char *w, uint32_t &scnt,
+                                                 int lkeep, float (&tauv)[NB])
 {
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fminf(m, acc[r]);
-    if (__builtin_amdgcn_ballot_w64(m < st.tau) != 0) slow_append<EPL, ROWN>(acc, m, st, blockbuf, jb, lkeep);
+    if (__builtin_amdgcn_ballot_w64(m < tauv[rb]) != 0) {
+        NABO_PROF_T0();
+        stage_hits<C, EPL, NB, NREC>(acc, m, rb, jb, w, scnt, lkeep, tauv);
+        NABO_PROF_ADD(w, 0, 1);
+        NABO_PROF_ADD(w, 1, NABO_PROF_DT() >> 4);           // (drains inside the episode are counted here too)
+    }
 }
 
-// Final flush of one row-block: sort every row, emit the kept candidate indices (+ tau).
-template <int EPL, int ROWN>
-__device__ __forceinline__ void flush_block(RowState &st, uint2 *blockbuf, int64_t lrow0, int split, int S, int lkeep,
-                                            uint32_t *__restrict__ cand_idx, float *__restrict__ cand_key,
-                                            float *__restrict__ cand_tau)
+// Final flush of a wave: drain what is staged, sort every row, emit the kept candidate indices (+ threshold).
+// lrow0: first row of the wave's first row-block, local to the launch (rows of a wave are consecutive).
+template <typename C, int EPL, int NB>
+__device__ __forceinline__ void lists_flush(unsigned char *w, uint32_t scnt, int64_t lrow0, int split, int S, int lkeep,
+                                            float (&tauv)[NB], uint32_t *__restrict__ cand_idx,
+                                            float *__restrict__ cand_key, float *__restrict__ cand_tau)
 {
-    constexpr int LMAX = ListCfg<EPL, ROWN>::LMAX, ROW = ListCfg<EPL, ROWN>::ROW;
+    constexpr int LMAX = C::LMAX;
     const int lane = lane_id();
-    for (int row = 0; row < 32; ++row) {
-        const uint32_t kc = (uint32_t)__builtin_amdgcn_readlane((int)st.kc, row);
-        const uint32_t pa = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row);
-        const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)st.pc, row + 32);
-        float t_row = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, st.tau), row));
+    if (scnt > 0) lists_drain<C, EPL, NB>(w, scnt, lkeep, tauv);
+#ifdef NABO_LISTS_PROF
+    if (lane < 8) atomicAdd(&nabo_lists_prof[lane], (unsigned long long)C::prof(w)[lane]);
+#endif
+    for (int row = 0; row < C::NROWS; ++row) {
         float key[EPL];
         uint32_t val[EPL];
-        const uint32_t nk = compact_row<EPL, ROWN>(blockbuf + row * ROW, kc, pa, pb, lkeep, t_row, key, val);
+        compact_row<C, EPL>(w, row, lkeep, key, val);
+        const float t_row = C::tauL(w)[row];
         const int64_t o = ((lrow0 + row) * S + split) * (int64_t)LMAX;
 #pragma unroll
         for (int r = 0; r < EPL; ++r) {
             const uint32_t e = (uint32_t)(r * 64 + lane);
             if (e < (uint32_t)LMAX) {
-                cand_idx[o + e] = e < nk ? val[r] : 0xFFFFFFFFu;
-                if (cand_key) cand_key[o + e] = e < nk ? key[r] : __builtin_inff();
+                cand_idx[o + e] = e < (uint32_t)lkeep ? val[r] : 0xFFFFFFFFu;
+                if (cand_key) cand_key[o + e] = e < (uint32_t)lkeep ? key[r] : __builtin_inff();
             }
         }
         if (lane == 0) cand_tau[(lrow0 + row) * S + split] = t_row;

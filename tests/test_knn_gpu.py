@@ -401,7 +401,7 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     kk = k + drop
     h_ok, s_ok = (g < 64 and kk + 4 <= 32), (g <= 52 and kk + 4 <= 28)
     assert kernels["f16x3h"].startswith("l2h_topk" if h_ok else "l2_topk"), kernels
-    assert kernels["f16x3s"].startswith("l2s_topk" if s_ok else "l2h_topk" if (h_ok and g > 52) else "l2_topk"), kernels
+    assert kernels["f16x3s"].startswith("l2s_topk" if (g <= 52 and kk + 4 <= 24) else ("l2h_topk", "l2_topk")), kernels
     assert kernels["f16x3"].startswith(("l2h_topk", "l2s_topk") if h_ok else "l2_topk"), kernels
 
 
