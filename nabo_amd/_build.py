@@ -95,8 +95,8 @@ def _build(force, verbose, extra, objdir):
 
 
 if __name__ == "__main__":
-    # python -m nabo_amd._build [--force] [--verbose] [--out tools/ab/x.so -DFLAG ...]
+    # python -m nabo_amd._build [--force] [--verbose] [--out tools/ab/x.so -DFLAG ... [-- more hipcc flags]]
     args = sys.argv[1:]
     out = args[args.index("--out") + 1] if "--out" in args else None
-    extra = [a for a in args if a.startswith("-D") or a.startswith("-mllvm=")]
+    extra = [a for a in args if a.startswith("-D")] + (args[args.index("--") + 1:] if "--" in args else [])
     print(build(force="--force" in args, verbose="--verbose" in args, extra=extra, out=out))

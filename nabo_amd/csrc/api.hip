@@ -21,7 +21,7 @@ hipError_t pack_query_launch(const double *X, int64_t m, int g, const double *ce
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st);
-void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu);
+void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 // f16x3 variant (l2h_topk.hip)
 hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st);
 hipError_t l2h_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
@@ -587,8 +587,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
         bool r1 = false;
         if (!use_h) {
-            lkeep_max = L;
-            nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu);
+            nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu, &lkeep_max);
             const int r1_mode = env_int("NABO_L2_R1", -1);             // -1 auto, 0 never, 1 always (experiments)
             // ... and also when the list warm-up is a large share of a workgroup's time (short reference streams,
             // e.g. one shard of eight): the same per-workgroup model as the split choice below, threshold measured
@@ -602,15 +601,15 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 (r1_mode == 1 || (m + rows_per_wg - 1) / rows_per_wg < (int64_t)ix->n_cu * wg_per_cu ||
                  warm_ms > 0.075 * stream_ms)) {
                 r1 = true;
-                nabo::l2_topk_geometry(ix->ksteps, -1, &rows_per_wg, &wg_per_cu);
+                nabo::l2_topk_geometry(ix->ksteps, -1, &rows_per_wg, &wg_per_cu, &lkeep_max);
             }
         }
         const int epl_launch = r1 ? -1 : epl;
         if (!ix->wide_retry) {
             if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
-            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,36> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
+            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,35> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
             else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
-                          r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 40 : 80);
+                          r1 ? 1 : (epl == 1 ? 2 : 1), epl, r1 ? 41 : epl == 1 ? 35 : 71);
         }
         if ((rc = ensure_packed(ix, use_h))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once

@@ -195,7 +195,7 @@ __device__ __forceinline__ float cbf_compact(float *kb, uint32_t *ib, int count,
         val[r] = 0xFFFFFFFFu;
         if (e < count) { key[r] = kb[e]; val[r] = ib[e]; }
     }
-    wave_bitonic_sort<EPL, float>(key, val);
+    wave_sort_f32<EPL>(key, val);
 #pragma unroll
     for (int r = 0; r < EPL; ++r) {
         const int e = r * 64 + lane;

@@ -256,16 +256,17 @@ static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_s
 }
 
 // Rows per workgroup and co-resident workgroups per CU of the variant that will run.
-void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu)
+void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 {
     int R = epl == 1 ? 2 : 1;
     *wg_per_cu = (R * ksteps <= 64) ? 2 : 1;
-    if (epl == -1) { R = 1; *wg_per_cu = 3; }          // epl = -1: the one-row-block, three-waves-per-SIMD variant
+    *lkeep_max = epl == 2 ? 64 : 30;                   // row entries 35 (R = 2) / 71 (64-entry lists), >= 5 pending slots
+    if (epl == -1) { R = 1; *wg_per_cu = 3; *lkeep_max = 32; }      // epl = -1: one row-block, three waves per SIMD, rows of 41
     *rows_per_wg = 4 * R * 32;
 }
 
 // ksteps must be one of the instantiated values; epl 1 -> lists of <= 32 (R=2), 2 -> <= 64 (R=1).
-// Rows take 36 (72) entries + the per-wave staging area: two workgroups (2 x 80 KB) per CU.
+// Rows take 35 (71) entries + the per-wave staging area: two workgroups (2 x 80 KB) per CU.
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st)
@@ -273,11 +274,11 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
 #define NABO_CASE(KS)                                                                                                 \
     case KS:                                                                                                          \
         if (epl == -1)                                                                                                \
-            return launch_one<KS, 1, 1, 40>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,      \
+            return launch_one<KS, 1, 1, 41>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,      \
                                             cand_tau, st);                                                            \
-        return epl == 1 ? launch_one<KS, 2, 1, 36>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+        return epl == 1 ? launch_one<KS, 2, 1, 35>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st)                                                       \
-                        : launch_one<KS, 1, 2, 72>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+                        : launch_one<KS, 1, 2, 71>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st);
     switch (ksteps) {
         NABO_CASE(8)

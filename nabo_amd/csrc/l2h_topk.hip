@@ -29,7 +29,7 @@ namespace nabo {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int L2H_NREC = 28;        // staging records per wave (topk_lists.h)
-constexpr int L2H_ROW = 36;         // list entries per row: 4 waves x (128 rows x 36 entries + staging) = 156 KB
+constexpr int L2H_ROW = 35;         // list entries per row (odd): 4 waves x (128 rows x 35 entries + staging) = 154 KB
 constexpr int L2H_LAG = 2;          // a register is refilled this many MFMAs behind its last reader (l2_topk.hip)
 
 // One chain: 32 refs x 32 targets x KC steps.  RELOAD: refill the tile's registers with tile `next` behind their last use.
@@ -43,7 +43,11 @@ __device__ __forceinline__ f32x16 hchain(f16x8 (&a)[KC], const f16x8 (&b)[KC], c
     for (int s = 0; s < KC + (RELOAD ? L2H_LAG : 0); ++s) {
         if (s < KC) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[s], b[s], acc, 0, 0, 0);
         const int r = s - L2H_LAG;
+#ifdef NABO_L2H_NORELOAD        // timing experiments: the same tile again and again (garbage results)
+        if (false) {
+#else
         if (RELOAD && r >= 0) {
+#endif
             __builtin_amdgcn_sched_barrier(0);
             a[r] = reinterpret_cast<const f16x8 *>(next)[r * 64 + lane];
             __builtin_amdgcn_sched_barrier(0);
@@ -108,6 +112,11 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
 #pragma unroll
     for (int r = 0; r < 16; ++r) accP[r] = __builtin_inff();       // inf < tau is false: nothing pending
 
+#ifdef NABO_L2H_NOFILTER          // timing experiments: chains only; the accumulators are kept alive through an empty asm
+#define L2H_FILTER(ACC, RB, JB) asm volatile("" ::"v"(ACC))
+#else
+#define L2H_FILTER(ACC, RB, JB) filter_and_stage<C, EPL, R, L2H_NREC>(ACC, RB, JB, wl, scnt, lkeep, tauv)
+#endif
     // all R chains of tile t on register set `a`; the last chain refills `a` with tile t+2
     auto tile_step = [&](f16x8(&a)[KC], int t) {
         const unsigned char *next2 = tile_ptr(t + 2);
@@ -119,11 +128,11 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
             if (rb & 1) {
                 if (rb == R - 1) accP = hchain<KC, true>(a, xb[rb], next2, lane);
                 else accP = hchain<KC, false>(a, xb[rb], next2, lane);
-                filter_and_stage<C, EPL, R, L2H_NREC>(accA, prev, (uint32_t)(tprev * 32 + 4 * hh), wl, scnt, lkeep, tauv);
+                L2H_FILTER(accA, prev, (uint32_t)(tprev * 32 + 4 * hh));
             } else {
                 if (rb == R - 1) accA = hchain<KC, true>(a, xb[rb], next2, lane);
                 else accA = hchain<KC, false>(a, xb[rb], next2, lane);
-                filter_and_stage<C, EPL, R, L2H_NREC>(accP, prev, (uint32_t)(tprev * 32 + 4 * hh), wl, scnt, lkeep, tauv);
+                L2H_FILTER(accP, prev, (uint32_t)(tprev * 32 + 4 * hh));
             }
         }
         if (R & 1) accP = accA;        // odd R: the pending chain is the one just computed
@@ -180,21 +189,21 @@ static hipError_t hlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
         unsigned long long h[8];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(nabo_lists_prof), sizeof(h));
-        fprintf(stderr, "[lists prof, cumulative] episodes %llu (x16 cyc %llu) drains %llu (x16 cyc %llu) compactions %llu (x16 cyc %llu) "
+        fprintf(stderr, "[lists prof, cumulative] episodes %llu (x16 cyc %llu) drains %llu (x16 cyc %llu) merges %llu (x16 cyc %llu) "
                         "records %llu appended %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
 #endif
     return hipGetLastError();
 }
 
-// Instantiated for lists of <= 32 kept entries (k + drop_first <= 28): 4 row-blocks per wave, rows of 36 list entries
-// + staging = 156 KB of LDS, one workgroup per CU.
+// Instantiated for lists of <= 30 kept entries (k + drop_first <= 26): 4 row-blocks per wave, rows of 35 list entries
+// + staging = 154 KB of LDS, one workgroup per CU.
 void l2h_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 {
     (void)kc;
     *rows_per_wg = 4 * 4 * 32;
     *wg_per_cu = 1;
-    *lkeep_max = L2H_ROW - 4 < 32 ? L2H_ROW - 4 : 32;      // at least 4 pending slots; emitted lists hold 32
+    *lkeep_max = L2H_ROW - 5 < 32 ? L2H_ROW - 5 : 32;      // at least 5 pending slots; emitted lists hold 32
 }
 
 // steps of 16 slots for g components: 3 (g+1) slots, instantiated values only (the packed layout of l2s_topk.hip)

@@ -16,8 +16,12 @@
 //     in parallel instead of one hit at a time.  Scores >= the row's threshold are dropped (the threshold only ever
 //     decreases, so they stay outside the final list).  Entries that find the pending list full stay flagged in their
 //     record and are retried after the compaction below.
-//   * COMPACT (rows whose pending list is full): wave-wide bitonic sort of kept + pending entries, keep the lkeep
-//     smallest, threshold := lkeep-th key.
+//   * MERGE (end of every drain): ONE LANE PER ROW.  The kept list of a row is UNSORTED, its threshold is the largest
+//     kept key and `pmax` its position; a lane walks its row's few pending entries and, for each one below the
+//     threshold, overwrites the largest kept entry and rescans its lkeep keys for the new maximum (~3 lkeep
+//     instructions, all 64 rows of a pass at once).  The first version sorted kept + pending wave-wide, one row at a
+//     time, whenever a pending list filled up: 4150 cycles per row compaction (tools: -DNABO_LISTS_PROF), 44 % of the
+//     whole hit path.  Merging after every drain also keeps the thresholds exact, so fewer scores are staged at all.
 // The VGPR copy of a threshold is refreshed after every drain; between drains it is stale (too large), which only
 // stages a few scores that the drain then drops.
 // Kept lists start as lkeep sentinel entries (+inf, 0xFFFFFFFF): no separate "kept count", and a row that never sees
@@ -27,28 +31,31 @@
 
 namespace nabo {
 
-// EPL: registers per lane in a wave-wide sort (lists of <= 64 * EPL entries); ROWN: entries per row in LDS (kept +
-// pending); NB: row-blocks per wave; NREC: staging records per wave.
+// EPL: emitted candidate lists hold 32 * EPL entries; ROWN: entries per row in LDS (kept + pending, odd);
+// NB: row-blocks per wave; NREC: staging records per wave.
 template <int EPL, int ROWN, int NB, int NREC>
 struct ListCfg {
     static constexpr int LMAX = 32 * EPL;                // stride of the emitted candidate lists
     static constexpr int ROW = ROWN;
     static constexpr int NROWS = NB * 32;
-    static_assert(ROW <= 64 * EPL, "a row must fit one wave-wide sort");
+    static_assert(ROW % 2 == 1, "odd row stride (lane-per-row accesses)");
     static_assert(NREC <= 64 && NREC % 2 == 0, "one lane per staged record");
     // per-wave LDS block (16-byte aligned; BYTES is a multiple of 16):
-    //   srec [NREC][16] f32 | rows [NROWS][ROW] uint2 | shdr [NREC] uint2 | pcnt [NROWS] u32 | tauL [NROWS] f32
+    //   srec [NREC][16] f32 | rows [NROWS][ROW] uint2 | shdr [NREC] uint2 | pcnt [NROWS] u32 | tauL [NROWS] f32 |
+    //   pmax [NROWS] u32.  ROW is odd: a lane-per-row walk then spreads over the LDS banks
     static constexpr int OFF_ROWS = NREC * 64;
     static constexpr int OFF_SHDR = OFF_ROWS + NROWS * ROW * 8;
     static constexpr int OFF_PCNT = OFF_SHDR + NREC * 8;
     static constexpr int OFF_TAU = OFF_PCNT + NROWS * 4;
+    static constexpr int OFF_PMAX = OFF_TAU + NROWS * 4;
 #ifdef NABO_LISTS_PROF
-    static constexpr int OFF_PROF = OFF_TAU + NROWS * 4;     // 16 u32 event counters / cycle sums (profiling builds only)
+    static constexpr int OFF_PROF = OFF_PMAX + NROWS * 4;    // 16 u32 event counters / cycle sums (profiling builds only)
     static constexpr int BYTES = OFF_PROF + 64;
     __device__ static uint32_t *prof(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_PROF); }
 #else
-    static constexpr int BYTES = OFF_TAU + NROWS * 4;
+    static constexpr int BYTES = OFF_PMAX + NROWS * 4;
 #endif
+    __device__ static uint32_t *pmax(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_PMAX); }
     static_assert(BYTES % 16 == 0, "per-wave list block must keep 16-byte alignment");
     __device__ static float *srec(unsigned char *w) { return reinterpret_cast<float *>(w); }
     __device__ static uint2 *rows(unsigned char *w) { return reinterpret_cast<uint2 *>(w + OFF_ROWS); }
@@ -87,46 +94,62 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
     for (int r = lane; r < C::NROWS; r += 64) {
         C::pcnt(w)[r] = 0u;
         C::tauL(w)[r] = tau0;
+        C::pmax(w)[r] = 0u;
     }
 #ifdef NABO_LISTS_PROF
     if (lane < 16) C::prof(w)[lane] = 0u;
 #endif
 }
 
-// Sort kept + pending entries of one row (wave-wide), keep the lkeep smallest, publish the new threshold.
-// Returns with key/val holding the sorted entries (element e = r * 64 + lane).
-template <typename C, int EPL>
-__device__ __forceinline__ void compact_row(unsigned char *w, int row, int lkeep, float (&key)[EPL], uint32_t (&val)[EPL])
+// MERGE: one lane per row (see the header comment).  Pending entries [lkeep, lkeep + min(pcnt, P)) of every row are
+// folded into its unsorted kept list [0, lkeep); threshold = largest kept key, pmax = where it sits.
+template <typename C>
+__device__ __forceinline__ void merge_rows(unsigned char *w, int lkeep)
 {
     const int lane = lane_id();
-    uint2 *rowbuf = C::rows(w) + row * C::ROW;
     const int P = C::ROW - lkeep;
-    uint32_t np = C::pcnt(w)[row];                      // wave-uniform (same address in every lane)
-    np = np < (uint32_t)P ? np : (uint32_t)P;            // reservations past the end were never written
-    const uint32_t total = (uint32_t)lkeep + np;
 #pragma unroll
-    for (int r = 0; r < EPL; ++r) {
-        const uint32_t e = (uint32_t)(r * 64 + lane);
-        key[r] = __builtin_inff();
-        val[r] = 0xFFFFFFFFu;
-        if (e < total) {
-            const uint2 v = rowbuf[e];
-            key[r] = __uint_as_float(v.x);
-            val[r] = v.y;
+    for (int base = 0; base < C::NROWS; base += 64) {
+        const int r = base + lane < C::NROWS ? base + lane : C::NROWS - 1;
+        uint32_t np = base + lane < C::NROWS ? C::pcnt(w)[r] : 0u;
+        np = np < (uint32_t)P ? np : (uint32_t)P;              // reservations past the end were never written
+        if (__builtin_amdgcn_ballot_w64(np != 0) == 0) continue;
+        uint2 *kept = C::rows(w) + r * C::ROW;
+        const uint2 *pend = kept + lkeep;
+        float tau = C::tauL(w)[r];
+        uint32_t pm = C::pmax(w)[r];
+        for (uint32_t e = 0; __builtin_amdgcn_ballot_w64(e < np) != 0; ++e) {
+            bool repl = false;
+            if (e < np) {
+                const uint2 v = pend[e];
+                repl = __uint_as_float(v.x) < tau;
+                if (repl) kept[pm] = v;                         // evict the largest kept entry
+            }
+            if (__builtin_amdgcn_ballot_w64(repl) != 0) {       // new maximum of the rows that changed
+                // eight keys per round trip: a one-key-at-a-time scan is a chain of lkeep dependent LDS latencies
+                // (12,900 cycles per merge measured); reads past lkeep (pending slots, the next row) are masked
+                float t = -__builtin_inff();
+                uint32_t p = 0;
+                for (int i0 = 0; i0 < lkeep; i0 += 8) {
+                    float kq[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const bool gt = (i0 + j < lkeep) && (kq[j] > t);
+                        t = gt ? kq[j] : t;
+                        p = gt ? (uint32_t)(i0 + j) : p;
+                    }
+                }
+                tau = repl ? t : tau;
+                pm = repl ? p : pm;
+            }
         }
-    }
-    wave_bitonic_sort<EPL, float>(key, val);
-#pragma unroll
-    for (int r = 0; r < EPL; ++r) {
-        const uint32_t e = (uint32_t)(r * 64 + lane);
-        if (e < (uint32_t)lkeep) rowbuf[e] = make_uint2(__float_as_uint(key[r]), val[r]);
-    }
-    const int e = lkeep - 1;
-    float t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[0]), e & 63));
-    if (EPL > 1 && e >= 64) t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, key[EPL - 1]), e & 63));
-    if (lane == 0) {
-        C::tauL(w)[row] = t;
-        C::pcnt(w)[row] = 0u;
+        if (np != 0) {
+            C::tauL(w)[r] = tau;
+            C::pmax(w)[r] = pm;
+            C::pcnt(w)[r] = 0u;
+        }
     }
 }
 
@@ -186,20 +209,11 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
             }
         }
         qm = left;                                       // qualified but found the row full: again after its compaction
-        // rows whose pending list is full (or over-reserved): compact, one row at a time, the whole wave sorting
-#pragma unroll
-        for (int base = 0; base < C::NROWS; base += 64) {
-            uint64_t fm = __builtin_amdgcn_ballot_w64(base + lane < C::NROWS && pcnt[base + lane < C::NROWS ? base + lane : 0] >= (uint32_t)P);
-            while (fm != 0) {
-                const int rr = base + __builtin_ctzll(fm);
-                fm &= fm - 1;
-                float key[EPL];
-                uint32_t val[EPL];
-                NABO_PROF_T0();
-                compact_row<C, EPL>(w, rr, lkeep, key, val);
-                NABO_PROF_ADD(w, 4, 1);
-                NABO_PROF_ADD(w, 5, NABO_PROF_DT() >> 4);
-            }
+        {   // fold every row's pending entries into its kept list (and empty the pending lists)
+            NABO_PROF_T0();
+            merge_rows<C>(w, lkeep);
+            NABO_PROF_ADD(w, 4, 1);
+            NABO_PROF_ADD(w, 5, NABO_PROF_DT() >> 4);
         }
         if (__builtin_amdgcn_ballot_w64(qm != 0) == 0) break;
     }
@@ -234,13 +248,35 @@ __device__ __forceinline__ void lists_drain(unsigned char *w, uint32_t scnt, int
 }
 
 // The episode: hitting lanes park their 16 scores; the staging area is drained when it is full.
+template <typename C>
+__device__ __forceinline__ void stage_write(const f32x16 &a, uint32_t p, int rb, uint32_t jb, unsigned char *w)
+{
+    f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * 16);
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+        f32x4 v;
+        v[0] = a[4 * q4]; v[1] = a[4 * q4 + 1]; v[2] = a[4 * q4 + 2]; v[3] = a[4 * q4 + 3];
+        rp[q4] = v;
+    }
+    C::shdr(w)[p] = make_uint2((uint32_t)(rb * 32 + (lane_id() & 31)) | (0xFFFFu << 8), jb);
+}
+
 template <typename C, int EPL, int NB, int NREC>
 __device__ __forceinline__ void stage_hits(const f32x16 &a, float m, int rb, uint32_t jb, unsigned char *w, uint32_t &scnt,
                                            int lkeep, float (&tauv)[NB])
 {
-    const int lane = lane_id();
     bool hit = m < tauv[rb];
-    for (;;) {
+    {   // the usual episode: everything fits -- one ballot, one rank, the writes
+        const uint64_t bm = __builtin_amdgcn_ballot_w64(hit);
+        const uint32_t n = (uint32_t)__builtin_popcountll(bm);
+        if (scnt + n <= (uint32_t)NREC) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+            if (hit) stage_write<C>(a, scnt + rank, rb, jb, w);
+            scnt += n;
+            return;
+        }
+    }
+    for (;;) {      // more hitting lanes than free records: fill, drain, look again with the new thresholds
         const uint64_t bm = __builtin_amdgcn_ballot_w64(hit);
         if (bm == 0) return;
         const uint32_t room = (uint32_t)NREC - scnt;
@@ -252,17 +288,7 @@ __device__ __forceinline__ void stage_hits(const f32x16 &a, float m, int rb, uin
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
         const bool take = hit && rank < room;
-        if (take) {
-            const uint32_t p = scnt + rank;
-            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * 16);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                f32x4 v;
-                v[0] = a[4 * q4]; v[1] = a[4 * q4 + 1]; v[2] = a[4 * q4 + 2]; v[3] = a[4 * q4 + 3];
-                rp[q4] = v;
-            }
-            C::shdr(w)[p] = make_uint2((uint32_t)(rb * 32 + (lane & 31)) | (0xFFFFu << 8), jb);
-        }
+        if (take) stage_write<C>(a, scnt + rank, rb, jb, w);
         const uint32_t n = (uint32_t)__builtin_popcountll(bm);
         scnt += n < room ? n : room;
         hit = hit && !take;
@@ -298,21 +324,21 @@ __device__ __forceinline__ void lists_flush(unsigned char *w, uint32_t scnt, int
 #ifdef NABO_LISTS_PROF
     if (lane < 8) atomicAdd(&nabo_lists_prof[lane], (unsigned long long)C::prof(w)[lane]);
 #endif
+    const uint2 *rows = C::rows(w);
     for (int row = 0; row < C::NROWS; ++row) {
-        float key[EPL];
-        uint32_t val[EPL];
-        compact_row<C, EPL>(w, row, lkeep, key, val);
-        const float t_row = C::tauL(w)[row];
+        // kept entries in list order (unsorted: refine.hip orders candidates by their exact distances anyway)
         const int64_t o = ((lrow0 + row) * S + split) * (int64_t)LMAX;
 #pragma unroll
         for (int r = 0; r < EPL; ++r) {
             const uint32_t e = (uint32_t)(r * 64 + lane);
             if (e < (uint32_t)LMAX) {
-                cand_idx[o + e] = e < (uint32_t)lkeep ? val[r] : 0xFFFFFFFFu;
-                if (cand_key) cand_key[o + e] = e < (uint32_t)lkeep ? key[r] : __builtin_inff();
+                uint2 v = make_uint2(__float_as_uint(__builtin_inff()), 0xFFFFFFFFu);
+                if (e < (uint32_t)lkeep) v = rows[row * C::ROW + e];
+                cand_idx[o + e] = v.y;
+                if (cand_key) cand_key[o + e] = __uint_as_float(v.x);
             }
         }
-        if (lane == 0) cand_tau[(lrow0 + row) * S + split] = t_row;
+        if (lane == 0) cand_tau[(lrow0 + row) * S + split] = C::tauL(w)[row];
     }
 }
 

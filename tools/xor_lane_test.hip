@@ -18,28 +18,29 @@ __global__ void kx(const int *in, int *out)
     out[5 * 64 + threadIdx.x] = xor_lane_i32(v, 32);
 }
 
-template <int EPL, typename K>
+template <int EPL, typename K, bool FAST>
 __global__ void ks(const K *kin, const uint32_t *vin, K *kout, uint32_t *vout)
 {
     K key[EPL];
     uint32_t val[EPL];
     for (int r = 0; r < EPL; ++r) { key[r] = kin[blockIdx.x * 64 * EPL + r * 64 + threadIdx.x]; val[r] = vin[blockIdx.x * 64 * EPL + r * 64 + threadIdx.x]; }
-    wave_bitonic_sort<EPL, K>(key, val);
+    if constexpr (FAST) wave_sort_f32<EPL>(key, val);
+    else wave_bitonic_sort<EPL, K>(key, val);
     for (int r = 0; r < EPL; ++r) { kout[blockIdx.x * 64 * EPL + r * 64 + threadIdx.x] = key[r]; vout[blockIdx.x * 64 * EPL + r * 64 + threadIdx.x] = val[r]; }
 }
 
-template <int EPL, typename K>
+template <int EPL, typename K, bool FAST = false>
 static int check_sort(const char *name)
 {
     const int B = 200, N = 64 * EPL;
     std::vector<K> k(B * N), ko(B * N);
     std::vector<uint32_t> v(B * N), vo(B * N);
     unsigned s = 12345;
-    for (int i = 0; i < B * N; ++i) { s = s * 1664525u + 1013904223u; k[i] = (K)((s >> 20) % 97) - 40; v[i] = (uint32_t)(i % N) * 7919u % 1000u; }   // many ties
+    for (int i = 0; i < B * N; ++i) { s = s * 1664525u + 1013904223u; k[i] = (K)((s >> 20) % 97) - 40; if ((s >> 9) % 50 == 0) k[i] = (K)__builtin_inff(); if ((s >> 11) % 60 == 0) k[i] = -k[i] * (K)1e30; v[i] = (uint32_t)(i % N) * 7919u % 1000u; }   // many ties
     K *dk, *dko; uint32_t *dv, *dvo;
     hipMalloc(&dk, sizeof(K) * B * N); hipMalloc(&dko, sizeof(K) * B * N); hipMalloc(&dv, 4 * B * N); hipMalloc(&dvo, 4 * B * N);
     hipMemcpy(dk, k.data(), sizeof(K) * B * N, hipMemcpyHostToDevice); hipMemcpy(dv, v.data(), 4 * B * N, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL((ks<EPL, K>), dim3(B), dim3(64), 0, 0, dk, dv, dko, dvo);
+    hipLaunchKernelGGL((ks<EPL, K, FAST>), dim3(B), dim3(64), 0, 0, dk, dv, dko, dvo);
     hipMemcpy(ko.data(), dko, sizeof(K) * B * N, hipMemcpyDeviceToHost); hipMemcpy(vo.data(), dvo, 4 * B * N, hipMemcpyDeviceToHost);
     int bad = 0;
     for (int b = 0; b < B; ++b) {
@@ -69,6 +70,8 @@ int main()
     }
     bad += check_sort<1, float>("sort 64 float");
     bad += check_sort<2, float>("sort 128 float");
+    bad += check_sort<1, float, true>("fast sort 64 float");
+    bad += check_sort<2, float, true>("fast sort 128 float");
     bad += check_sort<1, double>("sort 64 double");
     bad += check_sort<4, double>("sort 256 double");
     printf(bad ? "FAILED\n" : "ok\n");
