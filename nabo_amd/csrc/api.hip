@@ -79,10 +79,10 @@ hipError_t cbf_filter_launch(int gp, int epl, const float *xq, const void *xh, i
                              const void *ych, int64_t n, int g, const uint8_t *mask, int S, uint32_t *cand_idx,
                              float *cand_tau, hipStream_t st);
 hipError_t cbf_pack_refs_rows_launch(const double *Y, int64_t n, int g, int gp, float *yrow, hipStream_t st);
-hipError_t cbf_colmax_launch(const double *Y, int64_t n, int g, unsigned int *colmax, hipStream_t st);
-hipError_t cbf_pack_refs16_launch(const double *Y, int64_t n, int g, int gp, const double *scale, void *ych, hipStream_t st);
-hipError_t cbf_pack_targets16_launch(const double *X, int64_t m, int g, int gp, double f, const double *scale, void *xh,
-                                     hipStream_t st);
+hipError_t cbf_colminmax_launch(const double *Y, int64_t n, int g, unsigned int *colmm, hipStream_t st);
+hipError_t cbf_pack_refs8_launch(const double *Y, int64_t n, int g, int gp, const double *quant, void *ych, hipStream_t st);
+hipError_t cbf_pack_targets8_launch(const double *X, int64_t m, int g, int gp, double f, const double *quant, void *xh,
+                                    hipStream_t st);
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
 hipError_t iota_launch(uint32_t *out, int64_t n, hipStream_t st);
 hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
@@ -209,7 +209,7 @@ struct nabo_index {
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
     double ymax_sqrt = 0.0, ymax_sqrt_c = 0.0;
     // Canberra path: exact kernel operands (yt) and the fp32 lower-bound filter's (ycf)
-    DevBuf yt, ycf, yrow, cbflag, ych, cbscale, xh;    // ych/xh: packed f16 operands of the counting pass, cbscale [g] doubles
+    DevBuf yt, ycf, yrow, cbflag, ych, cbscale, xh;    // ych/xh: 7-bit operands of the counting pass, cbscale [2g] doubles (min, 1/step)
     int cb_gp = 0;
     bool cb_f32 = false;          // filter usable for these references (fits fp32, g <= 128)
 
@@ -450,28 +450,33 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
             HIP_TRY(hipStreamSynchronize(st));
             ix->cb_f32 = (flag == 0);
             if (ix->cb_f32) {
-                // per-dimension power-of-two scales for the f16 counting pass: max |s_k y_k| in (2^7, 2^8]
-                std::vector<unsigned int> cm((size_t)ix->g, 0u);
-                std::vector<double> sc((size_t)ix->g, 1.0);
-                if ((rc = ix->cbscale.reserve((size_t)ix->g * sizeof(double)))) return rc;
-                HIP_TRY(hipMemsetAsync(ix->cbscale.p, 0, (size_t)ix->g * sizeof(unsigned int), st));
-                HIP_TRY(nabo::cbf_colmax_launch(ix->dY, ix->n, ix->g, ix->cbscale.as<unsigned int>(), st));
-                HIP_TRY(hipMemcpyAsync(cm.data(), ix->cbscale.p, (size_t)ix->g * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+                // per-dimension quantisation of the counting pass (canberra_f32.hip): min_k and 127 / (max_k - min_k) over the
+                // references, from fp32 bounds that enclose every float64 value
+                const int G = ix->g;
+                std::vector<unsigned int> cm((size_t)2 * G, 0u);
+                std::vector<double> sc((size_t)2 * G, 0.0);
+                if ((rc = ix->cbscale.reserve((size_t)2 * G * sizeof(double)))) return rc;
+                HIP_TRY(hipMemsetAsync(ix->cbscale.p, 0xFF, (size_t)G * sizeof(unsigned int), st));
+                HIP_TRY(hipMemsetAsync(ix->cbscale.as<unsigned int>() + G, 0, (size_t)G * sizeof(unsigned int), st));
+                HIP_TRY(nabo::cbf_colminmax_launch(ix->dY, ix->n, G, ix->cbscale.as<unsigned int>(), st));
+                HIP_TRY(hipMemcpyAsync(cm.data(), ix->cbscale.p, (size_t)2 * G * sizeof(unsigned int), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                for (int k = 0; k < ix->g; ++k) {
-                    float mx;
-                    memcpy(&mx, &cm[k], sizeof(mx));
-                    if (mx > 0.0f && std::isfinite(mx)) {
-                        int e = 8 - (int)std::ceil(std::log2((double)mx) + 1e-9);
-                        if (e > 120) e = 120;
-                        if (e < -120) e = -120;
-                        sc[k] = std::ldexp(1.0, e);
-                    }
+                for (int k = 0; k < G; ++k) {
+                    auto unord = [](unsigned int u) {
+                        const unsigned int b = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+                        float f;
+                        memcpy(&f, &b, sizeof(f));
+                        return (double)f;
+                    };
+                    const double lo = unord(cm[(size_t)k]), hi = unord(cm[(size_t)G + k]);
+                    sc[(size_t)k] = std::isfinite(lo) ? lo : 0.0;
+                    sc[(size_t)G + k] = (std::isfinite(lo) && std::isfinite(hi) && hi > lo && std::isfinite(127.0 / (hi - lo)))
+                                            ? 127.0 / (hi - lo) : 0.0;              // 0: constant column, never counted as out
                 }
-                HIP_TRY(hipMemcpyAsync(ix->cbscale.p, sc.data(), (size_t)ix->g * sizeof(double), hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(ix->cbscale.p, sc.data(), (size_t)2 * G * sizeof(double), hipMemcpyHostToDevice, st));
                 if ((rc = ix->ych.reserve((size_t)chunks * 64 * ix->cb_gp * 2))) return rc;
                 HIP_TRY(nabo::cbf_pack_refs_rows_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->yrow.as<float>(), st));
-                HIP_TRY(nabo::cbf_pack_refs16_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
+                HIP_TRY(nabo::cbf_pack_refs8_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
                 HIP_TRY(hipStreamSynchronize(st));      // sc goes out of scope
             }
         }
@@ -835,7 +840,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // fp32 lower-bound filter -> float64 refine + certification -> exact re-solve of uncertified rows
             float slack, plateau;
             nabo::cbf_constants(g, &slack, &plateau);
-            snprintf(ix->kernel, sizeof(ix->kernel), "cbf_filter_kernel<%d> (packed-f16 count + fp32 lower bound)", ix->cb_gp);
+            snprintf(ix->kernel, sizeof(ix->kernel), "cbf_filter_kernel<%d> (7-bit integer count + fp32 lower bound)", ix->cb_gp);
             // filter geometry: T rows per workgroup, 2 workgroups per CU resident; every (row, split) ends
             // with `lists` candidate lists (one per wave).  Splits fill the chip when there are few rows and
             // trim the last, partially filled round of workgroups when there are many.
@@ -882,7 +887,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const int64_t rows_main = gx_tail > 0 ? gx_main * rpw : m;          // rows of the main launch
             const int64_t rows_tail = m - rows_main;
             if ((rc = ix->xpk.reserve((size_t)m * ix->cb_gp * 2 * sizeof(float)))) return rc;
-            if ((rc = ix->xh.reserve((size_t)m * ix->cb_gp * 4))) return rc;
+            if ((rc = ix->xh.reserve((size_t)m * ix->cb_gp * 2))) return rc;
             if ((rc = ix->cand_idx.reserve((size_t)rows_main * SL * L * sizeof(uint32_t)))) return rc;
             if ((rc = ix->cand_tau.reserve((size_t)rows_main * SL * sizeof(float) + 16))) return rc;
             if (rows_tail > 0) {
@@ -895,14 +900,14 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
             unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();
             HIP_TRY(nabo::cbf_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->xpk.as<float>(), d_flag, st));
-            HIP_TRY(nabo::cbf_pack_targets16_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbscale.as<double>(), ix->xh.p, st));
+            HIP_TRY(nabo::cbf_pack_targets8_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbscale.as<double>(), ix->xh.p, st));
             HIP_TRY(hipEventRecord(ix->ev[1], st));
             HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), ix->xh.p, rows_main, ix->yrow.as<float>(),
                                             ix->ych.p, ix->n, g, ix->dmask, Sf, ix->cand_idx.as<uint32_t>(),
                                             ix->cand_tau.as<float>(), st));
             if (rows_tail > 0)
                 HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>() + (size_t)rows_main * ix->cb_gp * 2,
-                                                ix->xh.as<unsigned char>() + (size_t)rows_main * ix->cb_gp * 4, rows_tail,
+                                                ix->xh.as<unsigned char>() + (size_t)rows_main * ix->cb_gp * 2, rows_tail,
                                                 ix->yrow.as<float>(), ix->ych.p, ix->n, g, ix->dmask, S2,
                                                 ix->cand_idx2.as<uint32_t>(), ix->cand_tau2.as<float>(), st));
             HIP_TRY(hipEventRecord(ix->ev[2], st));

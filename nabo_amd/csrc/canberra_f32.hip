@@ -73,103 +73,119 @@ __global__ void cbf_pack_refs_kernel(const double *__restrict__ Y, int64_t n, in
     }
 }
 
-// ---- f16 operands of the counting pass ---------------------------------------------------------------
-// The counting pass only has to PROVE "this dimension is out of window" for as many dimensions as it can; what
-// it cannot prove merely counts as 0.  That tolerates half precision, which buys packed arithmetic (two
-// dimensions per instruction) and four reference chunks per register set.  Every dimension k is scaled by a
-// power of two s_k (exact) chosen from the references so that max_j |s_k y_jk| lies in (2^7, 2^8]:
-//   y' = fl16(s_k y),  x' = fl16(s_k x)          relative error u = 2^-11 (1.001 u is used: the conversion may
-//                                                round twice), absolute 2^-25 below the normal range
-//   d' = fl16(x' - y'),  the kernel counts the dimension when  fma(d', d', -t2) > 0,  t2 = roundup16(thr'^2)
-//   (one rounding of the exact d'^2 - t2, so "> 0" means d'^2 > t2 >= thr'^2, i.e. |d'| > thr'; if d'^2 overflows
-//   f16 while t2 is finite then |d'| > 255.9 >= thr' as well; an overflowing t2 -- |x'| beyond ~4x the column's
-//   reference maximum -- makes the dimension uncountable, never miscounted).
-// With delta = x' - y' (exact): |d'| <= |delta| (1+u);  s|x-y| >= |delta| - u s (|x|+|y|) - 2 eta and
-// |y| <= |x| + |x-y| give  s |x-y| (1+u) >= |delta| - 2 u s |x| - 2 eta.  So with  T+ = fl64(f |x|) (1 + 2^-52)
-// (the reference's own threshold, padded for the rounding of its fl64 |x-y|),
-//   thr' = roundup16( (1+u) ( s T+ (1+u) + 2 u s |x| + 2 eta ) + eta )
-// guarantees  |d'| >= thr'  =>  |x-y| >= T+  =>  the reference's `num < f*|x|` is false: the dimension adds 1.
-// x' or thr' beyond the f16 range become +inf and the dimension is never counted.
-typedef _Float16 cbf_h2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t cbf_f16_up(double v)          // smallest f16 >= v (v >= 0), as bits
+// ---- operands of the counting pass: 7-bit integers, four dimensions per 32-bit word ---------------------------------
+// The counting pass only has to PROVE "this dimension is out of window" for as many dimensions as it can; what it
+// cannot prove merely counts as in-window.  That tolerates coarse arithmetic: every dimension k is quantised on the
+// references' own range, q(y) = floor((y - min_k) / step_k) in [0, 127] (step_k = (max_k - min_k) / 127), and the
+// reference's test  |x - y| >= f |x|  is bracketed by two integers per (target, dimension):
+//   T+  = fl64(f |x|) (1 + 2^-52) (1 + 1e-12)      the reference's own threshold, padded for its fl64 |x - y|
+//   qlo = floor((x - T+ - min_k) / step_k - margin)   q(y) <  qlo  =>  y <  min_k + qlo step_k <= x - T+   =>  out
+//   qhi = ceil ((x + T+ - min_k) / step_k + margin) - 1   q(y) > qhi  =>  y >= min_k + (qhi + 1) step_k >= x + T+  =>  out
+// (margin = 1e-6 (1 + |.|) buckets: far more than the float64 rounding of these expressions and of q(y) itself), both
+// clamped to [0, 127] -- a clamp only ever turns "out" into "cannot tell".  In-window-possible <=> qlo <= q(y) <= qhi.
+// Four dimensions share a word, one byte each with bit 7 as a guard:
+//   references   yg = q | 0x80,   yc = (127 - q) | 0x80        (two planes per chunk)
+//   targets      lo = qlo,        hc = 127 - qhi
+//   A = yg - lo   has bit 7 of a byte set  <=>  q >= qlo       (128 + q - qlo >= 1: no borrow crosses a byte)
+//   B = yc - hc   has bit 7 set            <=>  q <= qhi
+//   in-window dimensions of the word = popcount(A & B & 0x80808080)
+// i.e. v_sub_u32, v_sub_u32, v_bitop3_b32, v_bcnt_u32_b32 (accumulating) per FOUR dimensions and 64 references:
+// 1.0 vector instruction per pair and dimension, exact integer arithmetic, where the packed-f16 form of the first
+// version (v_pk_add, v_pk_fma clamp, v_dot2c per TWO dimensions) needed 1.5.  Padding dimensions are always in-window
+// (q = 0, lo = 0, hc = 0).
+__device__ __forceinline__ unsigned int cbf_ord(float v)                      // unsigned int that orders like the float
 {
-    if (!(v < 65504.0)) return 0x7C00u;
-    _Float16 h = (_Float16)v;                                     // round to nearest
-    uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, h);
-    if ((double)h < v) ++b;                                       // next representable (0x7BFF + 1 = inf)
-    return b;
+    const unsigned int b = __float_as_uint(v);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-// per-dimension max |y| (bits of a non-negative float order like unsigned integers).  A block reduces 256 rows in LDS
-// and issues one global atomic per column (one per ELEMENT took 37 ms at 1M x 50: 1 % of a mod-Canberra step).
+// per-dimension min and max of the references as ordered float bits: colmm[k] = min, colmm[g + k] = max (fp32,
+// widened to the enclosing float64 interval by the host).  A block reduces 256 rows in LDS first.
 constexpr int CBF_COLMAX_ROWS = 256;
-__global__ __launch_bounds__(256) void cbf_colmax_kernel(const double *__restrict__ Y, int64_t n, int g,
-                                                         unsigned int *__restrict__ colmax)
+__global__ __launch_bounds__(256) void cbf_colminmax_kernel(const double *__restrict__ Y, int64_t n, int g,
+                                                            unsigned int *__restrict__ colmm)
 {
-    extern __shared__ unsigned int smax[];
-    for (int k = threadIdx.x; k < g; k += blockDim.x) smax[k] = 0u;
+    extern __shared__ unsigned int smm[];                  // [g] min | [g] max
+    for (int k = threadIdx.x; k < g; k += blockDim.x) { smm[k] = 0xFFFFFFFFu; smm[g + k] = 0u; }
     __syncthreads();
     const int64_t e0 = (int64_t)blockIdx.x * CBF_COLMAX_ROWS * g;
     int64_t cnt = (n - (int64_t)blockIdx.x * CBF_COLMAX_ROWS) * g;
     if (cnt > (int64_t)CBF_COLMAX_ROWS * g) cnt = (int64_t)CBF_COLMAX_ROWS * g;
     for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const float v = fabsf((float)Y[e0 + i]);
-        if (v > 0.0f) atomicMax(&smax[(e0 + i) % g], __float_as_uint(v < 3e38f ? v : 3e38f));
+        const double y = Y[e0 + i];
+        float lo = (float)y, hi = lo;                      // enclose y: round-to-nearest may land on either side
+        if ((double)lo > y) lo = nextafterf(lo, -__builtin_inff());
+        if ((double)hi < y) hi = nextafterf(hi, __builtin_inff());
+        if (lo == lo && hi == hi) {
+            atomicMin(&smm[(e0 + i) % g], cbf_ord(lo));
+            atomicMax(&smm[g + (e0 + i) % g], cbf_ord(hi));
+        }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < g; k += blockDim.x)
-        if (smax[k]) atomicMax(&colmax[k], smax[k]);
+    for (int k = threadIdx.x; k < g; k += blockDim.x) {
+        atomicMin(&colmm[k], smm[k]);
+        atomicMax(&colmm[g + k], smm[g + k]);
+    }
 }
 
-// refs: ych[chunk][p][64] = half2(y'_{2p}, y'_{2p+1}); targets: xh[row][p] = (half2 x', half2 thr')
-__global__ void cbf_pack_refs16_kernel(const double *__restrict__ Y, int64_t n, int g, int gp,
-                                       const double *__restrict__ scale, uint32_t *__restrict__ ych)
+// refs: ych[(chunk * W + w) * 2 + plane][64], W = gp / 4 words; quant[k] = min_k, quant[g + k] = 1 / step_k (0: constant column)
+__global__ void cbf_pack_refs8_kernel(const double *__restrict__ Y, int64_t n, int g, int gp,
+                                      const double *__restrict__ quant, uint32_t *__restrict__ ych)
 {
     const int64_t chunk = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int64_t j = chunk * 64 + lane;
-    for (int p = threadIdx.x >> 6; p < gp / 2; p += (blockDim.x >> 6)) {
-        uint32_t w = 0;
+    const int W = gp / 4;
+    for (int w = threadIdx.x >> 6; w < W; w += (blockDim.x >> 6)) {
+        uint32_t yg = 0x80808080u, yc = 0x80808080u;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 2 * p + h;
-            double v = (j < n && k < g) ? Y[j * g + k] * scale[k] : 0.0;
-            if (!(fabs(v) < 65000.0)) v = v > 0 ? 65000.0 : (v < 0 ? -65000.0 : 0.0);   // cannot happen for finite input
-            w |= (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)v) << (16 * h);
+        for (int b = 0; b < 4; ++b) {
+            const int k = 4 * w + b;
+            int q = 0;
+            if (j < n && k < g) {
+                double u = (Y[j * g + k] - quant[k]) * quant[g + k];
+                u = u < 0.0 ? 0.0 : (u > 127.0 ? 127.0 : u);          // (NaN stays out of range checks: flagged elsewhere)
+                q = (int)u;
+                q = q < 0 ? 0 : (q > 127 ? 127 : q);
+            }
+            yg |= (uint32_t)q << (8 * b);
+            yc |= (uint32_t)((k < g ? 127 : 0) - (k < g ? q : 0)) << (8 * b);
         }
-        ych[(chunk * (gp / 2) + p) * 64 + lane] = w;
+        ych[((chunk * W + w) * 2 + 0) * 64 + lane] = yg;
+        ych[((chunk * W + w) * 2 + 1) * 64 + lane] = yc;
     }
 }
 
-__global__ void cbf_pack_targets16_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
-                                          const double *__restrict__ scale, uint2 *__restrict__ xh)
+// targets: xh[row][w] = (lo word, hc word)
+__global__ void cbf_pack_targets8_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
+                                         const double *__restrict__ quant, uint2 *__restrict__ xh)
 {
+    const int W = gp / 4;
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m * (gp / 2)) return;
-    const int64_t row = e / (gp / 2);
-    const int p = (int)(e - row * (gp / 2));
-    // 2^-11 (+0.1 %: a double -> f16 conversion may round twice, through fp32) and 2^-25
-    const double u = 4.8828125e-4 * 1.001, eta = 2.98023223876953125e-8;
-    uint32_t xw = 0, tw = 0;
+    if (e >= m * W) return;
+    const int64_t row = e / W;
+    const int w = (int)(e - row * W);
+    uint32_t lw = 0, hw = 0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int k = 2 * p + h;
-        uint32_t xb = 0, tb = 0x7C00u;                                             // padding: x' = 0, thr' = +inf
+    for (int b = 0; b < 4; ++b) {
+        const int k = 4 * w + b;
+        int lo = 0, hc = 0;                                   // padding / "cannot tell": always in-window
         if (k < g) {
-            const double x = X[row * g + k], sc = scale[k];
-            const double sx = x * sc;
-            if (fabs(sx) < 65000.0) {
-                xb = (uint32_t)__builtin_bit_cast(unsigned short, (_Float16)sx);
-                const double tp = (f * fabs(x)) * (1.0 + 2.3e-16);                   // T+
-                const double thr = (1.0 + u) * (sc * tp * (1.0 + u) + 2.0 * u * fabs(sx) + 2.0 * eta) + eta;
-                tb = cbf_f16_up(thr * thr * (1.0 + 1e-12));                         // the kernel compares d'^2 with thr'^2
-            }                                                                       // else: x' = 0 with thr' = inf (never counted)
+            const double x = X[row * g + k], inv = quant[g + k];
+            const double tp = (f * fabs(x)) * (1.0 + 2.3e-16) * (1.0 + 1e-12);             // T+
+            if (inv > 0.0 && tp == tp && tp < 1e300) {
+                const double u = (x - tp - quant[k]) * inv, v = (x + tp - quant[k]) * inv;
+                double ql = floor(u - 1e-6 * (1.0 + fabs(u)));
+                double qh = ceil(v + 1e-6 * (1.0 + fabs(v))) - 1.0;
+                ql = ql < 0.0 ? 0.0 : (ql > 127.0 ? 127.0 : ql);
+                qh = qh < 0.0 ? 0.0 : (qh > 127.0 ? 127.0 : qh);
+                if (ql == ql && qh == qh) { lo = (int)ql; hc = 127 - (int)qh; }
+            }
         }
-        xw |= xb << (16 * h);
-        tw |= tb << (16 * h);
+        lw |= (uint32_t)lo << (8 * b);
+        hw |= (uint32_t)hc << (8 * b);
     }
-    xh[e] = make_uint2(xw, tw);
+    xh[e] = make_uint2(lw, hw);
 }
 
 // row-major fp32 copy of the references ([n][gp], zero padded) for the bound pass: a lane that evaluates one
@@ -227,7 +243,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
                        float plateau, uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau, int dbg)
 {
     constexpr int L = 32 * EPL, CAP = L + 16 * EPL;     // kept + pending entries per list
-    constexpr int GH = GP / 2;           // packed dimension pairs
+    constexpr int GH = GP / 4;           // packed words: four dimensions each
     constexpr int GHS = GH + 1;          // LDS row stride (uint2): spreads the T rows over the banks
     constexpr int WLN = 512;             // work-list ring (entries); >= 63 + 64 * NCH
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -253,7 +269,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
     for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); cnt[e] = 0; }
     for (int e = lane; e < T * GH; e += 64) {
         const int64_t row = row0 + e / GH;
-        xs[(e / GH) * GHS + e % GH] = row < m ? xh[row * GH + e % GH] : make_uint2(0u, 0x7C007C00u);
+        xs[(e / GH) * GHS + e % GH] = row < m ? xh[row * GH + e % GH] : make_uint2(0u, 0u);
     }
     for (int e = lane; e < T * GP; e += 64) {
         const int64_t row = row0 + e / GP;
@@ -343,9 +359,8 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
     const int64_t c_begin = split * chunks_per_split;
     int64_t c_end = c_begin + chunks_per_split;
     if (c_end > n_chunks) c_end = n_chunks;
-    const cbf_h2 one2 = {(_Float16)1.0f, (_Float16)1.0f};
     for (int64_t chunk0 = c_begin; chunk0 < c_end; chunk0 += NCH) {
-        cbf_h2 yv[NCH][GH];
+        uint32_t yv[NCH][2 * GH];                               // (yg, yc) words of NCH chunks, lane = reference
         uint64_t vmask[NCH];                                    // live (in range, not ignored) references of each chunk
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -353,48 +368,40 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
             const int64_t j = chunk * 64 + lane;
             vmask[c] = __builtin_amdgcn_ballot_w64((chunk < c_end) && (j < n) && !(mask && mask[j]));
 #pragma unroll
-            for (int p = 0; p < GH; ++p)
-                yv[c][p] = __builtin_bit_cast(cbf_h2, (chunk < c_end) ? ych[(chunk * GH + p) * 64 + lane] : 0u);
+            for (int p = 0; p < 2 * GH; ++p)
+                yv[c][p] = (chunk < c_end) ? ych[(chunk * 2 * GH + p) * 64 + lane] : 0x80808080u;
         }
 
         for (int t = 0; t < t_cnt; ++t) {
             const uint2 *xr = xs + t * GHS;               // same address in every lane: LDS broadcast
-            float acc[NCH];
+            uint32_t inw[NCH];                            // dimensions that may be in-window (padding included)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) acc[c] = 0.0f;
+            for (int c = 0; c < NCH; ++c) inw[c] = 0u;
 #pragma unroll
             for (int p = 0; p < GH; ++p) {
-                const uint2 xt = xr[p];
-                const cbf_h2 xv = __builtin_bit_cast(cbf_h2, xt.x);
-                const cbf_h2 th = __builtin_bit_cast(cbf_h2, xt.y);
-                cbf_h2 d[NCH], ind[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) d[c] = xv - yv[c][p];
+                const uint2 xt = xr[p];                   // (lo word, hc word)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
-                    ind[c] = __builtin_elementwise_fma(d[c], d[c], -th);                      // d'^2 - thr'^2, ONE rounding
-                    ind[c] = __builtin_elementwise_min(__builtin_elementwise_max(ind[c], (cbf_h2){0, 0}), one2);
-                }                                                                             // (+inf - +inf = NaN -> 0)
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) acc[c] = __builtin_amdgcn_fdot2(ind[c], one2, acc[c], false);
+                    const uint32_t a = yv[c][2 * p] - xt.x, b = yv[c][2 * p + 1] - xt.y;
+                    inw[c] += (uint32_t)__builtin_popcount(__builtin_amdgcn_bitop3_b32(a, b, 0x80808080u, 0x80));
+                }
             }
-            // Survivor test, ONE compare per chunk.  acc <= proven-out dimensions (fp32 sum of g terms in [0,1],
-            // rounding < 1e-3), so the pair's distance is >= acc - 1e-3; the list key of a pair is
-            //     pre = (acc == g) ? plateau : min(acc - 1e-3 - slack, below_plateau)
-            // and the pair can be dropped when pre >= tau.  `acc < t1` with t1 = tau + 1e-3 + slack (+2e-5 for the
-            // roundings of the subtraction chain, rounded up) keeps a SUPERSET of {pre < tau} (acc == g: pre < tau
-            // means tau > g - slack, so t1 > g; acc != g: either acc - 1e-3 - slack < tau, or tau > below_plateau and
-            // then t1 > g >= acc): a few pairs on the boundary survive needlessly, pass 2 evaluates their exact key
-            // and applies `key < tau` itself.  The per-chunk form (select, subtract, min, compare, and, ballot, branch)
-            // cost 27 % of this kernel's vector instructions (rocprofv3 SQ_INSTS_VALU, profiles/).
+            // Survivor test, ONE compare per chunk.  n_out = GP - inw dimensions are PROVEN out of window, each adds
+            // exactly 1 to the reference's distance and the others add >= 0: distance >= n_out.  A pair is dropped when
+            // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. when inw <= GP - t1; the list key of a pair,
+            //     (all g dimensions out) ? plateau : min(lower bound - slack, below_plateau),
+            // is then >= tau as well (key >= n_out - slack for the first form, and the second only arises for tau <=
+            // plateau).  Pairs on the boundary survive needlessly; pass 2 evaluates their key and applies `key < tau`.
             const float tau_t = tau[t];
-            float t1 = tau_t + (1e-3f + 2e-5f + slack);
+            float t1 = tau_t + (2e-5f + slack);
             t1 = __uint_as_float(__float_as_uint(t1) + (t1 < __builtin_inff() ? 1u : 0u));       // next float up (tau_t > 0)
+            const float need = (float)GP - t1;                 // survivors have inw > need
+            const uint32_t thr_in = need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;         // (t1 = +inf: need = -inf)
             uint64_t sm[NCH];
             uint64_t any = 0;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
-                sm[c] = __builtin_amdgcn_ballot_w64(acc[c] < t1) & vmask[c];
+                sm[c] = __builtin_amdgcn_ballot_w64(inw[c] >= thr_in) & vmask[c];
                 any |= sm[c];
             }
             if (any != 0 && !(dbg & 1)) {
@@ -486,7 +493,7 @@ static hipError_t cbf_launch_one(const float *xq, const void *xh, int64_t m, con
     const int64_t cps = (n_chunks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)T * (GP / 2 + 1) * 8 + (size_t)T * (GP + 1) * 8 + (size_t)T * CAP * 8 + (size_t)T * 8 + 512 * 5;
+    const size_t lds = (size_t)T * (GP / 4 + 1) * 8 + (size_t)T * (GP + 1) * 8 + (size_t)T * CAP * 8 + (size_t)T * 8 + 512 * 5;
     auto kern = &cbf_filter_kernel<GP, EPL, T, NCH>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
@@ -502,10 +509,10 @@ static hipError_t cbf_launch_one(const float *xq, const void *xh, int64_t m, con
 // target rows per workgroup (the caller's split heuristic needs it)
 int cbf_rows_per_wg(int epl) { return epl == 1 ? cbf_t_rows(1) : cbf_t_rows(2); }
 
-hipError_t cbf_colmax_launch(const double *Y, int64_t n, int g, unsigned int *colmax, hipStream_t st)
+hipError_t cbf_colminmax_launch(const double *Y, int64_t n, int g, unsigned int *colmm, hipStream_t st)
 {
     const int64_t blocks = (n + CBF_COLMAX_ROWS - 1) / CBF_COLMAX_ROWS;
-    hipLaunchKernelGGL(cbf_colmax_kernel, dim3((unsigned)blocks), dim3(256), (size_t)g * sizeof(unsigned int), st, Y, n, g, colmax);
+    hipLaunchKernelGGL(cbf_colminmax_kernel, dim3((unsigned)blocks), dim3(256), (size_t)2 * g * sizeof(unsigned int), st, Y, n, g, colmm);
     return hipGetLastError();
 }
 
@@ -516,20 +523,20 @@ hipError_t cbf_pack_refs_rows_launch(const double *Y, int64_t n, int g, int gp, 
     return hipGetLastError();
 }
 
-hipError_t cbf_pack_refs16_launch(const double *Y, int64_t n, int g, int gp, const double *scale, void *ych, hipStream_t st)
+hipError_t cbf_pack_refs8_launch(const double *Y, int64_t n, int g, int gp, const double *quant, void *ych, hipStream_t st)
 {
     const int64_t chunks = (n + 63) / 64;
-    hipLaunchKernelGGL(cbf_pack_refs16_kernel, dim3((unsigned)chunks), dim3(256), 0, st, Y, n, g, gp, scale,
+    hipLaunchKernelGGL(cbf_pack_refs8_kernel, dim3((unsigned)chunks), dim3(256), 0, st, Y, n, g, gp, quant,
                        reinterpret_cast<uint32_t *>(ych));
     return hipGetLastError();
 }
 
-hipError_t cbf_pack_targets16_launch(const double *X, int64_t m, int g, int gp, double f, const double *scale, void *xh,
-                                     hipStream_t st)
+hipError_t cbf_pack_targets8_launch(const double *X, int64_t m, int g, int gp, double f, const double *quant, void *xh,
+                                    hipStream_t st)
 {
-    const int64_t tot = m * (gp / 2);
-    hipLaunchKernelGGL(cbf_pack_targets16_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, m, g, gp, f,
-                       scale, reinterpret_cast<uint2 *>(xh));
+    const int64_t tot = m * (gp / 4);
+    hipLaunchKernelGGL(cbf_pack_targets8_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, m, g, gp, f,
+                       quant, reinterpret_cast<uint2 *>(xh));
     return hipGetLastError();
 }
 

@@ -178,10 +178,10 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
         if (qm != 0) {
             const float t = tauL[row];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
+            for (int q4 = 3; q4 >= 0; --q4) {
                 const f32x4 v = rp[q4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) q |= (v[e] < t) ? (1u << (4 * q4 + e)) : 0u;
+                for (int e = 3; e >= 0; --e) q = q + q + (v[e] < t ? 1u : 0u);       // bit 4 q4 + e
             }
             q &= qm;
         }
@@ -192,19 +192,18 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
 #ifdef NABO_LISTS_PROF
         if (c > 0) atomicAdd(&C::prof(w)[7], (uint32_t)c);
 #endif
-        if (c > 0) {
+        {   // write my qualifying scores, lowest register first: as many rounds as the busiest lane has entries
+            // (usually one or two) instead of sixteen predicated blocks
             uint2 *pend = rows + row * C::ROW + lkeep;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 v = rp[q4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int i = 4 * q4 + e;
-                    if ((q >> i) & 1u) {
-                        if (slot < (uint32_t)P) pend[slot] = make_uint2(__float_as_uint(v[e]), jb + (uint32_t)((i & 3) + 8 * (i >> 2)));
-                        else left |= 1u << i;
-                        ++slot;
-                    }
+            const float *rf = reinterpret_cast<const float *>(rp);
+            uint32_t todo = q;
+            while (__builtin_amdgcn_ballot_w64(todo != 0) != 0) {
+                if (todo != 0) {
+                    const int i = __builtin_ctz(todo);
+                    todo &= todo - 1;
+                    if (slot < (uint32_t)P) pend[slot] = make_uint2(__float_as_uint(rf[i]), jb + (uint32_t)((i & 3) + 8 * (i >> 2)));
+                    else left |= 1u << i;
+                    ++slot;
                 }
             }
         }
