@@ -612,9 +612,9 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         const int epl_launch = r1 ? -1 : epl;
         if (!ix->wide_retry) {
             if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
-            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,35> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
+            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
             else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
-                          r1 ? 1 : (epl == 1 ? 2 : 1), epl, r1 ? 41 : epl == 1 ? 35 : 71);
+                          r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 33 : 65);
         }
         if ((rc = ensure_packed(ix, use_h))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once

@@ -159,7 +159,8 @@ __device__ __forceinline__ f32x16 mfma_chain(RefTile<KSTEPS> &y, const float (&x
 // cand_idx/cand_key: [rows_launch][S][LMAX], cand_tau: [rows_launch][S] (rows local to the launch).
 // Two waves per SIMD need <= 256 VGPRs; that holds while the resident target fragments
 // (R*KSTEPS registers) stay <= 64 -- larger shapes run one wave per SIMD without spilling.
-constexpr int L2_NREC = 20;         // staging records per wave (topk_lists.h)
+// staging records per wave (topk_lists.h): what the 80 KB (53 KB at three workgroups per CU) leave beside the rows
+__host__ __device__ constexpr int l2_nrec(int r, int epl) { return epl == 2 ? 40 : r == 2 ? 36 : 32; }
 
 template <int KSTEPS, int R, int EPL, int ROWN>
 __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS <= 64 ? 2 : 1)) void l2_topk_kernel(const float *__restrict__ Xpk,
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS
                                                                                   float *__restrict__ cand_tau,
                                                                                   int dbg /* ablation, 0 in production */)
 {
+    constexpr int L2_NREC = l2_nrec(R, EPL);
     using C = ListCfg<EPL, ROWN, R, L2_NREC>;
     constexpr int QTF = qtile_floats(KSTEPS);
     constexpr int RTF = rtile_floats(KSTEPS);
@@ -245,7 +247,7 @@ static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_s
                              int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
     static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
-    const size_t lds = (size_t)4 * ListCfg<EPL, ROWN, R, L2_NREC>::BYTES;
+    const size_t lds = (size_t)4 * ListCfg<EPL, ROWN, R, l2_nrec(R, EPL)>::BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL, ROWN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -260,13 +262,13 @@ void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu, int
 {
     int R = epl == 1 ? 2 : 1;
     *wg_per_cu = (R * ksteps <= 64) ? 2 : 1;
-    *lkeep_max = epl == 2 ? 64 : 30;                   // row entries 35 (R = 2) / 71 (64-entry lists), >= 5 pending slots
-    if (epl == -1) { R = 1; *wg_per_cu = 3; *lkeep_max = 32; }      // epl = -1: one row-block, three waves per SIMD, rows of 41
+    *lkeep_max = epl == 2 ? 64 : 32;                   // row entries 33 / 65 (64-entry lists)
+    if (epl == -1) { R = 1; *wg_per_cu = 3; }          // epl = -1: one row-block, three waves per SIMD
     *rows_per_wg = 4 * R * 32;
 }
 
 // ksteps must be one of the instantiated values; epl 1 -> lists of <= 32 (R=2), 2 -> <= 64 (R=1).
-// Rows take 35 (71) entries + the per-wave staging area: two workgroups (2 x 80 KB) per CU.
+// Rows take 33 (65) entries + the per-wave staging area: two workgroups (2 x 80 KB) per CU.
 hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx,
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st)
@@ -274,11 +276,11 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
 #define NABO_CASE(KS)                                                                                                 \
     case KS:                                                                                                          \
         if (epl == -1)                                                                                                \
-            return launch_one<KS, 1, 1, 41>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,      \
+            return launch_one<KS, 1, 1, 33>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,      \
                                             cand_tau, st);                                                            \
-        return epl == 1 ? launch_one<KS, 2, 1, 35>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+        return epl == 1 ? launch_one<KS, 2, 1, 33>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st)                                                       \
-                        : launch_one<KS, 1, 2, 71>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
+                        : launch_one<KS, 1, 2, 65>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, \
                                                   cand_tau, st);
     switch (ksteps) {
         NABO_CASE(8)

@@ -28,8 +28,8 @@ namespace nabo {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int L2H_NREC = 28;        // staging records per wave (topk_lists.h)
-constexpr int L2H_ROW = 35;         // list entries per row (odd): 4 waves x (128 rows x 35 entries + staging) = 154 KB
+constexpr int L2H_NREC = 56;        // staging records per wave (topk_lists.h)
+constexpr int L2H_ROW = 33;         // list entries per row (odd): 4 waves x (128 rows x 33 entries + staging) = 154 KB
 constexpr int L2H_LAG = 2;          // a register is refilled this many MFMAs behind its last reader (l2_topk.hip)
 
 // One chain: 32 refs x 32 targets x KC steps.  RELOAD: refill the tile's registers with tile `next` behind their last use.
@@ -189,21 +189,21 @@ static hipError_t hlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
         unsigned long long h[8];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(nabo_lists_prof), sizeof(h));
-        fprintf(stderr, "[lists prof, cumulative] episodes %llu (x16 cyc %llu) drains %llu (x16 cyc %llu) merges %llu (x16 cyc %llu) "
+        fprintf(stderr, "[lists prof, cumulative] episodes %llu (x16 cyc %llu) drains %llu (x16 cyc %llu) rounds %llu (%llu) "
                         "records %llu appended %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     }
 #endif
     return hipGetLastError();
 }
 
-// Instantiated for lists of <= 30 kept entries (k + drop_first <= 26): 4 row-blocks per wave, rows of 35 list entries
+// Instantiated for lists of <= 32 kept entries (k + drop_first <= 28): 4 row-blocks per wave, rows of 33 list entries
 // + staging = 154 KB of LDS, one workgroup per CU.
 void l2h_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 {
     (void)kc;
     *rows_per_wg = 4 * 4 * 32;
     *wg_per_cu = 1;
-    *lkeep_max = L2H_ROW - 5 < 32 ? L2H_ROW - 5 : 32;      // at least 5 pending slots; emitted lists hold 32
+    *lkeep_max = L2H_ROW < 32 ? L2H_ROW : 32;              // emitted lists hold 32
 }
 
 // steps of 16 slots for g components: 3 (g+1) slots, instantiated values only (the packed layout of l2s_topk.hip)

@@ -35,8 +35,8 @@ constexpr int L2S_WAVES = 8;        // waves per workgroup (two per SIMD)
 constexpr int L2S_R = 2;            // row-blocks per wave
 constexpr int L2S_NBUF = 3;         // ring depth (tiles)
 
-constexpr int L2S_NREC = 20;        // staging records per wave (topk_lists.h)
-__host__ __device__ constexpr int l2s_row_entries(int kc) { (void)kc; return 27; }   // list entries per row (odd): LDS budget
+constexpr int L2S_NREC = 32;        // staging records per wave (topk_lists.h)
+__host__ __device__ constexpr int l2s_row_entries(int kc) { (void)kc; return 25; }   // list entries per row (odd): LDS budget
 
 // LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + lane * 16 (cdna_hip_programming.md,
 // "What hipcc does not do": M0 written in the statement that reads it; hipcc does not count this load).
@@ -384,7 +384,7 @@ void l2s_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 {
     *rows_per_wg = L2S_WAVES * L2S_R * 32;
     *wg_per_cu = 1;
-    *lkeep_max = l2s_row_entries(kc) - 5;
+    *lkeep_max = l2s_row_entries(kc) - 1;
 }
 
 hipError_t l2s_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
