@@ -35,7 +35,11 @@ if REPO not in sys.path:
 # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz
 PEAK_F32_MFMA_TFLOPS = 157.3        # v_mfma_f32_32x32x2_f32: 64 flop/clk/SIMD
 PEAK_F16_MFMA_TFLOPS = 2516.6       # v_mfma_f32_32x32x16_f16: 32 cycles per 32x32x16 -> 1024 flop/clk/SIMD (dense)
-PEAK_VALU_GINST = 614.4             # wave64 vector instructions: one per 4 cycles and SIMD (v_add / v_fma / packed f16)
+# vector ISSUE peak for the mod-Canberra counting pass, MEASURED on this part by tools/issue_lab.hip for the pass's own
+# instruction mix (v_sub_u32, v_sub_u32, v_bitop3_b32, v_bcnt_u32_b32 on independent chains, 8 waves per SIMD):
+# 0.263 wave-instructions per clock and SIMD = 646.9 G/s (v_sub / v_bitop3 alone issue at 0.43 per clock, v_bcnt and
+# the packed-f16 kinds at 0.24; the nominal "one per 4 clocks" would be 614.4) -- profiles/r2_issue_lab.txt
+PEAK_VALU_GINST = 646.9
 
 
 def _time_knn(oracle, X, Y, k, metric, threads, budget_s):

@@ -26,7 +26,7 @@ void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu, int
 hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st);
 hipError_t l2h_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           hipStream_t st);
+                           int64_t pad_tile, hipStream_t st);
 void l2h_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 int l2h_pick_kc(int g);
 // f16x3 variant with K-concatenated operands and reference tiles shared per workgroup through an LDS ring (l2s_topk.hip)
@@ -706,11 +706,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if (gx_main > 0)
                 HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
                                               (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
-                                              ix->cand_tau.as<float>(), st));
+                                              ix->cand_tau.as<float>(), ix->ref_tiles_alloc - 1, st));
             if (gx_tail > 0)
                 HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
                                               (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
-                                              ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(), st));
+                                              ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
+                                              ix->ref_tiles_alloc - 1, st));
         } else {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl_launch, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,

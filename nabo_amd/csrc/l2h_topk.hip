@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
                                                           uint32_t *__restrict__ cand_idx,
                                                           float *__restrict__ cand_key,
-                                                          float *__restrict__ cand_tau, int dbg)
+                                                          float *__restrict__ cand_tau, int64_t pad_tile, int dbg)
 {
     using C = ListCfg<EPL, ROWN, R, L2H_NREC>;
     constexpr int TB = KC * 1024;                      // bytes per packed tile (targets and references alike)
@@ -94,11 +94,13 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
+    // Past the split's last tile the stream continues with an all-padding tile (+inf norms: nothing passes the filter),
+    // so the loop below always runs its two steps -- see the note on the loop-head wait.
     // dbg & 2 (timing experiments only, results are garbage): the stream wraps inside a 128-tile window that stays
     // in the XCD's L2 -- the kernel's time without any L2 miss
     auto tile_ptr = [&](int t) {
-        const int tc = t < t_end ? t : t_end - 1;
-        return Ypk + (int64_t)((dbg & 2) ? t_begin + ((tc - t_begin) & 127) : tc) * TB;
+        const int64_t tc = t < t_end ? (int64_t)t : pad_tile;
+        return Ypk + ((dbg & 2) ? (int64_t)(t_begin + ((t - t_begin) & 127)) : tc) * TB;
     };
 
     f16x8 a0[KC], a1[KC];
@@ -107,7 +109,6 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int s = 0; s < KC; ++s) { a0[s] = p0[s * 64 + lane]; a1[s] = p1[s * 64 + lane]; }
     }
-
     f32x16 accP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) accP[r] = __builtin_inff();       // inf < tau is false: nothing pending
@@ -137,9 +138,18 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
         }
         if (R & 1) accP = accA;        // odd R: the pending chain is the one just computed
     };
-    for (int t = t_begin; t < t_end; t += 2) {
+    // The wait hipcc places at the loop head is the strictest over every way into it, and it must be vmcnt(19..10): set
+    // a0's refills done, a1's (issued a few hundred cycles ago) still in flight.  Two ways in used to make it
+    // vmcnt(9..0) -- every second tile then waited for loads just issued, 24 % of the kernel's cycles (found with
+    // GRBM_GUI_ACTIVE per compile-time ablation): the prologue's loads (hipcc interleaves the two sets
+    // and moves them across fences, they are `const __restrict__`), hence the peeled first pair of steps; and an
+    // `if (t + 1 < t_end)` around the second step, which gave the flow graph a path back to the head with one set's
+    // refills outstanding, hence the padding tile.
+    tile_step(a0, t_begin);
+    tile_step(a1, t_begin + 1);
+    for (int t = t_begin + 2; t < t_end; t += 2) {
         tile_step(a0, t);
-        if (t + 1 < t_end) tile_step(a1, t + 1);
+        tile_step(a1, t + 1);                      // t + 1 == t_end: the padding tile
     }
     filter_and_stage<C, EPL, R, L2H_NREC>(accP, R - 1, (uint32_t)((t_end - 1) * 32 + 4 * hh), wl, scnt, lkeep, tauv);
 
@@ -173,7 +183,7 @@ hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre
 template <int KC, int R, int EPL, int ROWN>
 static hipError_t hlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              hipStream_t st)
+                              int64_t pad_tile, hipStream_t st)
 {
     static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
     constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, R, L2H_NREC>::BYTES;
@@ -183,7 +193,7 @@ static hipError_t hlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(256);
     hipLaunchKernelGGL((l2h_topk_kernel<KC, R, EPL, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off,
-                       lkeep, cand_idx, cand_key, cand_tau, dbg);
+                       lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg);
 #ifdef NABO_LISTS_PROF
     {
         unsigned long long h[8];
@@ -218,9 +228,9 @@ int l2h_pick_kc(int g)
 
 hipError_t l2h_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           hipStream_t st)
+                           int64_t pad_tile, hipStream_t st)
 {
-#define NABO_H(KCV) case KCV: return hlaunch_one<KCV, 4, 1, L2H_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
+#define NABO_H(KCV) case KCV: return hlaunch_one<KCV, 4, 1, L2H_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
     switch (kc) {
         NABO_H(2) NABO_H(4) NABO_H(6) NABO_H(8) NABO_H(10) NABO_H(12)
     default: return hipErrorInvalidValue;

@@ -107,9 +107,13 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
     // id and reads the word back to learn WHICH lane's store the LDS kept -- without volatile hipcc forwards the stored
     // value to the load and every contender believes it won; a lane that lost a round must re-read the threshold and
     // the position the winner left behind, not reuse what it loaded a round earlier.
-    volatile float *tauL = C::tauL(w);
-    volatile uint32_t *pmaxL = C::pmax(w);
-    volatile uint32_t *owner = C::owner(w);
+    // (LDS address space spelled out: a volatile access through a generic pointer compiles to flat_load / flat_store,
+    // which count on vmcnt and made every drain wait for the reference-tile loads in flight)
+    typedef __attribute__((address_space(3))) volatile float lds_vf32;
+    typedef __attribute__((address_space(3))) volatile uint32_t lds_vu32;
+    lds_vf32 *tauL = (lds_vf32 *)C::tauL(w);
+    lds_vu32 *pmaxL = (lds_vu32 *)C::pmax(w);
+    lds_vu32 *owner = (lds_vu32 *)C::owner(w);
     const bool mine = (uint32_t)lane < scnt;
     uint32_t row = 0, jb = 0, q = 0;
     const f32x4 *rp = reinterpret_cast<const f32x4 *>(C::srec(w) + (mine ? lane : 0) * 16);

@@ -6,6 +6,7 @@
 // Output: wave-instructions per clock and SIMD at the nominal 2.4 GHz, and G wave-instructions/s for the chip.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdint>
 
 #define REP16(OP)                                                                                                  \
     OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
@@ -43,6 +44,28 @@ __global__ __launch_bounds__(256) void k(int iters, float *out)
 #undef OP
             } else if (KIND == 5) {
 #define OP(i) asm volatile("v_min3_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
+                REP16(OP)
+#undef OP
+            } else if (KIND == 7) {      // the SWAR counting loop of round 2: sub, sub, bitop3, bcnt (accumulating)
+                uint32_t *u32 = reinterpret_cast<uint32_t *>(a);
+                const uint32_t xi = __float_as_uint(x), yi = __float_as_uint(y);
+#define OP(i) asm volatile("v_sub_u32 %0, %2, %1\n\tv_sub_u32 %1, %1, %3\n\tv_bitop3_b32 %0, %0, %1, %4 bitop3:0x80\n\tv_bcnt_u32_b32 %1, %0, %1" \
+                           : "+v"(u32[i]), "+v"(u32[(i + 8) & 15]) : "v"(xi), "v"(yi), "s"(0x80808080u));
+                REP16(OP)
+#undef OP
+            } else if (KIND == 8) {
+                uint32_t *u32 = reinterpret_cast<uint32_t *>(a);
+#define OP(i) asm volatile("v_sub_u32 %0, %1, %0" : "+v"(u32[i]) : "v"(__float_as_uint(x)));
+                REP16(OP)
+#undef OP
+            } else if (KIND == 9) {
+                uint32_t *u32 = reinterpret_cast<uint32_t *>(a);
+#define OP(i) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(u32[i]) : "v"(__float_as_uint(x)));
+                REP16(OP)
+#undef OP
+            } else if (KIND == 10) {
+                uint32_t *u32 = reinterpret_cast<uint32_t *>(a);
+#define OP(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80" : "+v"(u32[i]) : "v"(__float_as_uint(x)), "v"(__float_as_uint(y)));
                 REP16(OP)
 #undef OP
             } else {
@@ -91,5 +114,9 @@ int main()
     run<4>("pk_add + pk_fma(clamp) + dot2c", 3, out);
     run<5>("v_min3_f32", 1, out);
     run<6>("v_pk_fma_f32", 1, out);
+    run<8>("v_sub_u32", 1, out);
+    run<9>("v_bcnt_u32_b32", 1, out);
+    run<10>("v_bitop3_b32", 1, out);
+    run<7>("sub + sub + bitop3 + bcnt (SWAR)", 4, out);
     return 0;
 }

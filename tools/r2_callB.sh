@@ -6,6 +6,7 @@ O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 B="--no-extras --no-cpu-baseline"
 tools/issue_lab.bin > $O/issue_lab.txt 2>&1 || true
+tools/mfma_clock_lab.bin > $O/mfma_clock_lab.txt 2>&1 || true
 echo "issue lab done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_euclid -- python3 bench.py $B --steps 3 --warmup 1 > $O/bench_under_rocprof.json 2> $O/rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_canberra -- python3 bench.py $B --metric canberra --steps 2 --warmup 1 > $O/bench_canberra_under_rocprof.json 2>> $O/rocprof.err
@@ -34,4 +35,4 @@ python bench.py $B --metric cosine --dims 100 --neighbors 50 --steps 2 --warmup 
 for n in 8 4 2; do python tools/check_shard_fullscale.py $n | tail -1 >> $O/shard_fullscale.txt; done
 cat $O/ablate.txt $O/shard_fullscale.txt
 grep -h "l2h_topk\|cbf_filter" $O/pmc_euclid_summary.csv $O/pmc_canberra_summary.csv
-cat $O/issue_lab.txt
+cat $O/issue_lab.txt $O/mfma_clock_lab.txt
