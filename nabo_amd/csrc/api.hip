@@ -32,9 +32,14 @@ int l2h_pick_kc(int g);
 // f16x3 variant with K-concatenated operands and reference tiles shared per workgroup through an LDS ring (l2s_topk.hip)
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
-                            hipStream_t st);
+                            bool layout16, hipStream_t st);
 hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
-                              int64_t ntiles_total, unsigned char *out, double *xnorm, hipStream_t st);
+                              int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st);
+// the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
+hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                           int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           int64_t pad_tile, hipStream_t st);
+void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 hipError_t l2s_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st);
 void l2s_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
@@ -201,6 +206,7 @@ struct nabo_index {
     int mode = 0;
     int kc = 0;
     bool shared = false;
+    bool q16 = false;              // l2q_topk.hip (16x16x32 MFMA shape; operands in the layout16 packing)
     double hscale = 1.0;
     double fscale = 1.0;           // power-of-two input scale of the fp32 path: max |y~| * fscale in (1/2, 1]
     int ksteps = 0;
@@ -272,7 +278,7 @@ static int ensure_packed(nabo_index *ix, bool want_h)
         ix->hscale = scale = std::ldexp(1.0, e2 + 12);
         HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc,
                                        ix->ref_tiles_alloc, ix->dmask, ix->ycpk.as<unsigned char>(),
-                                       ix->normmax.as<unsigned int>(), st));
+                                       ix->normmax.as<unsigned int>(), ix->q16, st));
     } else {
         const int Q = (ix->ksteps + 3) / 4;
         const size_t tile_bytes = ((size_t)Q * 256 + 32) * sizeof(float);
@@ -368,6 +374,9 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
             ix->mode = 1;
             ix->kc = nabo::l2h_pick_kc(g);
             ix->shared = md && strcmp(md, "f16x3s") == 0 && nabo::l2s_pick_kc(g) == ix->kc;
+            // default: the 16x16x32 MFMA shape (l2q_topk.hip; the chip holds a higher clock on it); =f16x3h pins the
+            // 32x32x16 per-wave kernel, =f16x3s the shared-tile one (both use the 32x32 operand layout)
+            ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0));
         }
     }
     int cus = 0;
@@ -585,7 +594,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 nabo::l2s_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
                 use_c = (cand_mode ? kk : kk + 4) <= lkeep_max;
             }
-            if (!use_c) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
+            if (!use_c && ix->q16) nabo::l2q_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
+            else if (!use_c) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
         // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
@@ -612,6 +622,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         const int epl_launch = r1 ? -1 : epl;
         if (!ix->wide_retry) {
             if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
+            else if (use_h && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, K-concatenated f16x3 split)", ix->kc);
             else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
             else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
                           r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 33 : 65);
@@ -688,7 +699,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
         if (use_h)
             HIP_TRY(nabo::pack_cquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->kc, rows_pad / 32,
-                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), st));
+                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), ix->q16, st));
         else
             HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->fscale, ix->ksteps, rows_pad / 32,
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
@@ -702,6 +713,16 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 HIP_TRY(nabo::l2s_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(), (int)tps2, S2,
                                               (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
                                               ix->cand_tau2.as<float>(), st));
+        } else if (use_h && ix->q16) {
+            if (gx_main > 0)
+                HIP_TRY(nabo::l2q_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
+                                              (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
+                                              ix->cand_tau.as<float>(), ix->ref_tiles_alloc - 1, st));
+            if (gx_tail > 0)
+                HIP_TRY(nabo::l2q_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
+                                              (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
+                                              ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
+                                              ix->ref_tiles_alloc - 1, st));
         } else if (use_h) {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),

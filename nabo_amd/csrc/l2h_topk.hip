@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
                                                           float *__restrict__ cand_key,
                                                           float *__restrict__ cand_tau, int64_t pad_tile, int dbg)
 {
-    using C = ListCfg<EPL, ROWN, R, L2H_NREC>;
+    constexpr int NREC = L2H_NREC;
+    using C = ListCfg<EPL, ROWN, R, NREC>;
     constexpr int TB = KC * 1024;                      // bytes per packed tile (targets and references alike)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -82,7 +83,13 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
     for (int rb = 0; rb < R; ++rb) {
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Xpk + (ttile0 + rb) * TB);
 #pragma unroll
-        for (int s = 0; s < KC; ++s) xb[rb][s] = p[s * 64 + lane];
+        for (int s = 0; s < KC; ++s) {
+            xb[rb][s] = p[s * 64 + lane];
+            // The wave's B operands (160 of its ~370 registers, read-only from here on) are pinned in AGPRs, which the
+            // MFMA reads directly.  Left to itself hipcc keeps them in arch VGPRs, runs out, "spills" them to AGPRs
+            // and copies them back before every use: 0.86 v_accvgpr_read per MFMA in the loop.
+            asm volatile("" : "+a"(xb[rb][s]));
+        }
     }
     unsigned char *wl = smem_raw + (size_t)wave * C::BYTES;          // this wave's lists (topk_lists.h)
     float tauv[R];
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
 #ifdef NABO_L2H_NOFILTER          // timing experiments: chains only; the accumulators are kept alive through an empty asm
 #define L2H_FILTER(ACC, RB, JB) asm volatile("" ::"v"(ACC))
 #else
-#define L2H_FILTER(ACC, RB, JB) filter_and_stage<C, EPL, R, L2H_NREC>(ACC, RB, JB, wl, scnt, lkeep, tauv)
+#define L2H_FILTER(ACC, RB, JB) filter_and_stage<C, EPL, R, NREC>(ACC, RB, JB, wl, scnt, lkeep, tauv)
 #endif
     // all R chains of tile t on register set `a`; the last chain refills `a` with tile t+2
     auto tile_step = [&](f16x8(&a)[KC], int t) {
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
         tile_step(a0, t);
         tile_step(a1, t + 1);                      // t + 1 == t_end: the padding tile
     }
-    filter_and_stage<C, EPL, R, L2H_NREC>(accP, R - 1, (uint32_t)((t_end - 1) * 32 + 4 * hh), wl, scnt, lkeep, tauv);
+    filter_and_stage<C, EPL, R, NREC>(accP, R - 1, (uint32_t)((t_end - 1) * 32 + 4 * hh), wl, scnt, lkeep, tauv);
 
     lists_flush<C, EPL, R>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }

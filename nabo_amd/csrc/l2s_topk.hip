@@ -252,12 +252,17 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
 }
 
 // ---- packing ------------------------------------------------------------------------------
-// One wave per 32-cell tile; lane l supplies cell l & 31, slots 16 s + 8 (l >> 5) + j of the concatenated vector.
-// Slot p: segment p / (g+1), entry e = p % (g+1); e < g: component e, e == g: the norm slot.
+// One wave per 32-cell tile.  Slot p of a cell's concatenated vector: segment p / (g+1), entry e = p % (g+1); e < g:
+// component e, e == g: the norm slot.
 //   references  [hi | lo | hi],  norm slots (nh, nl, 0) with nh + nl = ||y~||^2 2^-15 (+inf when masked / padding)
 //   targets     [-2hi | -2hi | -2lo],  norm slots (2^15, 2^15, 0)
 // v = (V - centre) * scale; hi = f16(v), lo = f16(v - hi).  norm64 (targets): ||hi+lo||^2 in UNSCALED units.
-template <bool IS_REF>
+// Register layouts (16 bytes per lane and register, a tile is kc KiB either way):
+//   L16 = false (v_mfma_f32_32x32x16_f16; l2h / l2s kernels): register s < kc, lane l: cell l & 31,
+//                slots 16 s + 8 (l >> 5) + j;
+//   L16 = true  (v_mfma_f32_16x16x32_f16; l2q kernel): register h (kc/2) + s, h < 2, s < kc/2, lane l: cell 16 h + (l & 15),
+//                slots 32 s + 8 (l >> 4) + j.
+template <bool IS_REF, bool L16>
 __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restrict__ V, int64_t ncell, int g,
                                                          const double *__restrict__ centre, double scale, int kc,
                                                          int64_t ntiles_total, const uint8_t *__restrict__ mask,
@@ -267,75 +272,88 @@ __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restric
     const int64_t tile = blockIdx.x;
     if (tile >= ntiles_total) return;
     const int lane = threadIdx.x;
-    const int c = lane & 31, hh = lane >> 5;
-    const int64_t cell = tile * 32 + c;
-    const bool live = cell < ncell;
     const int g1 = g + 1;
     unsigned char *o = out + tile * (int64_t)kc * 1024;
-    // whole-row pass: range check and ||rep||^2 (both lane halves of a cell compute the same)
-    bool bad = false;
-    double ss = 0.0;
-    for (int e = 0; e < g && live; ++e) {
-        const float f = (float)((V[cell * g + e] - centre[e]) * scale);
-        bad = bad || !(fabsf(f) <= 30000.0f);                 // f16 range (targets carry a factor 2); NaN / inf input
-        const _Float16 h = (_Float16)f;
-        const _Float16 l = (_Float16)(f - (float)h);
-        const double rep = (double)(float)h + (double)(float)l;
-        ss += rep * rep;
-    }
-    float nh = 0.0f, nl = 0.0f;
-    if (IS_REF) {
-        float nf = __builtin_inff();
-        if (live && !bad && !(mask && mask[cell])) {
-            nf = (float)ss * 3.0517578125e-05f;                // ||y~||^2 (scaled units) * 2^-15
-            if (hh == 0) atomicMax(norm_max_bits, __float_as_uint((float)ss));
+    const int nh_cells = L16 ? 2 : 1;                        // cells this lane packs
+    const int ks = L16 ? kc / 2 : kc;                        // registers per cell
+    const int grp = L16 ? lane >> 4 : lane >> 5;             // which 8 slots of a step this lane supplies
+    for (int hc = 0; hc < nh_cells; ++hc) {
+        const int c = L16 ? 16 * hc + (lane & 15) : lane & 31;
+        const int64_t cell = tile * 32 + c;
+        const bool live = cell < ncell;
+        // whole-row pass: range check and ||rep||^2 (every lane of a cell computes the same)
+        bool bad = false;
+        double ss = 0.0;
+        for (int e = 0; e < g && live; ++e) {
+            const float f = (float)((V[cell * g + e] - centre[e]) * scale);
+            bad = bad || !(fabsf(f) <= 30000.0f);                 // f16 range (targets carry a factor 2); NaN / inf input
+            const _Float16 h = (_Float16)f;
+            const _Float16 l = (_Float16)(f - (float)h);
+            const double rep = (double)(float)h + (double)(float)l;
+            ss += rep * rep;
         }
-        const _Float16 h = (_Float16)nf;
-        nh = (float)h;
-        if (nf < __builtin_inff()) nl = (float)(_Float16)(nf - (float)h);
-    } else {
-        nh = nl = live ? 32768.0f : 0.0f;                      // segments 0 and 1; NOT scaled by -2: the product is +||y||^2
-        if (hh == 0 && live) norm64[cell] = bad ? __builtin_nan("") : ss / (scale * scale);
-    }
-    for (int s = 0; s < kc; ++s) {
-        f16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int p = 16 * s + 8 * hh + j;
-            const int seg = p / g1, e = p - seg * g1;
-            float val = 0.0f;
-            if (seg < 3) {
-                if (e == g) {
-                    val = seg == 0 ? nh : seg == 1 ? nl : 0.0f;
-                } else if (live && !bad) {
-                    const float f = (float)((V[cell * g + e] - centre[e]) * scale);
-                    const _Float16 h = (_Float16)f;
-                    const float lo = (float)(_Float16)(f - (float)h);
-                    const bool want_lo = IS_REF ? seg == 1 : seg == 2;
-                    val = want_lo ? lo : (float)h;
-                    if (!IS_REF) val *= -2.0f;
-                }
+        float nh = 0.0f, nl = 0.0f;
+        if (IS_REF) {
+            float nf = __builtin_inff();
+            if (live && !bad && !(mask && mask[cell])) {
+                nf = (float)ss * 3.0517578125e-05f;                // ||y~||^2 (scaled units) * 2^-15
+                if (grp == 0) atomicMax(norm_max_bits, __float_as_uint((float)ss));
             }
-            v[j] = (_Float16)val;
+            const _Float16 h = (_Float16)nf;
+            nh = (float)h;
+            if (nf < __builtin_inff()) nl = (float)(_Float16)(nf - (float)h);
+        } else {
+            nh = nl = live ? 32768.0f : 0.0f;                      // segments 0 and 1; NOT scaled by -2: the product is +||y||^2
+            if (grp == 0 && live) norm64[cell] = bad ? __builtin_nan("") : ss / (scale * scale);
         }
-        reinterpret_cast<f16x8 *>(o)[s * 64 + lane] = v;
+        for (int s = 0; s < ks; ++s) {
+            f16x8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int p = (L16 ? 32 : 16) * s + 8 * grp + j;
+                const int seg = p / g1, e = p - seg * g1;
+                float val = 0.0f;
+                if (seg < 3) {
+                    if (e == g) {
+                        val = seg == 0 ? nh : seg == 1 ? nl : 0.0f;
+                    } else if (live && !bad) {
+                        const float f = (float)((V[cell * g + e] - centre[e]) * scale);
+                        const _Float16 h = (_Float16)f;
+                        const float lo = (float)(_Float16)(f - (float)h);
+                        const bool want_lo = IS_REF ? seg == 1 : seg == 2;
+                        val = want_lo ? lo : (float)h;
+                        if (!IS_REF) val *= -2.0f;
+                    }
+                }
+                v[j] = (_Float16)val;
+            }
+            reinterpret_cast<f16x8 *>(o)[(hc * ks + s) * 64 + lane] = v;
+        }
     }
 }
 
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
-                            hipStream_t st)
+                            bool layout16, hipStream_t st)
 {
-    hipLaunchKernelGGL((pack_ctiles_kernel<true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre, scale, kc,
-                       ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
+    if (layout16)
+        hipLaunchKernelGGL((pack_ctiles_kernel<true, true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre,
+                           scale, kc, ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
+    else
+        hipLaunchKernelGGL((pack_ctiles_kernel<true, false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre,
+                           scale, kc, ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
     return hipGetLastError();
 }
 
 hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
-                              int64_t ntiles_total, unsigned char *out, double *xnorm, hipStream_t st)
+                              int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st)
 {
-    hipLaunchKernelGGL((pack_ctiles_kernel<false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre, scale, kc,
-                       ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
+    if (layout16)
+        hipLaunchKernelGGL((pack_ctiles_kernel<false, true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre,
+                           scale, kc, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
+    else
+        hipLaunchKernelGGL((pack_ctiles_kernel<false, false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre,
+                           scale, kc, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
     return hipGetLastError();
 }
 

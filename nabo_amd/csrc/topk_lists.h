@@ -3,6 +3,7 @@
 //
 // Accumulator convention (v_mfma_f32_32x32x*): lane l holds, for target row (l & 31) of a row-block, 16 scores a[i];
 // register i of lane half h = l >> 5 belongs to reference jb + cd_row(i, 0) where jb = first reference of the tile + 4 h.
+// (v_mfma_f32_16x16x32, l2q_topk.hip: row-blocks of 16 rows, 8 scores per lane and record -- ListCfg's RPBv.)
 //
 // A chain's filter is 8 v_min3 + 1 v_cmp against the row's threshold tau (one VGPR, lane = row).  What happens on a hit
 // used to be the largest non-MFMA item of these kernels: the hitting lanes -- one or two of 64 -- searched their 16
@@ -30,18 +31,24 @@
 namespace nabo {
 
 // EPL: emitted candidate lists hold 32 * EPL entries; ROWN: entries per row in LDS (odd, >= lkeep); NB: row-blocks per
-// wave; NREC: staging records per wave (<= 64: one lane per record).
-template <int EPL, int ROWN, int NB, int NREC>
+// wave; NREC: staging records per wave (<= 64: one lane per record); RPBv: target rows per row-block -- 32 for the
+// 32x32 MFMA shapes (a lane holds 16 scores of row l & 31, references jb + (i & 3) + 8 (i >> 2)), 16 for 16x16x32
+// (l2q_topk.hip: 8 scores of row l & 15, references jb + (i & 3) + 16 (i >> 2)).
+template <int EPL, int ROWN, int NB, int NREC, int RPBv = 32>
 struct ListCfg {
     static constexpr int LMAX = 32 * EPL;                // stride of the emitted candidate lists
     static constexpr int ROW = ROWN;
-    static constexpr int NROWS = NB * 32;
+    static constexpr int RPB = RPBv;                     // rows per row-block
+    static constexpr int RS = RPBv / 2;                  // scores per lane and record (64 lanes x RS = RPB rows x 32 references)
+    static constexpr int JSTRIDE = RPBv == 32 ? 8 : 16;  // reference stride between a lane's groups of four scores
+    static_assert(RPBv == 32 || RPBv == 16, "row-blocks of 32 or 16 rows");
+    static constexpr int NROWS = NB * RPBv;
     static_assert(ROW % 2 == 1, "odd row stride: lane-per-row walks spread over the LDS banks");
     static_assert(NREC <= 64 && NREC % 2 == 0, "one lane per staged record");
     // per-wave LDS block (16-byte aligned; BYTES is a multiple of 16):
-    //   srec [NREC][16] f32 | rows [NROWS][ROW] uint2 | shdr [NREC] uint2 | tauL [NROWS] f32 | pmax [NROWS] u32 |
+    //   srec [NREC][RS] f32 | rows [NROWS][ROW] uint2 | shdr [NREC] uint2 | tauL [NROWS] f32 | pmax [NROWS] u32 |
     //   owner [NROWS] u32
-    static constexpr int OFF_ROWS = NREC * 64;
+    static constexpr int OFF_ROWS = NREC * RS * 4;
     static constexpr int OFF_SHDR = OFF_ROWS + NROWS * ROW * 8;
     static constexpr int OFF_TAU = OFF_SHDR + NREC * 8;
     static constexpr int OFF_PMAX = OFF_TAU + NROWS * 4;
@@ -116,7 +123,7 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
     lds_vu32 *owner = (lds_vu32 *)C::owner(w);
     const bool mine = (uint32_t)lane < scnt;
     uint32_t row = 0, jb = 0, q = 0;
-    const f32x4 *rp = reinterpret_cast<const f32x4 *>(C::srec(w) + (mine ? lane : 0) * 16);
+    const f32x4 *rp = reinterpret_cast<const f32x4 *>(C::srec(w) + (mine ? lane : 0) * C::RS);
     const float *rf = reinterpret_cast<const float *>(rp);
     if (mine) {
         const uint2 h = C::shdr(w)[lane];
@@ -124,7 +131,7 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
         jb = h.y;
         const float t = tauL[row];                           // which scores are below the row's threshold right now
 #pragma unroll
-        for (int q4 = 3; q4 >= 0; --q4) {
+        for (int q4 = C::RS / 4 - 1; q4 >= 0; --q4) {
             const f32x4 v = rp[q4];
 #pragma unroll
             for (int e = 3; e >= 0; --e) q = q + q + (v[e] < t ? 1u : 0u);       // bit 4 q4 + e
@@ -147,7 +154,7 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
                 const float key = rf[i];
                 repl = key < tau;
                 if (repl) {
-                    kept[pm] = make_uint2(__float_as_uint(key), jb + (uint32_t)((i & 3) + 8 * (i >> 2)));     // evict the largest kept entry
+                    kept[pm] = make_uint2(__float_as_uint(key), jb + (uint32_t)((i & 3) + C::JSTRIDE * (i >> 2)));     // evict the largest kept entry
 #ifdef NABO_LISTS_PROF
                     atomicAdd(&C::prof(w)[7], 1u);
 #endif
@@ -205,26 +212,26 @@ __device__ __forceinline__ void lists_drain(unsigned char *w, uint32_t scnt, int
     NABO_PROF_ADD(w, 3, NABO_PROF_DT() >> 4);
     NABO_PROF_ADD(w, 6, scnt);
 #pragma unroll
-    for (int rb = 0; rb < NB; ++rb) tauv[rb] = C::tauL(w)[rb * 32 + (lane_id() & 31)];
+    for (int rb = 0; rb < NB; ++rb) tauv[rb] = C::tauL(w)[rb * C::RPB + (lane_id() & (C::RPB - 1))];
 }
 
-// The episode: hitting lanes park their 16 scores; the staging area is drained when it is full.
+// The episode: hitting lanes park their scores (a[C::RS]); the staging area is drained when it is full.
 template <typename C>
-__device__ __forceinline__ void stage_write(const f32x16 &a, uint32_t p, int rb, uint32_t jb, unsigned char *w)
+__device__ __forceinline__ void stage_write(const float (&a)[C::RS], uint32_t p, int rb, uint32_t jb, unsigned char *w)
 {
-    f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * 16);
+    f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * C::RS);
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
+    for (int q4 = 0; q4 < C::RS / 4; ++q4) {
         f32x4 v;
         v[0] = a[4 * q4]; v[1] = a[4 * q4 + 1]; v[2] = a[4 * q4 + 2]; v[3] = a[4 * q4 + 3];
         rp[q4] = v;
     }
-    C::shdr(w)[p] = make_uint2((uint32_t)(rb * 32 + (lane_id() & 31)), jb);
+    C::shdr(w)[p] = make_uint2((uint32_t)(rb * C::RPB + (lane_id() & (C::RPB - 1))), jb);
 }
 
 template <typename C, int EPL, int NB, int NREC>
-__device__ __forceinline__ void stage_hits(const f32x16 &a, float m, int rb, uint32_t jb, unsigned char *w, uint32_t &scnt,
-                                           int lkeep, float (&tauv)[NB])
+__device__ __forceinline__ void stage_hits(const float (&a)[C::RS], float m, int rb, uint32_t jb, unsigned char *w,
+                                           uint32_t &scnt, int lkeep, float (&tauv)[NB])
 {
     bool hit = m < tauv[rb];
     {   // the usual episode: everything fits -- one ballot, one rank, the writes
@@ -256,17 +263,41 @@ __device__ __forceinline__ void stage_hits(const f32x16 &a, float m, int rb, uin
     }
 }
 
-// A chain's filter: lane minimum of the 16 scores against the row's threshold; a wave-uniform branch on "any hit".
+// Two row-blocks' hits in one episode (l2q_topk.hip: one filter branch covers a PAIR of 16-row blocks): one rank
+// computation and one staging-area check for both; the rare overflow goes through the general path.
+template <typename C, int EPL, int NB, int NREC>
+__device__ __forceinline__ void stage_hits2(const float (&a0)[C::RS], float m0, const float (&a1)[C::RS], float m1, int rb0,
+                                            uint32_t jb, unsigned char *w, uint32_t &scnt, int lkeep, float (&tauv)[NB])
+{
+    const bool h0 = m0 < tauv[rb0], h1 = m1 < tauv[rb0 + 1];
+    const uint64_t b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
+    const uint32_t n0 = (uint32_t)__builtin_popcountll(b0), n = n0 + (uint32_t)__builtin_popcountll(b1);
+    if (scnt + n <= (uint32_t)NREC) {
+        if (h0) stage_write<C>(a0, scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)), rb0, jb, w);
+        if (h1) stage_write<C>(a1, scnt + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u)), rb0 + 1, jb, w);
+        scnt += n;
+        return;
+    }
+    stage_hits<C, EPL, NB, NREC>(a0, m0, rb0, jb, w, scnt, lkeep, tauv);
+    stage_hits<C, EPL, NB, NREC>(a1, m1, rb0 + 1, jb, w, scnt, lkeep, tauv);
+}
+
+// A chain's filter (32x32 shapes): lane minimum of the 16 scores against the row's threshold; a wave-uniform branch on
+// "any hit".
 template <typename C, int EPL, int NB, int NREC>
 __device__ __forceinline__ void filter_and_stage(const f32x16 &acc, int rb, uint32_t jb, unsigned char *w, uint32_t &scnt,
                                                  int lkeep, float (&tauv)[NB])
 {
+    static_assert(C::RS == 16, "32x32 accumulator layout");
     float m = acc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) m = fminf(m, acc[r]);
     if (__builtin_amdgcn_ballot_w64(m < tauv[rb]) != 0) {
         NABO_PROF_T0();
-        stage_hits<C, EPL, NB, NREC>(acc, m, rb, jb, w, scnt, lkeep, tauv);
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = acc[r];
+        stage_hits<C, EPL, NB, NREC>(a, m, rb, jb, w, scnt, lkeep, tauv);
         NABO_PROF_ADD(w, 0, 1);
         NABO_PROF_ADD(w, 1, NABO_PROF_DT() >> 4);           // (drains inside the episode are counted here too)
     }

@@ -376,13 +376,14 @@ def test_zero_target_rows_is_a_no_op(gpu_lib):
                                           (64, 3000, 100, 11, False)])
 def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     """The Euclidean filter runs on the f16 matrix pipe (f16x3 split, the default where it is instantiated:
-    g < 64 and k + drop + 4 <= 32) or on the fp32 MFMA (everything else, or NABO_L2_MODE=f32): the float64 refine +
-    certification make both return exactly what the oracle does."""
+    g < 64 and k + drop + 4 <= 32; three kernels: 16x16x32 MFMA shape = default, 32x32x16 per-wave, 32x32x16 with shared
+    LDS tiles) or on the fp32 MFMA (everything else, or NABO_L2_MODE=f32): the float64 refine + certification make all
+    of them return exactly what the oracle does."""
     Y = pca_like(n, g, seed=1000 + n + g)
     X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
     oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
     kernels = {}
-    for mode in ("f16x3", "f16x3h", "f16x3s", "f32", None):
+    for mode in ("f16x3", "f16x3h", "f16x3q", "f16x3s", "f32", None):
         if mode:
             os.environ["NABO_L2_MODE"] = mode
         try:
@@ -402,10 +403,11 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     h_ok, s_ok = (g < 64 and kk + 4 <= 32), (g <= 52 and kk + 4 <= 28)
     assert kernels["f16x3h"].startswith("l2h_topk" if h_ok else "l2_topk"), kernels
     assert kernels["f16x3s"].startswith("l2s_topk" if (g <= 52 and kk + 4 <= 24) else ("l2h_topk", "l2_topk")), kernels
-    assert kernels["f16x3"].startswith(("l2h_topk", "l2s_topk") if h_ok else "l2_topk"), kernels
+    assert kernels["f16x3q"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels          # 16x16x32 MFMA shape
+    assert kernels["f16x3"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels                 # the default f16x3 kernel
 
 
-@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3s", 274), ("f16x3h", 274)])
+@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3s", 274), ("f16x3h", 274), ("f16x3q", 274)])
 def test_tail_round_split_rows_are_exact(gpu_lib, mode, full_round):
     """More target workgroups than resident slots: the last, partially filled round is launched with its
     own reference split (api.hip "tail round").  Rows of BOTH launches must match the oracle."""

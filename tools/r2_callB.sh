@@ -30,9 +30,11 @@ for ab in 1 2 3; do
   NABO_DEBUG_ABLATE=$ab python bench.py $B --steps 3 --warmup 1 2>> $O/ablate.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ablate $ab kernel_ms', d['roofline']['kernel_ms'], 'ms_per_step', d['ms_per_step'])" >> $O/ablate.txt
 done
 NABO_L2_MODE=f32 python bench.py $B --steps 3 --warmup 1 > $O/bench_f32_mode.json 2>> $O/ablate.err
+NABO_L2_MODE=f16x3h python bench.py $B --steps 3 --warmup 1 > $O/bench_f16x3h_mode.json 2>> $O/ablate.err
+NABO_L2_MODE=f16x3s python bench.py $B --steps 3 --warmup 1 > $O/bench_f16x3s_mode.json 2>> $O/ablate.err
 python bench.py $B --targets 100000 --refs 100000 --steps 10 --warmup 2 > $O/bench_100kx100k.json 2>> $O/ablate.err
 python bench.py $B --metric cosine --dims 100 --neighbors 50 --steps 2 --warmup 1 > $O/bench_cosine_1M_d100_k50.json 2>> $O/ablate.err
 for n in 8 4 2; do python tools/check_shard_fullscale.py $n | tail -1 >> $O/shard_fullscale.txt; done
 cat $O/ablate.txt $O/shard_fullscale.txt
-grep -h "l2h_topk\|cbf_filter" $O/pmc_euclid_summary.csv $O/pmc_canberra_summary.csv
+grep -h "l2q_topk\|cbf_filter" $O/pmc_euclid_summary.csv $O/pmc_canberra_summary.csv
 cat $O/issue_lab.txt $O/mfma_clock_lab.txt
