@@ -34,7 +34,10 @@ if REPO not in sys.path:
 
 # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 2.4 GHz
 PEAK_F32_MFMA_TFLOPS = 157.3        # v_mfma_f32_32x32x2_f32: 64 flop/clk/SIMD
-PEAK_F16_MFMA_TFLOPS = 2516.6       # v_mfma_f32_32x32x16_f16: 32 cycles per 32x32x16 -> 1024 flop/clk/SIMD (dense)
+# v_mfma_f32_32x32x16_f16 / 16x16x32_f16: 1024 flop/clk/SIMD (dense) at the nominal 2.4 GHz.  The part holds that clock
+# only on all-zero operands; a bare MFMA loop on random data sustains 1.6 PF (32x32x16) / 1.9-2.0 PF (16x16x32) --
+# tools/mfma_clock_lab.hip, profiles/r2_mfma_clock_lab.txt, DESIGN.md 4.1b.  The roofline is priced against the nominal peak.
+PEAK_F16_MFMA_TFLOPS = 2516.6
 # vector ISSUE peak for the mod-Canberra counting pass, MEASURED on this part by tools/issue_lab.hip for the pass's own
 # instruction mix (v_sub_u32, v_sub_u32, v_bitop3_b32, v_bcnt_u32_b32 on independent chains, 8 waves per SIMD):
 # 0.263 wave-instructions per clock and SIMD = 646.9 G/s (v_sub / v_bitop3 alone issue at 0.43 per clock, v_bcnt and
@@ -250,7 +253,8 @@ def main():
                 "traffic": (rec or {}).get("bytes_per_step"), "traffic_record": rec,
                 "algorithmic_bytes": 4.0 * d * (m + n_shard) + 12.0 * k * m,      # fp32 operands + (i32, f64) results
                 "kernel": kern, "kernel_ms": t_kernel * 1e3,
-                "matrix_pipe_busy": (rec or {}).get("matrix_pipe_busy")}
+                "matrix_pipe_busy": (rec or {}).get("matrix_pipe_busy"),
+                "clock_ghz_held": (rec or {}).get("clock_ghz_held")}
         else:
             rec = pmc_record("canberra", workload, so)
             line["roofline"] = canberra_roofline(rec, t_kernel, kern)

@@ -35,6 +35,9 @@ rec["traffic"][be["config"]["workload"]] = {
     # FETCH_SIZE tallies 128-byte requests at 64 bytes for wide streaming reads on gfx950 (MI355X_MICROARCH.md, HBM): x2
     "bytes_per_step": 2.0 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
     "matrix_pipe_busy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8.0 * 1024.0),
+    # GRBM_GUI_ACTIVE sums the 8 XCDs: cycles the kernel took, and the clock the part held under it (DVFS)
+    "cycles_per_simd": gui / 8.0, "kernel_ms_in_that_pass": be["roofline"]["kernel_ms"],
+    "clock_ghz_held": gui / 8.0 / (be["roofline"]["kernel_ms"] * 1e6),
     "insts": {k: c[k] for k in c if k.startswith("SQ_INSTS")},
     "wave_cycles": {k: c[k] for k in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in c},
     "source": dst_prefix + "pmc_euclid_summary.csv (rocprofv3 --pmc, one counter group per pass, tools/r2_callB.sh)"}
