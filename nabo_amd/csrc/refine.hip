@@ -138,7 +138,10 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 //               non-candidate from below by B; ||x^-y^||^2 = 2(1-cos) up to the float64 rounding of the
 //               normalisation and of cosine_exact itself (< 1e-13 for g <= 128), so the row is certified
 //               when  B/2 - 2e-13 > c_(k')  (exact cosine value of the k'-th candidate).
-template <int NCL, int MET>
+// STAGE (NCL == 1, g <= 64): candidate rows are fetched by the whole wave, one coalesced g*8-byte read per candidate,
+// into a wave-private LDS block and each lane then evaluates ITS candidate from LDS, in the reference's component
+// order -- a lane walking its own row in global memory moved 8 bytes per 64-byte request (1.15 TB/s at 1M rows).
+template <int NCL, int MET, bool STAGE>
 __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                      const double *__restrict__ Y, int g,
                                                      const uint32_t *__restrict__ cand_idx,
@@ -160,16 +163,33 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     const int ncand = S * L;
     double key[NCL];
     uint32_t val[NCL];
+    if (STAGE) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char refine_smem[];
+        const int gp = g | 1;                                  // odd row stride (in doubles): lanes spread over the banks
+        double *stg = reinterpret_cast<double *>(refine_smem) + (size_t)(threadIdx.x >> 6) * ncand * gp;
+        const uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
+        for (int c = 0; c < ncand; ++c) {
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)myj, c);
+            if (j != 0xFFFFFFFFu && lane < g) stg[c * gp + lane] = Y[(int64_t)j * g + lane];
+        }
+        key[0] = __builtin_inf();
+        val[0] = 0xFFFFFFFFu;
+        if (myj != 0xFFFFFFFFu) {
+            val[0] = myj;
+            key[0] = exact_dist(MET, x, stg + lane * gp, g, cb_f);
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < NCL; ++r) {
-        const int e = r * 64 + lane;
-        key[r] = __builtin_inf();
-        val[r] = 0xFFFFFFFFu;
-        if (e < ncand) {
-            const uint32_t j = cand_idx[lrow * ncand + e];
-            if (j != 0xFFFFFFFFu) {
-                val[r] = j;
-                key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, cb_f);
+        for (int r = 0; r < NCL; ++r) {
+            const int e = r * 64 + lane;
+            key[r] = __builtin_inf();
+            val[r] = 0xFFFFFFFFu;
+            if (e < ncand) {
+                const uint32_t j = cand_idx[lrow * ncand + e];
+                if (j != 0xFFFFFFFFu) {
+                    val[r] = j;
+                    key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, cb_f);
+                }
             }
         }
     }
@@ -557,27 +577,31 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
+    // staged gather: one candidate per lane, rows of <= 64 components, 4 waves x S*L rows within 64 KB of LDS
+    const size_t stage_bytes = (size_t)4 * S * L * (g | 1) * sizeof(double);
+    const bool stage = ncl <= 1 && g <= 64 && stage_bytes <= 65536;
+#define NABO_RF2(N, MV, SV)                                                                                          \
+    hipLaunchKernelGGL((refine_kernel<N, MV, SV>), grid, block, SV ? stage_bytes : 0, st, X, row0, m, Y, g, cand_idx,   \
+                       cand_tau, S, L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,       \
+                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count)
 #define NABO_RF(N)                                                                                               \
     do {                                                                                                         \
-        if (metric == 1)                                                                                         \
-            hipLaunchKernelGGL((refine_kernel<N, 1>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S,   \
-                               L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
-                               n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
-        else if (metric == 2)                                                                                    \
-            hipLaunchKernelGGL((refine_kernel<N, 2>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S,   \
-                               L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
-                               n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((refine_kernel<N, 0>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S,   \
-                               L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,        \
-                               n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count); \
+        if (metric == 1) NABO_RF2(N, 1, false);                                                                  \
+        else if (metric == 2) NABO_RF2(N, 2, false);                                                             \
+        else NABO_RF2(N, 0, false);                                                                              \
     } while (0)
+    if (stage) {
+        if (metric == 1) NABO_RF2(1, 1, true);
+        else if (metric == 2) NABO_RF2(1, 2, true);
+        else NABO_RF2(1, 0, true);
+    } else
     if (ncl <= 1) NABO_RF(1);
     else if (ncl <= 2) NABO_RF(2);
     else if (ncl <= 4) NABO_RF(4);
     else if (ncl <= 8) NABO_RF(8);
     else if (ncl <= 16) NABO_RF(16);
     else return hipErrorInvalidValue;
+#undef NABO_RF2
 #undef NABO_RF
     return hipGetLastError();
 }

@@ -68,6 +68,18 @@ __global__ __launch_bounds__(256) void k(int iters, float *out)
 #define OP(i) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x80" : "+v"(u32[i]) : "v"(__float_as_uint(x)), "v"(__float_as_uint(y)));
                 REP16(OP)
 #undef OP
+            } else if (KIND >= 11 && KIND <= 16) {
+                uint32_t *u32 = reinterpret_cast<uint32_t *>(a);
+                const uint32_t xi = __float_as_uint(x), yi = __float_as_uint(y);
+#define OP(i)                                                                                                         \
+    if (KIND == 11) asm volatile("v_sad_u8 %0, %1, %2, %0" : "+v"(u32[i]) : "v"(xi), "v"(yi));                         \
+    if (KIND == 12) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(u32[i]) : "v"(xi), "v"(yi));                    \
+    if (KIND == 13) asm volatile("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(u32[i]) : "v"(xi), "v"(yi));                    \
+    if (KIND == 14) asm volatile("v_add3_u32 %0, %1, %2, %0" : "+v"(u32[i]) : "v"(xi), "v"(yi));                       \
+    if (KIND == 15) asm volatile("v_lshl_add_u32 %0, %1, 1, %0" : "+v"(u32[i]) : "v"(xi));                             \
+    if (KIND == 16) asm volatile("v_sad_u32 %0, %1, %2, %0" : "+v"(u32[i]) : "v"(xi), "v"(yi));
+                REP16(OP)
+#undef OP
             } else {
 #define OP(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(*reinterpret_cast<double *>(&a[(i & 7) * 2])) : "v"(*reinterpret_cast<double *>(&a[0])), "v"(*reinterpret_cast<double *>(&a[2])));
                 REP16(OP)
@@ -118,5 +130,11 @@ int main()
     run<9>("v_bcnt_u32_b32", 1, out);
     run<10>("v_bitop3_b32", 1, out);
     run<7>("sub + sub + bitop3 + bcnt (SWAR)", 4, out);
+    run<11>("v_sad_u8", 1, out);
+    run<12>("v_dot4_u32_u8", 1, out);
+    run<13>("v_mad_u32_u24", 1, out);
+    run<14>("v_add3_u32", 1, out);
+    run<15>("v_lshl_add_u32", 1, out);
+    run<16>("v_sad_u32", 1, out);
     return 0;
 }
