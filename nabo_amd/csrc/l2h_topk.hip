@@ -120,28 +120,28 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
 #pragma unroll
     for (int r = 0; r < 16; ++r) accP[r] = __builtin_inff();       // inf < tau is false: nothing pending
 
-#ifdef NABO_L2H_NOFILTER          // timing experiments: chains only; the accumulators are kept alive through an empty asm
-#define L2H_FILTER(ACC, RB, JB) asm volatile("" ::"v"(ACC))
-#else
-#define L2H_FILTER(ACC, RB, JB) filter_and_stage<C, EPL, R, NREC>(ACC, RB, JB, wl, scnt, lkeep, tauv)
-#endif
-    // all R chains of tile t on register set `a`; the last chain refills `a` with tile t+2
+    // all R chains of tile t on register set `a`; the last chain refills `a` with tile t+2.  The previous chain's filter
+    // is evaluated "before" the chain (no control flow: hipcc interleaves it with the chain's MFMAs; placed after a
+    // refill chain, behind that chain's scheduling fences, it ran with the matrix pipe idle) and acted on after it.
     auto tile_step = [&](f16x8(&a)[KC], int t) {
         const unsigned char *next2 = tile_ptr(t + 2);
         f32x16 accA;
 #pragma unroll
         for (int rb = 0; rb < R; ++rb) {
             const int prev = (rb + R - 1) % R;
-            const int tprev = rb == 0 ? t - 1 : t;
-            if (rb & 1) {
-                if (rb == R - 1) accP = hchain<KC, true>(a, xb[rb], next2, lane);
-                else accP = hchain<KC, false>(a, xb[rb], next2, lane);
-                L2H_FILTER(accA, prev, (uint32_t)(tprev * 32 + 4 * hh));
-            } else {
-                if (rb == R - 1) accA = hchain<KC, true>(a, xb[rb], next2, lane);
-                else accA = hchain<KC, false>(a, xb[rb], next2, lane);
-                L2H_FILTER(accP, prev, (uint32_t)(tprev * 32 + 4 * hh));
-            }
+            const uint32_t jbp = (uint32_t)((rb == 0 ? t - 1 : t) * 32 + 4 * hh);
+            f32x16 &cur = (rb & 1) ? accP : accA;
+            f32x16 &old = (rb & 1) ? accA : accP;
+#ifndef NABO_L2H_NOFILTER
+            const FilterVerdict v = filter_eval<R>(old, prev, tauv);
+#endif
+            if (rb == R - 1) cur = hchain<KC, true>(a, xb[rb], next2, lane);
+            else cur = hchain<KC, false>(a, xb[rb], next2, lane);
+#ifndef NABO_L2H_NOFILTER
+            filter_stage<C, EPL, R, NREC>(old, v, prev, jbp, wl, scnt, lkeep, tauv);
+#else
+            asm volatile("" ::"v"(old));        // timing experiments: chains only, the accumulators kept alive
+#endif
         }
         if (R & 1) accP = accA;        // odd R: the pending chain is the one just computed
     };

@@ -66,26 +66,50 @@ __device__ __forceinline__ qacc qchain(f16x8 (&a)[2][KS], const f16x8 (&b0)[KS],
     return acc;
 }
 
-// filter of a pair: lane minimum of the 8 scores of each row-block against its threshold, ONE wave-uniform branch
+// Filter of a pair, in two parts.  EVAL (no control flow: hipcc schedules it between the MFMAs of the chain that is
+// issued next -- placed after a refill chain, behind that chain's scheduling fences, it ran with the matrix pipe idle):
+// lane minimum of the 8 scores of each row-block against its threshold.  STAGE: ONE wave-uniform branch on "any hit".
+struct qverdict { float m0, m1; uint64_t any; };
+
+template <int NB>
+__device__ __forceinline__ qverdict qfilter_eval(const qacc &acc, int rb0, const float (&tauv)[NB])
+{
+    qverdict v;
+    v.m0 = acc.v[0][0][0];
+    v.m1 = acc.v[1][0][0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        v.m0 = fminf(v.m0, acc.v[0][i >> 2][i & 3]);
+        v.m1 = fminf(v.m1, acc.v[1][i >> 2][i & 3]);
+    }
+    v.any = __builtin_amdgcn_ballot_w64((v.m0 < tauv[rb0]) || (v.m1 < tauv[rb0 + 1]));
+    return v;
+}
+
+template <typename C, int EPL, int NB, int NREC>
+__device__ __forceinline__ void qfilter_stage(const qacc &acc, const qverdict &v, int rb0, uint32_t jb, unsigned char *w,
+                                              uint32_t &scnt, int lkeep, float (&tauv)[NB])
+{
+    if (v.any != 0) {
+        NABO_PROF_T0();
+        float s0[8], s1[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            s0[i] = acc.v[0][0][i]; s0[4 + i] = acc.v[0][1][i];
+            s1[i] = acc.v[1][0][i]; s1[4 + i] = acc.v[1][1][i];
+        }
+        stage_hits2<C, EPL, NB, NREC>(s0, v.m0, s1, v.m1, rb0, jb, w, scnt, lkeep, tauv);
+        NABO_PROF_ADD(w, 0, 1);
+        NABO_PROF_ADD(w, 1, NABO_PROF_DT() >> 4);
+    }
+}
+
 template <typename C, int EPL, int NB, int NREC>
 __device__ __forceinline__ void qfilter(const qacc &acc, int rb0, uint32_t jb, unsigned char *w, uint32_t &scnt, int lkeep,
                                         float (&tauv)[NB])
 {
-    float s0[8], s1[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        s0[i] = acc.v[0][0][i]; s0[4 + i] = acc.v[0][1][i];
-        s1[i] = acc.v[1][0][i]; s1[4 + i] = acc.v[1][1][i];
-    }
-    float m0 = s0[0], m1 = s1[0];
-#pragma unroll
-    for (int i = 1; i < 8; ++i) { m0 = fminf(m0, s0[i]); m1 = fminf(m1, s1[i]); }
-    if (__builtin_amdgcn_ballot_w64((m0 < tauv[rb0]) || (m1 < tauv[rb0 + 1])) != 0) {
-        NABO_PROF_T0();
-        stage_hits2<C, EPL, NB, NREC>(s0, m0, s1, m1, rb0, jb, w, scnt, lkeep, tauv);
-        NABO_PROF_ADD(w, 0, 1);
-        NABO_PROF_ADD(w, 1, NABO_PROF_DT() >> 4);
-    }
+    const qverdict v = qfilter_eval<NB>(acc, rb0, tauv);
+    qfilter_stage<C, EPL, NB, NREC>(acc, v, rb0, jb, w, scnt, lkeep, tauv);
 }
 
 // Grid: x = target super-blocks (4 waves x 128 rows), y = reference splits.
@@ -136,7 +160,9 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
     // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop always runs two steps
     auto tile_ptr = [&](int t) {
         const int64_t tc = t < t_end ? (int64_t)t : pad_tile;
-        return Ypk + ((dbg & 2) ? (int64_t)(t_begin + ((t - t_begin) & 127)) : tc) * TB;
+        // dbg & 2 / dbg & 4 (timing experiments, garbage results): the stream wraps inside a window of 128 tiles (stays in
+        // the XCD's L2) / of 2 tiles (stays in the CU's vector L1)
+        return Ypk + ((dbg & 2) ? (int64_t)(t_begin + ((t - t_begin) & 127)) : (dbg & 4) ? (int64_t)(t_begin + ((t - t_begin) & 1)) : tc) * TB;
     };
 
     f16x8 a0[2][KS], a1[2][KS];
@@ -154,27 +180,37 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int h = 0; h < 2; ++h) accP.v[r][h] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
 
-#ifdef NABO_L2H_NOFILTER
-#define L2Q_FILTER(ACC, RB, JB) asm volatile("" ::"v"(ACC.v[0][0]), "v"(ACC.v[0][1]), "v"(ACC.v[1][0]), "v"(ACC.v[1][1]))
-#else
-#define L2Q_FILTER(ACC, RB, JB) qfilter<C, EPL, NB, NREC>(ACC, RB, JB, wl, scnt, lkeep, tauv)
-#endif
-    // all NP pair-chains of tile t on register set `a`; the last one refills `a` with tile t+2
+    // all NP pair-chains of tile t on register set `a`; the last one refills `a` with tile t+2.  The previous pair's
+    // verdict is computed "before" the chain (see qfilter_eval) and acted on after it.
     auto tile_step = [&](f16x8(&a)[2][KS], int t) {
         const unsigned char *next2 = tile_ptr(t + 2);
         qacc accA;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int prev = (p + NP - 1) % NP;
-            const int tprev = p == 0 ? t - 1 : t;
+            const uint32_t jbp = (uint32_t)((p == 0 ? t - 1 : t) * 32 + 4 * lq);
             if (p & 1) {
+#ifndef NABO_L2H_NOFILTER
+                const qverdict v = qfilter_eval<NB>(accA, 2 * prev, tauv);
+#endif
                 if (p == NP - 1) accP = qchain<KS, true>(a, xb[2 * p], xb[2 * p + 1], next2, lane);
                 else accP = qchain<KS, false>(a, xb[2 * p], xb[2 * p + 1], next2, lane);
-                L2Q_FILTER(accA, 2 * prev, (uint32_t)(tprev * 32 + 4 * lq));
+#ifndef NABO_L2H_NOFILTER
+                qfilter_stage<C, EPL, NB, NREC>(accA, v, 2 * prev, jbp, wl, scnt, lkeep, tauv);
+#else
+                asm volatile("" ::"v"(accA.v[0][0]), "v"(accA.v[0][1]), "v"(accA.v[1][0]), "v"(accA.v[1][1]));
+#endif
             } else {
+#ifndef NABO_L2H_NOFILTER
+                const qverdict v = qfilter_eval<NB>(accP, 2 * prev, tauv);
+#endif
                 if (p == NP - 1) accA = qchain<KS, true>(a, xb[2 * p], xb[2 * p + 1], next2, lane);
                 else accA = qchain<KS, false>(a, xb[2 * p], xb[2 * p + 1], next2, lane);
-                L2Q_FILTER(accP, 2 * prev, (uint32_t)(tprev * 32 + 4 * lq));
+#ifndef NABO_L2H_NOFILTER
+                qfilter_stage<C, EPL, NB, NREC>(accP, v, 2 * prev, jbp, wl, scnt, lkeep, tauv);
+#else
+                asm volatile("" ::"v"(accP.v[0][0]), "v"(accP.v[0][1]), "v"(accP.v[1][0]), "v"(accP.v[1][1]));
+#endif
             }
         }
     };

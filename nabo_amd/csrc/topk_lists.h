@@ -303,6 +303,37 @@ __device__ __forceinline__ void filter_and_stage(const f32x16 &acc, int rb, uint
     }
 }
 
+// The same filter in two parts (l2h_topk.hip): the minimum / compare, free of control flow so that hipcc can schedule it
+// between the MFMAs of the chain issued next, and the branch on its verdict.
+struct FilterVerdict { float m; uint64_t any; };
+
+template <int NB>
+__device__ __forceinline__ FilterVerdict filter_eval(const f32x16 &acc, int rb, const float (&tauv)[NB])
+{
+    FilterVerdict v;
+    v.m = acc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) v.m = fminf(v.m, acc[r]);
+    v.any = __builtin_amdgcn_ballot_w64(v.m < tauv[rb]);
+    return v;
+}
+
+template <typename C, int EPL, int NB, int NREC>
+__device__ __forceinline__ void filter_stage(const f32x16 &acc, const FilterVerdict &v, int rb, uint32_t jb, unsigned char *w,
+                                             uint32_t &scnt, int lkeep, float (&tauv)[NB])
+{
+    static_assert(C::RS == 16, "32x32 accumulator layout");
+    if (v.any != 0) {
+        NABO_PROF_T0();
+        float a[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[r] = acc[r];
+        stage_hits<C, EPL, NB, NREC>(a, v.m, rb, jb, w, scnt, lkeep, tauv);
+        NABO_PROF_ADD(w, 0, 1);
+        NABO_PROF_ADD(w, 1, NABO_PROF_DT() >> 4);
+    }
+}
+
 // Final flush of a wave: drain what is staged, emit every row's kept candidate indices (+ threshold).
 // lrow0: first row of the wave's first row-block, local to the launch (rows of a wave are consecutive).
 template <typename C, int EPL, int NB>

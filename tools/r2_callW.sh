@@ -26,3 +26,6 @@ pm l2h_nohit NABO_DEBUG_ABLATE=1
 cat $O/ab.txt
 NABO_KNN_SO=$PWD/tools/ab/prof.so NABO_L2_MODE=f16x3q python bench.py $B --steps 1 --warmup 0 2>&1 >/dev/null | grep "lists prof" | tail -1
 NABO_KNN_SO=$PWD/tools/ab/prof.so python bench.py $B --steps 1 --warmup 0 2>&1 >/dev/null | grep "lists prof" | tail -1
+pm l2q_l1win NABO_L2_MODE=f16x3q NABO_DEBUG_ABLATE=5
+pm l2q_l2win NABO_L2_MODE=f16x3q NABO_DEBUG_ABLATE=3
+tail -2 $O/ab.txt
