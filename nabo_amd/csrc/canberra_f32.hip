@@ -227,15 +227,16 @@ __device__ __forceinline__ float cbf_compact(float *kb, uint32_t *ib, int count,
 // back as broadcasts (one ds_read_b64 per two dimensions and NCH chunks).
 //
 // Two passes:
-//   1. COUNT, packed f16, 1.5 VALU per pair and dimension (v_pk_add_f16, v_pk_fma_f16 clamp, v_dot2c per TWO
-//      dimensions): acc = sum_k clamp((x'-y')^2 - thr'^2, 0, 1) <= number of dimensions PROVEN out of window
-//      (see the pack kernels).  Each of those adds exactly 1 to the reference's distance and the others add
-//      >= 0, so distance >= acc; a pair whose acc already reaches the row's threshold is dropped here (all but
-//      ~1e-3 of the pairs once the lists have warmed up).
+//   1. COUNT, 7-bit integers, four dimensions per word (the operands described above the pack kernels): v_sub_u32,
+//      v_sub_u32, v_bitop3_b32, v_bcnt_u32_b32 per word and chunk = 1.0 vector instruction per pair and dimension.
+//      inw = dimensions that MAY be in the window; the others are PROVEN out, each adds exactly 1 to the reference's
+//      distance and the rest add >= 0, so distance >= (counted dimensions - inw); a pair whose bound already reaches the
+//      row's threshold is dropped here (all but ~1e-3 of the pairs once the lists have warmed up).  GWD = 1 drops the last
+//      word from the count when it holds padding only (g <= GP - 4: g = 50 counts 13 words, not GP / 4 = 14).
 //   2. BOUND (the fp32 ~15-slot divide-and-accumulate expression) only for the survivors, which are compacted
 //      through a wave-private work list so that all 64 lanes of a batch carry a live pair: lane p takes pair
 //      (t_p, j_p) and gathers x and y from the packed fp32 arrays (16-byte loads from the row-major fp32 copies; rare).
-template <int GP, int EPL, int T, int NCH>
+template <int GP, int EPL, int T, int NCH, int GWD>
 __global__ __launch_bounds__(64, 2)
 void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ xh, int64_t m,
                        const float *__restrict__ yrow, const uint32_t *__restrict__ ych, int64_t n, int g,
@@ -244,6 +245,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
 {
     constexpr int L = 32 * EPL, CAP = L + 16 * EPL;     // kept + pending entries per list
     constexpr int GH = GP / 4;           // packed words: four dimensions each
+    constexpr int GW = GH - GWD;         // words the counting pass looks at
     constexpr int GHS = GH + 1;          // LDS row stride (uint2): spreads the T rows over the banks
     constexpr int WLN = 512;             // work-list ring (entries); >= 63 + 64 * NCH
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -360,7 +362,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
     int64_t c_end = c_begin + chunks_per_split;
     if (c_end > n_chunks) c_end = n_chunks;
     for (int64_t chunk0 = c_begin; chunk0 < c_end; chunk0 += NCH) {
-        uint32_t yv[NCH][2 * GH];                               // (yg, yc) words of NCH chunks, lane = reference
+        uint32_t yv[NCH][2 * GW];                               // (yg, yc) words of NCH chunks, lane = reference
         uint64_t vmask[NCH];                                    // live (in range, not ignored) references of each chunk
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -368,7 +370,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
             const int64_t j = chunk * 64 + lane;
             vmask[c] = __builtin_amdgcn_ballot_w64((chunk < c_end) && (j < n) && !(mask && mask[j]));
 #pragma unroll
-            for (int p = 0; p < 2 * GH; ++p)
+            for (int p = 0; p < 2 * GW; ++p)
                 yv[c][p] = (chunk < c_end) ? ych[(chunk * 2 * GH + p) * 64 + lane] : 0x80808080u;
         }
 
@@ -378,7 +380,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
 #pragma unroll
             for (int c = 0; c < NCH; ++c) inw[c] = 0u;
 #pragma unroll
-            for (int p = 0; p < GH; ++p) {
+            for (int p = 0; p < GW; ++p) {
                 const uint2 xt = xr[p];                   // (lo word, hc word)
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -386,16 +388,16 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
                     inw[c] += (uint32_t)__builtin_popcount(__builtin_amdgcn_bitop3_b32(a, b, 0x80808080u, 0x80));
                 }
             }
-            // Survivor test, ONE compare per chunk.  n_out = GP - inw dimensions are PROVEN out of window, each adds
+            // Survivor test, ONE compare per chunk.  n_out = 4 GW - inw dimensions are PROVEN out of window, each adds
             // exactly 1 to the reference's distance and the others add >= 0: distance >= n_out.  A pair is dropped when
-            // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. when inw <= GP - t1; the list key of a pair,
+            // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. when inw <= 4 GW - t1; the list key of a pair,
             //     (all g dimensions out) ? plateau : min(lower bound - slack, below_plateau),
             // is then >= tau as well (key >= n_out - slack for the first form, and the second only arises for tau <=
             // plateau).  Pairs on the boundary survive needlessly; pass 2 evaluates their key and applies `key < tau`.
             const float tau_t = tau[t];
             float t1 = tau_t + (2e-5f + slack);
             t1 = __uint_as_float(__float_as_uint(t1) + (t1 < __builtin_inff() ? 1u : 0u));       // next float up (tau_t > 0)
-            const float need = (float)GP - t1;                 // survivors have inw > need
+            const float need = (float)(4 * GW) - t1;           // survivors have inw > need (4 GW dimensions are counted)
             const uint32_t thr_in = need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;         // (t1 = +inf: need = -inf)
             uint64_t sm[NCH];
             uint64_t any = 0;
@@ -494,7 +496,11 @@ static hipError_t cbf_launch_one(const float *xq, const void *xh, int64_t m, con
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
     const size_t lds = (size_t)T * (GP / 4 + 1) * 8 + (size_t)T * (GP + 1) * 8 + (size_t)T * CAP * 8 + (size_t)T * 8 + 512 * 5;
-    auto kern = &cbf_filter_kernel<GP, EPL, T, NCH>;
+    // the last count word holds padding only: leave it out (g = 50: 13 of 14 words, 7 % of the counting pass)
+    // (not at GP = 8: LLVM's iterative-ilp scheduler crashes on the one-word instantiation)
+    constexpr int GWD = GP >= 16 ? 1 : 0;
+    const bool trim = GWD == 1 && g <= GP - 4;
+    auto kern = trim ? &cbf_filter_kernel<GP, EPL, T, NCH, GWD> : &cbf_filter_kernel<GP, EPL, T, NCH, 0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds);
     if (e != hipSuccess) return e;
