@@ -178,7 +178,10 @@ int32_t nabo_candidates_per_shard(int32_t kk, int32_t world, int64_t m);
  * row, merge, the owner accepts a row when its k'-th distance lies below every shard's bound; rows it refuses are
  * re-solved exactly in a second, small round); 2 = local certification (every shard's certified first k' entries;
  * the only form for the modified Canberra metric).  The positional drop (nabo/_mapping.py:142) is applied after
- * the merge.  Returns after the communicator's stream has drained. */
+ * the merge.  Returns after the communicator's stream has drained.
+ * Ignored references (ref_mask): with more than one shard a row with fewer than k' unmasked references in the WHOLE
+ * reference set ends in absent entries (-1 / NaN); the one-device path continues such a row with the ignored
+ * references by index, as numpy.ma's NaN fill does (nabo/_mapping.py:135-146). */
 int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
                        int64_t *out_idx, double *out_dist, int32_t protocol);
 /* ms: [0] local query (this rank's shard), [1] exchange, [2] merge + certificate, [3] second round, [4] slice,

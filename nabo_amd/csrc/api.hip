@@ -199,6 +199,7 @@ struct nabo_index {
     const uint8_t *dmask = nullptr;
     int64_t n_masked = 0;
     int n_masked_list = 0;
+    bool shard_mode = false;       // set by nabo_sharded_query around its local queries: no masked tail (see tail_len)
 
     // Euclidean / cosine filter.  mode 0: fp32 MFMA only (l2_topk.hip); mode 1: f16x3 split on the f16 matrix pipe
     // (K-concatenated operands, kc steps of 16 slots; g < 64): l2h_topk.hip (per-wave streaming) or, when shared is set
@@ -247,7 +248,14 @@ int index_device(const nabo_index *ix) { return ix->device; }
 int index_g(const nabo_index *ix) { return ix->g; }
 int index_metric(const nabo_index *ix) { return ix->metric; }
 bool index_can_emit_candidates(const nabo_index *ix) { return ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0; }
+void index_set_shard_mode(nabo_index *ix, bool on) { ix->shard_mode = on; }
 }  // namespace nabo
+
+// Entries of the masked-reference list a row may continue with when it has fewer than k' unmasked references
+// (numpy.ma's NaN fill sorts the ignored references last, by index: nabo/_mapping.py:135-146).  A SHARD must not do
+// that: its masked references would enter the global merge as if they were neighbours (found by the randomised
+// sweep: 40-reference shards, 60 % masked) -- there the tail is left absent (-1 / NaN), which the merge skips.
+static int tail_len(const nabo_index *ix) { return ix->shard_mode ? 0 : ix->n_masked_list; }
 
 // Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernels (K-concatenated f16 tiles).
 static int ensure_packed(nabo_index *ix, bool want_h)
@@ -573,7 +581,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipEventRecord(ix->ev[2], st));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
-                                        (unsigned int)m, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
+                                        (unsigned int)m, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), tail_len(ix),
                                         d_oidx, d_odist, ix->exact_d.as<double>(), (unsigned int)d_rows, st));
         HIP_TRY(hipEventRecord(ix->ev[4], st));
         n_fail = (unsigned int)m;
@@ -790,13 +798,13 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         }
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
-                                    ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
+                                    ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
-                                        ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(),
+                                        tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
                                         ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
@@ -835,7 +843,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if (d_rows > 65535) d_rows = 65535;
             if ((rc = ix->exact_d.reserve((size_t)d_rows * ix->n * sizeof(double)))) return rc;
             HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
-                                            n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list,
+                                            n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), tail_len(ix),
                                             d_oidx, d_odist, ix->exact_d.as<double>(), (unsigned int)d_rows, st));
         }
         HIP_TRY(hipEventRecord(ix->ev[4], st));
@@ -942,12 +950,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             }
             HIP_TRY(nabo::refine_launch(dX, 0, rows_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), SL,
                                         L, nullptr, 0.0, 0.0, 1.0, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
-                                        ix->n_masked_list, d_oidx, d_odist, ix->fails.as<uint32_t>(), d_failcnt, st, 1,
+                                        tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(), d_failcnt, st, 1,
                                         ix->f, plateau));
             if (rows_tail > 0)
                 HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                             ix->cand_tau2.as<float>(), SL2, L, nullptr, 0.0, 0.0, 1.0, k, drop, ix->base,
-                                            n_valid, ix->mlistbuf.as<uint32_t>(), ix->n_masked_list, d_oidx, d_odist,
+                                            n_valid, ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
                                             ix->fails.as<uint32_t>(), d_failcnt, st, 1, ix->f, plateau));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             unsigned int hf[2] = {0, 0};
@@ -994,7 +1002,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             if (n_valid < kk)
                 HIP_TRY(nabo::masked_tail_launch(dX, m, ix->dY, g, ix->metric, ix->f, ix->mlistbuf.as<uint32_t>(),
-                                                 ix->n_masked_list, (int)n_valid, k, drop, ix->base, d_oidx, d_odist, st));
+                                                 tail_len(ix), (int)n_valid, k, drop, ix->base, d_oidx, d_odist, st));
             HIP_TRY(hipEventRecord(ix->ev[4], st));
         }
         n_wg = gx * S;

@@ -261,14 +261,29 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
     float *tau = reinterpret_cast<float *>(idxs + T * CAP);
     int *cnt = reinterpret_cast<int *>(tau + T);
-    uint32_t *wl = reinterpret_cast<uint32_t *>(cnt + T);
+    uint32_t *thr_l = reinterpret_cast<uint32_t *>(cnt + T);        // survivor threshold of the counting pass, per row
+    uint32_t *wl = reinterpret_cast<uint32_t *>(thr_l + T);
     unsigned char *wl_t = reinterpret_cast<unsigned char *>(wl + WLN);
 
     const int S = gridDim.y;
     const int split = blockIdx.y;
     const int64_t row0 = (int64_t)blockIdx.x * T;
     if (row0 >= m) return;                                   // (no barriers in this kernel)
-    for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); cnt[e] = 0; }
+    // Survivor test of the counting pass, ONE compare per chunk.  n_out = 4 GW - inw dimensions are PROVEN out of window,
+    // each adds exactly 1 to the reference's distance and the others add >= 0: distance >= n_out.  A pair is dropped when
+    // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. when inw <= 4 GW - t1; the list key of a pair,
+    //     (all g dimensions out) ? plateau : min(lower bound - slack, below_plateau),
+    // is then >= tau as well (key >= n_out - slack for the first form, and the second only arises for tau <=
+    // plateau).  Pairs on the boundary survive needlessly; pass 2 evaluates their key and applies `key < tau`.
+    // The integer threshold is kept next to tau and recomputed only when tau changes (it cost 9 vector instructions
+    // per row and chunk group inside the counting loop).
+    auto count_threshold = [&](float tau_t) -> uint32_t {
+        float t1 = tau_t + (2e-5f + slack);
+        t1 = __uint_as_float(__float_as_uint(t1) + (t1 < __builtin_inff() ? 1u : 0u));           // next float up (tau_t > 0)
+        const float need = (float)(4 * GW) - t1;               // survivors have inw > need (4 GW dimensions are counted)
+        return need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;                              // (t1 = +inf: need = -inf)
+    };
+    for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); cnt[e] = 0; thr_l[e] = 0u; }
     for (int e = lane; e < T * GH; e += 64) {
         const int64_t row = row0 + e / GH;
         xs[(e / GH) * GHS + e % GH] = row < m ? xh[row * GH + e % GH] : make_uint2(0u, 0u);
@@ -339,7 +354,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
                     float kr[EPL];
                     uint32_t vr[EPL];
                     const float nt = cbf_compact<EPL>(keys + t2 * CAP, idxs + t2 * CAP, c, kr, vr);
-                    if (lane == 0) { tau[t2] = nt; cnt[t2] = L; }
+                    if (lane == 0) { tau[t2] = nt; cnt[t2] = L; thr_l[t2] = count_threshold(nt); }
                     pend = pend && (key < nt);
                 } else {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
@@ -388,17 +403,7 @@ void cbf_filter_kernel(const float2 *__restrict__ xq, const uint2 *__restrict__ 
                     inw[c] += (uint32_t)__builtin_popcount(__builtin_amdgcn_bitop3_b32(a, b, 0x80808080u, 0x80));
                 }
             }
-            // Survivor test, ONE compare per chunk.  n_out = 4 GW - inw dimensions are PROVEN out of window, each adds
-            // exactly 1 to the reference's distance and the others add >= 0: distance >= n_out.  A pair is dropped when
-            // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. when inw <= 4 GW - t1; the list key of a pair,
-            //     (all g dimensions out) ? plateau : min(lower bound - slack, below_plateau),
-            // is then >= tau as well (key >= n_out - slack for the first form, and the second only arises for tau <=
-            // plateau).  Pairs on the boundary survive needlessly; pass 2 evaluates their key and applies `key < tau`.
-            const float tau_t = tau[t];
-            float t1 = tau_t + (2e-5f + slack);
-            t1 = __uint_as_float(__float_as_uint(t1) + (t1 < __builtin_inff() ? 1u : 0u));       // next float up (tau_t > 0)
-            const float need = (float)(4 * GW) - t1;           // survivors have inw > need (4 GW dimensions are counted)
-            const uint32_t thr_in = need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;         // (t1 = +inf: need = -inf)
+            const uint32_t thr_in = thr_l[t];                  // survivors have inw >= thr_in (count_threshold above)
             uint64_t sm[NCH];
             uint64_t any = 0;
 #pragma unroll
@@ -495,7 +500,7 @@ static hipError_t cbf_launch_one(const float *xq, const void *xh, int64_t m, con
     const int64_t cps = (n_chunks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)T * (GP / 4 + 1) * 8 + (size_t)T * (GP + 1) * 8 + (size_t)T * CAP * 8 + (size_t)T * 8 + 512 * 5;
+    const size_t lds = (size_t)T * (GP / 4 + 1) * 8 + (size_t)T * (GP + 1) * 8 + (size_t)T * CAP * 8 + (size_t)T * 12 + 512 * 5;
     // the last count word holds padding only: leave it out (g = 50: 13 of 14 words, 7 % of the counting pass)
     // (not at GP = 8: LLVM's iterative-ilp scheduler crashes on the one-word instantiation)
     constexpr int GWD = GP >= 16 ? 1 : 0;

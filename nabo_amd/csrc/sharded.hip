@@ -53,6 +53,7 @@ int index_device(const nabo_index *ix);
 int index_g(const nabo_index *ix);
 int index_metric(const nabo_index *ix);
 bool index_can_emit_candidates(const nabo_index *ix);
+void index_set_shard_mode(nabo_index *ix, bool on);
 }  // namespace nabo
 
 namespace {
@@ -496,8 +497,24 @@ int nabo_comm_barrier(nabo_comm *c)
     return nabo_comm_allreduce_max_f64(c, &z);
 }
 
+static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
+                              int64_t *out_idx, double *out_dist, int32_t protocol);
+
 int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
                        int64_t *out_idx, double *out_dist, int32_t protocol)
+{
+    // With more than one shard, a shard's local queries must not continue a short row with its MASKED references
+    // (api.hip: tail_len): they would enter the merge as neighbours.  Rows with fewer than k' unmasked references in
+    // the WHOLE reference set then end in absent entries (-1 / NaN) instead of the ignored references by index.
+    const bool shards = c && ix && c->world > 1;
+    if (shards) nabo::index_set_shard_mode(ix, true);
+    const int rc = sharded_query_impl(c, ix, X, m, k, drop_first, out_idx, out_dist, protocol);
+    if (shards) nabo::index_set_shard_mode(ix, false);
+    return rc;
+}
+
+static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
+                              int64_t *out_idx, double *out_dist, int32_t protocol)
 {
     if (!c || !ix || !X || !out_idx || !out_dist) return api_fail(NABO_E_INVALID, "NULL argument");
     if (m < 1 || k < 1) return api_fail(NABO_E_INVALID, "bad shape m=%lld k=%d", (long long)m, k);

@@ -104,6 +104,30 @@ def test_sharded_query_on_one_gpu_equals_unsharded_and_oracle(gpu_lib, N, m, n, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("metric", [0, 1, 2])
+def test_shards_with_fewer_unmasked_references_than_k_do_not_leak_ignored_ones(gpu_lib, metric):
+    """Found by tools/stress_sweep2.py: a 40-reference shard with 60 % of its references ignored has fewer than k'
+    unmasked ones; its local query used to continue the row with the IGNORED references (the one-device rule for short
+    rows, nabo/_mapping.py:135-146) and those entered the global merge as neighbours."""
+    rng = np.random.default_rng(74)
+    n, m, g, k, N = 200, 301, 19, 14, 5
+    Y = pca_like(n, g, seed=741)
+    Y[rng.integers(0, n, n // 3)] = Y[int(rng.integers(0, n))]          # a block of identical references: ties
+    X = pca_like(m, g, seed=742)
+    mask = (rng.random(n) < 0.6).astype(np.uint8)
+    mask[:40] = 1
+    mask[3:11] = 0                                                     # shard 0 keeps 8 of its 40 references
+    assert int((mask == 0).sum()) >= k and min(int((mask[lo:hi] == 0).sum()) for lo, hi in
+                                               (_sharded.shard_bounds(n, N, r) for r in range(N))) < k
+    grp = _sharded.LoopbackGroup(N, 0, n, g, metric, Y, ref_mask=mask).set_ref()
+    gi, gd = grp.query(X, k)
+    grp.close()
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, nthreads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert not mask[gi].any()
+
+
+@pytest.mark.gpu
 def test_every_rank_ends_with_the_same_full_result(gpu_lib):
     from nabo_amd import _knn
     N, m, n, g, k = 4, 1234, 9000, 24, 10
