@@ -1,3 +1,4 @@
+# round 2: cycles, held clock and matrix-pipe occupancy of the f16x3 kernels on the current build, one --pmc pass each
 set -e
 TAG=${TAG:-r2w}
 O=$PWD/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
@@ -15,17 +16,14 @@ for r in csv.DictReader(open("$O/pmc_${name}_summary.csv")):
     if "topk_kernel" in r["kernel"]: c[r["counter"]] = c.get(r["counter"], 0) + float(r["sum"])
 ms = d["roofline"]["kernel_ms"]
 cyc = c["GRBM_GUI_ACTIVE"] / 8
-print("%-12s kernel_ms %.1f  cycles/SIMD %.3e  clock %.3f GHz  matrix pipe busy %.1f %%  VALU insts (incl. MFMA) %.3e  fallback %s"
-      % ("$name", ms, cyc, cyc / ms / 1e6, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), c["SQ_INSTS_VALU"], d.get("fallback_rows")))
+print("%-24s %-16s kernel_ms %.1f  cycles/SIMD %.3e  clock held %.3f GHz  matrix pipe busy %.1f %%  VALU insts (incl. MFMA) %.3e  fallback rows %s  digest %s"
+      % ("$name", d["roofline"]["kernel"].split("<")[0], ms, cyc, cyc / ms / 1e6, 100 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), c["SQ_INSTS_VALU"], d.get("fallback_rows"), d.get("so_digest")))
 PY
 }
-pm l2q NABO_L2_MODE=f16x3q
-pm l2q_nohit NABO_L2_MODE=f16x3q NABO_DEBUG_ABLATE=1
-pm l2h
-pm l2h_nohit NABO_DEBUG_ABLATE=1
+pm default_16x16x32
+pm default_16x16x32_nohit NABO_DEBUG_ABLATE=1
+pm f16x3h_32x32x16 NABO_L2_MODE=f16x3h
+pm f16x3h_32x32x16_nohit NABO_L2_MODE=f16x3h NABO_DEBUG_ABLATE=1
+pm f16x3s_shared_tiles NABO_L2_MODE=f16x3s
+pm f32 NABO_L2_MODE=f32
 cat $O/ab.txt
-NABO_KNN_SO=$PWD/tools/ab/prof.so NABO_L2_MODE=f16x3q python bench.py $B --steps 1 --warmup 0 2>&1 >/dev/null | grep "lists prof" | tail -1
-NABO_KNN_SO=$PWD/tools/ab/prof.so python bench.py $B --steps 1 --warmup 0 2>&1 >/dev/null | grep "lists prof" | tail -1
-pm l2q_l1win NABO_L2_MODE=f16x3q NABO_DEBUG_ABLATE=5
-pm l2q_l2win NABO_L2_MODE=f16x3q NABO_DEBUG_ABLATE=3
-tail -2 $O/ab.txt
