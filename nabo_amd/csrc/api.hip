@@ -51,11 +51,12 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
                          unsigned int *fail_count, hipStream_t st, int metric = 0, double cb_f = 0.0,
-                         float cb_plateau = 0.0f);
+                         float cb_plateau = 0.0f, int lvalid = 0);
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
-                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0);
+                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0,
+                              int lvalid = 0);
 hipError_t normalise_rows_launch(const double *X, int64_t m, int g, double *out, hipStream_t st);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
@@ -773,12 +774,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (cand_mode) {
             HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(),
                                              S, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
-                                             n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0));
+                                             n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0, lkeep));
             if (gx_tail > 0)
                 HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                                  ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                                  ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st,
-                                                 cosine ? 2 : 0));
+                                                 cosine ? 2 : 0, lkeep));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             HIP_TRY(hipEventRecord(ix->ev[4], st));
             HIP_TRY(hipEventRecord(ix->ev[5], st));
@@ -799,13 +800,14 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
-                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0));
+                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f,
+                                    lkeep));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
-                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0));
+                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                                                      const uint32_t *__restrict__ masked_list, int n_masked_list,
                                                      int64_t *__restrict__ out_idx, double *__restrict__ out_dist,
                                                      uint32_t *__restrict__ fail_rows,
-                                                     unsigned int *__restrict__ fail_count)
+                                                     unsigned int *__restrict__ fail_count, int stage_rows)
 {
     // rows [row0, m) of X; candidate arrays are indexed by the row LOCAL to this launch
     const int lane = lane_id();
@@ -166,17 +166,24 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     if (STAGE) {
         extern __shared__ __attribute__((aligned(16))) unsigned char refine_smem[];
         const int gp = g | 1;                                  // odd row stride (in doubles): lanes spread over the banks
-        double *stg = reinterpret_cast<double *>(refine_smem) + (size_t)(threadIdx.x >> 6) * ncand * gp;
+        double *stg = reinterpret_cast<double *>(refine_smem) + (size_t)(threadIdx.x >> 6) * stage_rows * gp;
         const uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
-        for (int c = 0; c < ncand; ++c) {
-            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)myj, c);
-            if (j != 0xFFFFFFFFu && lane < g) stg[c * gp + lane] = Y[(int64_t)j * g + lane];
+        // valid candidates are packed into the first stage_rows LDS rows (the lists hold <= lkeep of their L entries:
+        // sizing the block for all S * L kept the kernel at three waves per SIMD)
+        uint64_t live = __builtin_amdgcn_ballot_w64(myj != 0xFFFFFFFFu);
+        const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+        for (int c = 0; live != 0; ++c) {
+            const int src = __builtin_ctzll(live);
+            live &= live - 1;
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)myj, src);
+            if (c < stage_rows && lane < g) stg[c * gp + lane] = Y[(int64_t)j * g + lane];
         }
         key[0] = __builtin_inf();
         val[0] = 0xFFFFFFFFu;
         if (myj != 0xFFFFFFFFu) {
             val[0] = myj;
-            key[0] = exact_dist(MET, x, stg + lane * gp, g, cb_f);
+            key[0] = slot < stage_rows ? exact_dist(MET, x, stg + slot * gp, g, cb_f)
+                                       : exact_dist(MET, x, Y + (int64_t)myj * g, g, cb_f);
         }
     } else {
 #pragma unroll
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
 // the emitted candidates: min over splits of (tau * scale + ||x~||^2 - E), and additionally the squared
 // distance of the first candidate that did not fit into `kout`.  +inf when nothing was dropped, -inf when
 // the filter saw non-finite scores (forces the exact second phase).
-template <int NCL, int MET>
+template <int NCL, int MET, bool STAGE>
 __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                           const double *__restrict__ Y, int g,
                                                           const uint32_t *__restrict__ cand_idx,
@@ -289,7 +296,8 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
                                                           const double *__restrict__ xnorm, double err_coef,
                                                           double ymax_sqrt, double tau_scale, int kout, int64_t base,
                                                           int64_t n_valid_total, int64_t *__restrict__ out_idx,
-                                                          double *__restrict__ out_dist, double *__restrict__ out_bound)
+                                                          double *__restrict__ out_dist, double *__restrict__ out_bound,
+                                                          int stage_rows)
 {
     const int lane = lane_id();
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -299,16 +307,40 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
     const int ncand = S * L;
     double key[NCL];
     uint32_t val[NCL];
+    if (STAGE) {                                               // coalesced candidate rows through LDS (refine_kernel)
+        extern __shared__ __attribute__((aligned(16))) unsigned char refine_smem[];
+        const int gp = g | 1;
+        double *stg = reinterpret_cast<double *>(refine_smem) + (size_t)(threadIdx.x >> 6) * stage_rows * gp;
+        const uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
+        // valid candidates are packed into the first stage_rows LDS rows (the lists hold <= lkeep of their L entries:
+        // sizing the block for all S * L kept the kernel at three waves per SIMD)
+        uint64_t live = __builtin_amdgcn_ballot_w64(myj != 0xFFFFFFFFu);
+        const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
+        for (int c = 0; live != 0; ++c) {
+            const int src = __builtin_ctzll(live);
+            live &= live - 1;
+            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)myj, src);
+            if (c < stage_rows && lane < g) stg[c * gp + lane] = Y[(int64_t)j * g + lane];
+        }
+        key[0] = __builtin_inf();
+        val[0] = 0xFFFFFFFFu;
+        if (myj != 0xFFFFFFFFu) {
+            val[0] = myj;
+            key[0] = slot < stage_rows ? exact_dist(MET, x, stg + slot * gp, g, 0.0)
+                                       : exact_dist(MET, x, Y + (int64_t)myj * g, g, 0.0);
+        }
+    } else {
 #pragma unroll
-    for (int r = 0; r < NCL; ++r) {
-        const int e = r * 64 + lane;
-        key[r] = __builtin_inf();
-        val[r] = 0xFFFFFFFFu;
-        if (e < ncand) {
-            const uint32_t j = cand_idx[lrow * ncand + e];
-            if (j != 0xFFFFFFFFu) {
-                val[r] = j;
-                key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, 0.0);
+        for (int r = 0; r < NCL; ++r) {
+            const int e = r * 64 + lane;
+            key[r] = __builtin_inf();
+            val[r] = 0xFFFFFFFFu;
+            if (e < ncand) {
+                const uint32_t j = cand_idx[lrow * ncand + e];
+                if (j != 0xFFFFFFFFu) {
+                    val[r] = j;
+                    key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, 0.0);
+                }
             }
         }
     }
@@ -572,18 +604,20 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          double ymax_sqrt, double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total,
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
                          uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st, int metric = 0,
-                         double cb_f = 0.0, float cb_plateau = 0.0f)
+                         double cb_f = 0.0, float cb_plateau = 0.0f, int lvalid = 0)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
     // staged gather: one candidate per lane, rows of <= 64 components, 4 waves x S*L rows within 64 KB of LDS
-    const size_t stage_bytes = (size_t)4 * S * L * (g | 1) * sizeof(double);
+    // lvalid: entries of a list that can be valid (lkeep; 0 = all L)
+    const int stage_rows = S * ((lvalid > 0 && lvalid < L) ? lvalid : L);
+    const size_t stage_bytes = (size_t)4 * stage_rows * (g | 1) * sizeof(double);
     const bool stage = ncl <= 1 && g <= 64 && stage_bytes <= 65536;
 #define NABO_RF2(N, MV, SV)                                                                                          \
     hipLaunchKernelGGL((refine_kernel<N, MV, SV>), grid, block, SV ? stage_bytes : 0, st, X, row0, m, Y, g, cand_idx,   \
                        cand_tau, S, L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,       \
-                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count)
+                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count, stage_rows)
 #define NABO_RF(N)                                                                                               \
     do {                                                                                                         \
         if (metric == 1) NABO_RF2(N, 1, false);                                                                  \
@@ -609,28 +643,35 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
-                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0)
+                              int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0,
+                              int lvalid = 0)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
     dim3 grid((unsigned)((m - row0 + 3) / 4)), block(256);
+    const int stage_rows = S * ((lvalid > 0 && lvalid < L) ? lvalid : L);
+    const size_t stage_bytes = (size_t)4 * stage_rows * (g | 1) * sizeof(double);
+    const bool stage = ncl <= 1 && g <= 64 && stage_bytes <= 65536;
+#define NABO_RC2(N, MV, SV)                                                                                             \
+    hipLaunchKernelGGL((refine_cand_kernel<N, MV, SV>), grid, block, SV ? stage_bytes : 0, st, X, row0, m, Y, g, cand_idx, \
+                       cand_tau, S, L, xnorm, err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx,       \
+                       out_dist, out_bound, stage_rows)
 #define NABO_RC(N)                                                                                                  \
     do {                                                                                                            \
-        if (metric == 2)                                                                                            \
-            hipLaunchKernelGGL((refine_cand_kernel<N, 2>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
-                               L, xnorm, err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx, out_dist, \
-                               out_bound);                                                                          \
-        else                                                                                                        \
-            hipLaunchKernelGGL((refine_cand_kernel<N, 0>), grid, block, 0, st, X, row0, m, Y, g, cand_idx, cand_tau, S, \
-                               L, xnorm, err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx, out_dist, \
-                               out_bound);                                                                          \
+        if (metric == 2) NABO_RC2(N, 2, false);                                                                     \
+        else NABO_RC2(N, 0, false);                                                                                 \
     } while (0)
+    if (stage) {
+        if (metric == 2) NABO_RC2(1, 2, true);
+        else NABO_RC2(1, 0, true);
+    } else
     if (ncl <= 1) NABO_RC(1);
     else if (ncl <= 2) NABO_RC(2);
     else if (ncl <= 4) NABO_RC(4);
     else if (ncl <= 8) NABO_RC(8);
     else if (ncl <= 16) NABO_RC(16);
     else return hipErrorInvalidValue;
+#undef NABO_RC2
 #undef NABO_RC
     return hipGetLastError();
 }

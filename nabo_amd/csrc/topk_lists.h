@@ -106,9 +106,13 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
 }
 
 // Batched list updates: one lane per staged record (see the header comment).
+#ifndef NABO_RESCAN
+#define NABO_RESCAN 16
+#endif
 template <typename C>
 __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt, int lkeep)
 {
+    constexpr int RESCAN = NABO_RESCAN;
     const int lane = lane_id();
     // volatile: lanes of one wave hand rows over to each other through these words.  The arbitration stores the lane
     // id and reads the word back to learn WHICH lane's store the LDS kept -- without volatile hipcc forwards the stored
@@ -161,16 +165,16 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
                 }
             }
             if (__builtin_amdgcn_ballot_w64(repl) != 0) {       // new maximum of the rows that changed
-                // eight keys per round trip: a one-key-at-a-time scan is a chain of lkeep dependent LDS latencies;
+                // RESCAN keys per round trip: a one-key-at-a-time scan is a chain of lkeep dependent LDS latencies;
                 // reads past lkeep (the next row, the header area) are masked
                 float t = -__builtin_inff();
                 uint32_t p = 0;
-                for (int i0 = 0; i0 < lkeep; i0 += 8) {
-                    float kq[8];
+                for (int i0 = 0; i0 < lkeep; i0 += RESCAN) {
+                    float kq[RESCAN];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
+                    for (int j = 0; j < RESCAN; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < RESCAN; ++j) {
                         const bool gt = (i0 + j < lkeep) && (kq[j] > t);
                         t = gt ? kq[j] : t;
                         p = gt ? (uint32_t)(i0 + j) : p;
