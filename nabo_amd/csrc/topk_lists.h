@@ -107,7 +107,7 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
 
 // Batched list updates: one lane per staged record (see the header comment).
 #ifndef NABO_RESCAN
-#define NABO_RESCAN 16
+#define NABO_RESCAN 12
 #endif
 template <typename C>
 __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt, int lkeep)
