@@ -146,7 +146,20 @@ def main():
     X = pca_like(m, d, seed=2003)
     force_comm = os.environ.get("NABO_BENCH_FORCE_COMM") == "1"      # rehearsal: the N>1 code path with one rank
     comm = _sharded.Comm.from_env(dev) if (world > 1 or force_comm) else None
-    lo, hi = shard_bounds(n, world, rank)
+    # Layout of the N ranks: R reference pieces x N / R target slices.  Every row fills a candidate list on
+    # EVERY piece, so that part of a rank's work does not shrink with the piece; a 1M x 50 reference set (0.4 GB of 288)
+    # has no need to be cut eight ways.  Default: two pieces from four ranks on (the exchange / merge / certificate of the
+    # prescribed ref-sharded form inside each pair, the gather over all ranks); NABO_REF_SHARDS=<N> is the 1-D form.
+    # (Modified Canberra shards exchange certified lists: 1-D only.)
+    ranks = max(world, loop, 1)
+    R = int(os.environ.get("NABO_REF_SHARDS", "0"))
+    if R <= 0:
+        R = 2 if (ranks >= 4 and ranks % 2 == 0 and a.metric != "canberra") else ranks
+    if ranks % R:
+        raise SystemExit("NABO_REF_SHARDS must divide the number of ranks")
+    if comm is not None and R != world:
+        comm.set_ref_shards(R)
+    lo, hi = shard_bounds(n, R if world > 1 else 1, rank % R if world > 1 else 0)
     dX = _knn.DeviceBuffer(X.nbytes, dev).upload(X)
     dY = _knn.DeviceBuffer((hi - lo) * d * 8, dev).upload(np.ascontiguousarray(Yfull[lo:hi]))
     dI = _knn.DeviceBuffer(m * k * 8, dev)
@@ -155,7 +168,7 @@ def main():
     stats, xstats = [], []
 
     if loop > 1:
-        group = _sharded.LoopbackGroup(loop, dev, n, d, metric_id, Yfull)
+        group = _sharded.LoopbackGroup(loop, dev, n, d, metric_id, Yfull, ref_shards=R)
 
         def step():
             group.set_ref()
@@ -217,13 +230,15 @@ def main():
         assert same
 
     if rank == 0:
-        shards = max(world, loop, 1)
+        shards, slices = R, ranks // R
         so = _lib.so_digest()
         kern = index.last_kernel() if loop <= 1 else group.indices[0].last_kernel()
         ms_step = dt / a.steps * 1e3
         t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events on the kernel's own stream
-        n_shard = (hi - lo) if loop <= 1 else shard_bounds(n, loop, 0)[1]
+        n_shard = (hi - lo) if loop <= 1 else shard_bounds(n, R, 0)[1]
         workload = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, shards)
+        if slices > 1:
+            workload += " x %d target slices" % slices
         line = {
             "metric": "cell-pair distances/s (k-NN build, 1Mx1M d=50 k=15)" if (m, n, d, k) == (1000000, 1000000, 50, 15)
                       else "cell-pair distances/s (k-NN build)",
@@ -232,7 +247,7 @@ def main():
             "knn_build_s": dt / a.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if "f32_32x32x2" in kern else ("f16" if "f16" in kern else "f64"), "data": "synthetic",
-            "config": {"workload": workload, "parallelism": "ref-shard%d" % shards,
+            "config": {"workload": workload, "parallelism": "ref-shard%d" % shards + ("-slice%d" % slices if slices > 1 else ""),
                        "arithmetic": "low-precision score filter on the matrix pipe, float64 re-evaluation + certification: "
                                      "indices and distances equal the reference's float64 path"},
             "phases_ms": {key: float(np.mean([s[key] for s in stats])) for key in
@@ -241,7 +256,7 @@ def main():
             "so_digest": so,
         }
         if a.metric != "canberra":
-            flops = 2.0 * m * n_shard * d                                     # algorithmic: the -2XY^T term
+            flops = 2.0 * (m / slices) * n_shard * d                          # algorithmic (this rank): the -2XY^T term
             achieved = flops / t_kernel / 1e12
             f16 = "f16" in kern
             peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
@@ -260,6 +275,8 @@ def main():
             line["roofline"] = canberra_roofline(rec, t_kernel, kern)
         if xstats:
             line["sharded"] = {"world": world, "loopback_ranks": loop if loop > 1 else None,
+                               "layout": {"ref_shards": shards, "target_slices": slices,
+                                          "note": "NABO_REF_SHARDS=%d is the 1-D form (one piece per rank)" % ranks},
                                "exchange_ms": float(np.mean([x["ms_exchange"] for x in xstats])),
                                "merge_ms": float(np.mean([x["ms_merge"] for x in xstats])),
                                "gather_ms": float(np.mean([x["ms_gather"] for x in xstats])),

@@ -163,6 +163,12 @@ int nabo_comm_rank(const nabo_comm *c);
 int nabo_comm_world(const nabo_comm *c);
 /* Collective helpers for a host that has no other communication layer (bench.py's timing bracket):
  * barrier, and MAX over ranks of one non-negative host double (in place). */
+/* 2-D layout for the sharded query (optional; 0 or the world size = the 1-D form): the references are cut into
+ * ref_shards pieces, rank r holds piece r % ref_shards (the caller builds its index from that piece) and answers for target
+ * slice r / ref_shards; the exchange, merge and certificate run inside each group of ref_shards ranks, the final gather
+ * over all ranks.  A shard's list work does not shrink with the shard (every row fills a list on every piece): fewer,
+ * larger pieces cost less of it.  ref_shards must divide the world size; global-certification protocol only. */
+int nabo_comm_set_ref_shards(nabo_comm *c, int32_t ref_shards);
 int nabo_comm_barrier(nabo_comm *c);
 int nabo_comm_allreduce_max_f64(nabo_comm *c, double *value);
 

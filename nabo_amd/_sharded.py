@@ -120,6 +120,12 @@ class Comm:
         _lib.check(getattr(_lib.lib(), fn)(hs, dv, n))
         return [cls(C.c_void_p(hs[i]), int(devices[i]), i, n) for i in range(n)]
 
+    def set_ref_shards(self, ref_shards):
+        """2-D layout (include/nabo_knn.h: nabo_comm_set_ref_shards); the caller's index must hold piece rank % ref_shards."""
+        _lib.check(_lib.lib().nabo_comm_set_ref_shards(self._h, int(ref_shards)))
+        self.ref_shards = int(ref_shards)
+        return self
+
     def barrier(self):
         _lib.check(_lib.lib().nabo_comm_barrier(self._h))
 
@@ -170,14 +176,23 @@ class ShardedGroup:
     (the C calls release the GIL; the collectives inside nabo_sharded_query rendezvous the threads).
     transport "rccl": one GPU per rank, ncclCommInitAll; "loopback": device-to-device copies, devices may repeat."""
 
-    def __init__(self, devices, n_ref, g, metric, Y, dist_factor=0.25, ref_mask=None, transport="rccl", protocol="auto"):
+    def __init__(self, devices, n_ref, g, metric, Y, dist_factor=0.25, ref_mask=None, transport="rccl", protocol="auto",
+                 ref_shards=None):
+        """ref_shards (optional, divides the number of ranks): the 2-D layout of nabo_comm_set_ref_shards -- the
+        references in ref_shards pieces (rank r holds piece r % ref_shards), the target rows in len(devices) / ref_shards
+        slices; None = one piece per rank."""
         from ._knn import KnnIndex
         self.devices = [int(d) for d in devices]
         N = len(self.devices)
+        R = N if ref_shards is None else int(ref_shards)
+        if R < 1 or N % R:
+            raise ValueError("ref_shards must divide the number of ranks")
         self.comms = Comm.loopback(self.devices) if transport == "loopback" else Comm.all_devices(self.devices)
+        for c in self.comms:
+            c.set_ref_shards(R)
         self.indices, self._Y, self._mask = [], [], []
         for r in range(N):
-            lo, hi = shard_bounds(n_ref, N, r)
+            lo, hi = shard_bounds(n_ref, R, r % R)
             self.indices.append(KnnIndex(hi - lo, g, metric=metric, dist_factor=dist_factor, ref_index_base=lo,
                                          device=self.devices[r]))
             self._Y.append(np.ascontiguousarray(Y[lo:hi], dtype=np.float64))

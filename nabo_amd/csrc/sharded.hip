@@ -175,6 +175,9 @@ struct nabo_comm {
     double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
     int group_depth = 0;
+    // 2-D layout (nabo_comm_set_ref_shards): the references are cut into ref_shards pieces, rank r holds piece
+    // r % ref_shards and answers for target slice r / ref_shards; 0 = world (every rank its own piece: the 1-D form)
+    int ref_shards = 0;
 };
 
 namespace {
@@ -192,26 +195,28 @@ int group_end(nabo_comm *c)
     return NABO_OK;
 }
 
-// block p of `send` (bytes each) goes to peer p; block p of `recv` comes from peer p
-int all_to_all(nabo_comm *c, const void *send, void *recv, size_t bytes)
+// Among the ranks [first, first + count) (the caller's rank is one of them; every rank of the world makes the call,
+// with its own group): block b of `send` (bytes each) goes to peer first + b; block b of `recv` comes from peer first + b.
+int all_to_all(nabo_comm *c, const void *send, void *recv, size_t bytes, int first = 0, int count = -1)
 {
-    const int N = c->world;
+    const int N = count < 0 ? c->world : count;
+    const int me = c->rank - first;
     if (bytes == 0) return NABO_OK;
     if (c->kind == 0) {
         int rc = group_begin(c);
         if (rc) return rc;
-        for (int p = 0; p < N; ++p) {
-            RCCL_TRY(g_rccl.Send(static_cast<const char *>(send) + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, c->stream));
-            RCCL_TRY(g_rccl.Recv(static_cast<char *>(recv) + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, c->stream));
+        for (int b = 0; b < N; ++b) {
+            RCCL_TRY(g_rccl.Send(static_cast<const char *>(send) + (size_t)b * bytes, bytes, ncclUint8, first + b, c->nccl, c->stream));
+            RCCL_TRY(g_rccl.Recv(static_cast<char *>(recv) + (size_t)b * bytes, bytes, ncclUint8, first + b, c->nccl, c->stream));
         }
         return group_end(c);
     }
     HIP_TRY(hipStreamSynchronize(c->stream));                 // my send buffer is final
     c->hub->ptr[c->rank] = send;
     pthread_barrier_wait(&c->hub->bar);
-    for (int p = 0; p < N; ++p)
-        HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + (size_t)p * bytes,
-                               static_cast<const char *>(c->hub->ptr[p]) + (size_t)c->rank * bytes, bytes, hipMemcpyDefault,
+    for (int b = 0; b < N; ++b)
+        HIP_TRY(hipMemcpyAsync(static_cast<char *>(recv) + (size_t)b * bytes,
+                               static_cast<const char *>(c->hub->ptr[first + b]) + (size_t)me * bytes, bytes, hipMemcpyDefault,
                                c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     pthread_barrier_wait(&c->hub->bar);                       // nobody reuses a send buffer before all have copied
@@ -466,6 +471,15 @@ int nabo_comm_destroy(nabo_comm *c)
 int nabo_comm_rank(const nabo_comm *c) { return c ? c->rank : -1; }
 int nabo_comm_world(const nabo_comm *c) { return c ? c->world : -1; }
 
+int nabo_comm_set_ref_shards(nabo_comm *c, int32_t ref_shards)
+{
+    if (!c) return api_fail(NABO_E_INVALID, "NULL communicator");
+    if (ref_shards < 0 || (ref_shards > 0 && c->world % ref_shards != 0))
+        return api_fail(NABO_E_INVALID, "ref_shards = %d does not divide the world size %d", ref_shards, c->world);
+    c->ref_shards = ref_shards == c->world ? 0 : ref_shards;
+    return NABO_OK;
+}
+
 int nabo_comm_allreduce_max_f64(nabo_comm *c, double *value)
 {
     if (!c || !value) return api_fail(NABO_E_INVALID, "NULL argument");
@@ -524,9 +538,17 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
     const int N = c->world, g = nabo::index_g(ix);
     const int d0 = drop_first ? 1 : 0, kk = k + d0;
     const int64_t mr = (m + N - 1) / N, m_pad = mr * N, row0 = (int64_t)c->rank * mr;
+    // 2-D layout: R reference pieces x N / R target slices; my group = the R ranks [gfirst, gfirst + R) that hold the
+    // pieces for my slice, rows [s0, s0 + R mr) (ms of them exist).  R = N: one group, the whole batch (the 1-D form).
+    const int R = c->ref_shards > 0 ? c->ref_shards : N;
+    const int gfirst = (c->rank / R) * R;
+    const int64_t s0 = (int64_t)gfirst * mr, ms_pad = (int64_t)R * mr;
+    const int64_t ms = m - s0 < 0 ? 0 : (m - s0 < ms_pad ? m - s0 : ms_pad);
     hipStream_t st = c->stream;
     // protocol: 0 auto, 1 global certification, 2 local certification
-    const bool can_cand = nabo::index_can_emit_candidates(ix) && (kk + N - 1) / N <= 32;
+    const bool can_cand = nabo::index_can_emit_candidates(ix) && (kk + R - 1) / R <= 32;
+    if (R != N && (protocol == 2 || !can_cand))
+        return api_fail(NABO_E_UNSUPPORTED, "the 2-D shard layout (ref_shards = %d of %d ranks) needs the global-certification protocol", R, N);
     if (protocol == 1 && !can_cand) return api_fail(NABO_E_UNSUPPORTED, "global certification needs the Euclidean / cosine filter and k'/N <= 32");
     const bool global = protocol == 1 || (protocol == 0 && can_cand && N > 1);
     if ((int64_t)N * (global ? 32 : kk) > 1024 && !global) return api_fail(NABO_E_UNSUPPORTED, "N * (k + drop_first) = %d exceeds the merge width 1024", N * kk);
@@ -538,35 +560,36 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
     const unsigned blk = 256;
 
     if (global) {
-        const int Ls = nabo_candidates_per_shard(kk, N, m);
+        const int Ls = nabo_candidates_per_shard(kk, R, m);
         c->counters[1] = Ls;
-        const size_t li = (size_t)m_pad * Ls * 8, lb = (size_t)m_pad * 8;
+        const size_t li = (size_t)ms_pad * Ls * 8, lb = (size_t)ms_pad * 8;
         if ((rc = c->ci.reserve(li)) || (rc = c->cd.reserve(li)) || (rc = c->cb.reserve(lb)) || (rc = c->ri.reserve(li)) ||
             (rc = c->rd.reserve(li)) || (rc = c->rb.reserve(lb)))
             return rc;
-        if (m_pad != m) {          // ragged tail: absent entries, +inf bounds
-            const int64_t nx = (m_pad - m) * Ls;
+        if (ms_pad != ms) {        // ragged tail of my slice: absent entries, +inf bounds
+            const int64_t nx = (ms_pad - ms) * Ls;
             hipLaunchKernelGGL(fill_absent_kernel, dim3((unsigned)((nx + blk - 1) / blk)), dim3(blk), 0, st,
-                               c->ci.as<int64_t>() + m * Ls, c->cd.as<double>() + m * Ls, nx, c->cb.as<double>() + m, m_pad - m);
+                               c->ci.as<int64_t>() + ms * Ls, c->cd.as<double>() + ms * Ls, nx, c->cb.as<double>() + ms, ms_pad - ms);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(st));
         }
-        if ((rc = nabo_index_query_candidates(ix, X, 1, m, Ls, c->ci.as<int64_t>(), c->cd.as<double>(), c->cb.as<double>())))
+        if (ms > 0 && (rc = nabo_index_query_candidates(ix, X + s0 * g, 1, ms, Ls, c->ci.as<int64_t>(), c->cd.as<double>(),
+                                                        c->cb.as<double>())))
             return rc;
         (void)hipSetDevice(c->device);
         HIP_TRY(hipEventRecord(c->ev[1], st));
         if ((rc = group_begin(c))) return rc;
-        if ((rc = all_to_all(c, c->ci.p, c->ri.p, (size_t)mr * Ls * 8))) return rc;
-        if ((rc = all_to_all(c, c->cd.p, c->rd.p, (size_t)mr * Ls * 8))) return rc;
-        if ((rc = all_to_all(c, c->cb.p, c->rb.p, (size_t)mr * 8))) return rc;
+        if ((rc = all_to_all(c, c->ci.p, c->ri.p, (size_t)mr * Ls * 8, gfirst, R))) return rc;
+        if ((rc = all_to_all(c, c->cd.p, c->rd.p, (size_t)mr * Ls * 8, gfirst, R))) return rc;
+        if ((rc = all_to_all(c, c->cb.p, c->rb.p, (size_t)mr * 8, gfirst, R))) return rc;
         if ((rc = group_end(c))) return rc;
         HIP_TRY(hipEventRecord(c->ev[2], st));
-        HIP_TRY(nabo::merge_parts_launch(c->rd.as<double>(), c->ri.as<int64_t>(), N, mr, Ls, kk, 0, c->mi.as<int64_t>(),
+        HIP_TRY(nabo::merge_parts_launch(c->rd.as<double>(), c->ri.as<int64_t>(), R, mr, Ls, kk, 0, c->mi.as<int64_t>(),
                                          c->md.as<double>(), st));
         if ((rc = c->cnt.reserve(64)) || (rc = c->bad.reserve((size_t)mr * 8))) return rc;
         HIP_TRY(hipMemsetAsync(c->cnt.p, 0, 16, st));
         hipLaunchKernelGGL(certify_kernel, dim3((unsigned)((mr + blk - 1) / blk)), dim3(blk), 0, st, c->mi.as<int64_t>(),
-                           c->md.as<double>(), kk, c->rb.as<double>(), N, mr, row0, m, c->bad.as<int64_t>(),
+                           c->md.as<double>(), kk, c->rb.as<double>(), R, mr, row0, m, c->bad.as<int64_t>(),
                            c->cnt.as<unsigned long long>());
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev[3], st));
@@ -612,8 +635,9 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
             if ((rc = all_gather(c, c->bi.p, c->gi.p, (size_t)nb * kk * 8))) return rc;
             if ((rc = all_gather(c, c->bd.p, c->gd.p, (size_t)nb * kk * 8))) return rc;
             if ((rc = group_end(c))) return rc;
-            HIP_TRY(nabo::merge_parts_launch(c->gd.as<double>(), c->gi.as<int64_t>(), N, nb, kk, kk, 0, c->fi.as<int64_t>(),
-                                             c->fd.as<double>(), st));
+            // (every rank re-solved every refused row on its reference piece; the R parts of MY group cover all pieces)
+            HIP_TRY(nabo::merge_parts_launch(c->gd.as<double>() + (size_t)gfirst * nb * kk, c->gi.as<int64_t>() + (size_t)gfirst * nb * kk,
+                                             R, nb, kk, kk, 0, c->fi.as<int64_t>(), c->fd.as<double>(), st));
             hipLaunchKernelGGL(adopt_kernel, dim3((unsigned)((nb * kk + blk - 1) / blk)), dim3(blk), 0, st, c->sel.as<uint32_t>(), nb,
                                c->fi.as<int64_t>(), c->fd.as<double>(), kk, row0, mr, c->mi.as<int64_t>(), c->md.as<double>());
             HIP_TRY(hipGetLastError());

@@ -128,6 +128,46 @@ def test_shards_with_fewer_unmasked_references_than_k_do_not_leak_ignored_ones(g
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,R,m,n,g,k,drop,metric,sorted_refs", [
+    (8, 2, 3001, 9000, 24, 15, False, 0, False), (4, 2, 700, 5000, 50, 11, True, 0, False),
+    (8, 4, 1234, 12000, 30, 10, False, 2, False), (6, 3, 999, 6000, 16, 15, True, 0, True),
+    (8, 1, 515, 4000, 20, 7, False, 0, False), (4, 2, 5, 3000, 12, 6, False, 0, False)])
+def test_two_dimensional_layout_equals_oracle(gpu_lib, N, R, m, n, g, k, drop, metric, sorted_refs):
+    """nabo_comm_set_ref_shards: R reference pieces x N / R target slices (exchange, merge and certificate inside each
+    group of R ranks, the gather over all N) -- same answer as one device, on every rank, ragged slices and the second
+    round included."""
+    from nabo_amd import _knn
+    Y = pca_like(n, g, seed=900 + n)
+    if sorted_refs:
+        Y = np.ascontiguousarray(Y[np.argsort(Y[:, 0], kind="stable")])
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=950 + m)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, metric, Y, ref_shards=R).set_ref()
+    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
+    outs = [(_knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)) for _ in range(N)]
+    grp.query_device(dx.ptr, m, k, drop, [a.ptr for a, _ in outs], [b.ptr for _, b in outs])
+    st = [grp.last_stats(r) for r in range(N)]
+    res = [(a.download((m, k), np.int64), b.download((m, k), np.float64)) for a, b in outs]
+    grp.close()
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, drop_first=drop, nthreads=8)
+    for gi, gd in res:
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    assert all(s["protocol"] == "global" for s in st)
+    if sorted_refs:
+        assert st[0]["uncertified"] > 0
+
+
+@pytest.mark.gpu
+def test_two_dimensional_layout_rejects_what_it_cannot_do(gpu_lib):
+    Y = pca_like(2000, 10, seed=5)
+    with pytest.raises(ValueError):
+        _sharded.LoopbackGroup(4, 0, 2000, 10, 0, Y, ref_shards=3)
+    grp = _sharded.LoopbackGroup(4, 0, 2000, 10, 1, Y, ref_shards=2).set_ref()       # modified Canberra: local protocol only
+    with pytest.raises(Exception):
+        grp.query(pca_like(10, 10, seed=6), 3)
+    grp.close()
+
+
+@pytest.mark.gpu
 def test_every_rank_ends_with_the_same_full_result(gpu_lib):
     from nabo_amd import _knn
     N, m, n, g, k = 4, 1234, 9000, 24, 10
