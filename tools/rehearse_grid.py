@@ -1,5 +1,5 @@
 """One rank's share of the 8-GPU step under the 2-D layout (R reference pieces x 8/R target slices), measured on ONE GPU:
-the candidate query of piece 0 for slice 0 -- n/R references x m/(8/R) target rows.     python tools/rehearse_grid.py [R]"""
+the candidate query of piece 0 for slice 0 -- n/R references x m/(8/R) target rows.     python tools/rehearse_grid.py [R [N]]"""
 import os
 import sys
 
@@ -9,8 +9,8 @@ from nabo_amd import _knn  # noqa: E402
 from nabo_amd._sharded import shard_bounds, candidates_per_shard  # noqa: E402
 from nabo_amd._synth import pca_like  # noqa: E402
 
-N = 8
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 m, n, d, k = 1000000, 1000000, 50, 15
 Y = pca_like(n, d, seed=1003)
 X = pca_like(m, d, seed=2003)
@@ -23,5 +23,5 @@ di, dd, db = _knn.DeviceBuffer(ms * Ls * 8), _knn.DeviceBuffer(ms * Ls * 8), _kn
 for rep in range(3):
     sx.query_candidates_device(dx.ptr, ms, Ls, di.ptr, dd.ptr, db.ptr)
     st = sx.last_stats()
-print("N=8 as %d reference pieces x %d target slices: a rank queries %d references x %d rows, Ls=%d:" % (R, N // R, hi - lo, ms, Ls),
+print("N=%d as %d reference pieces x %d target slices: a rank queries %d references x %d rows, Ls=%d:" % (N, R, N // R, hi - lo, ms, Ls),
       {k2: round(v, 2) for k2, v in st.items() if k2.startswith("ms_")})
