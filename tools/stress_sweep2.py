@@ -75,7 +75,11 @@ for case in range(n_cases):
                 mask = None
         if min(_sharded.shard_bounds(n, N, r)[1] - _sharded.shard_bounds(n, N, r)[0] for r in range(N)) < kk:
             continue                                      # a shard must hold k' references (include/nabo_knn.h)
-        grp = _sharded.LoopbackGroup(N, 0, n, g, metric, Y, ref_mask=mask).set_ref()
+        # the 2-D layout (R reference pieces x N / R target slices) for the metrics that certify globally
+        R = int(rng.choice([r for r in range(1, N + 1) if N % r == 0])) if metric != 1 else N
+        if min(_sharded.shard_bounds(n, R, r)[1] - _sharded.shard_bounds(n, R, r)[0] for r in range(R)) < kk:
+            R = N
+        grp = _sharded.LoopbackGroup(N, 0, n, g, metric, Y, ref_mask=mask, ref_shards=R).set_ref()
         gi, gd = grp.query(X, k, drop_first=drop)
         grp.close()
         oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, drop_first=drop, nthreads=16)
@@ -83,7 +87,7 @@ for case in range(n_cases):
             bad = np.where((gi != oi).any(1) | ~((gd == od) | (np.isnan(gd) & np.isnan(od))).all(1))[0]
             r = int(bad[0])
             print("rows differing: %d of %d; first %d\n got idx  %s\n want idx %s\n got d  %s\n want d %s" % (len(bad), m, r, gi[r], oi[r], gd[r], od[r]))
-            fail("sharded case %d N=%d n=%d m=%d g=%d k=%d drop=%s metric=%d flavour=%d" % (case, N, n, m, g, k, drop, metric, fl))
+            fail("sharded case %d N=%d R=%d n=%d m=%d g=%d k=%d drop=%s metric=%d flavour=%d" % (case, N, R, n, m, g, k, drop, metric, fl))
     elif kind == "set_mask":
         n = int(rng.choice([100, 2000, 9000])); m = int(rng.choice([3, 70, 400])); g = int(rng.integers(1, 80))
         metric = int(rng.integers(0, 3)); k = int(rng.integers(1, 12))
