@@ -50,7 +50,7 @@ class ShardedKnn:
     merge(parts_idx [N,mr,kk], parts_dist, k, drop_first) -> (idx [mr,k], dist [mr,k]) torch tensors
     """
 
-    def __init__(self, dist_module, local_knn, merge, device, local_cand=None):
+    def __init__(self, dist_module, local_knn, merge, device, local_cand=None, ref_shards=None):
         self.dist = dist_module
         self.local_knn = local_knn
         self.merge = merge
@@ -62,14 +62,24 @@ class ShardedKnn:
         # rehearsal mode: device tensors but a CPU-only backend (gloo) -> stage collectives through host
         self.stage = (dist_module.is_initialized() and dist_module.get_backend() == "gloo"
                       and str(device).startswith("cuda"))
+        # 2-D layout (nabo_comm_set_ref_shards): R reference pieces x world / R target slices; rank r holds piece r % R
+        # (local_knn / local_cand answer for THAT piece) and exchanges inside the group of R ranks of its slice
+        self.R = self.world if ref_shards is None else int(ref_shards)
+        assert self.world % self.R == 0
+        self.group = None
+        if self.R != self.world:
+            for t in range(self.world // self.R):          # every rank creates every group, in the same order
+                grp = dist_module.new_group(list(range(t * self.R, (t + 1) * self.R)))
+                if t == self.rank // self.R:
+                    self.group = grp
 
     def _a2a(self, recv, send):
         if self.stage:
             r, s = recv.cpu(), send.cpu()
-            self.dist.all_to_all_single(r, s)
+            self.dist.all_to_all_single(r, s, group=self.group)
             recv.copy_(r)
         else:
-            self.dist.all_to_all_single(recv, send)
+            self.dist.all_to_all_single(recv, send, group=self.group)
 
     def _gather(self, full, part):
         if self.stage:
@@ -95,8 +105,9 @@ class ShardedKnn:
         N = self.world
         import os
         force = os.environ.get("NABO_DIST_FORCE_CERT") == "1"          # experiments: protocol overhead at N = 1
-        if self.local_cand is not None and (N > 1 or force) and -(-kk // N) <= 32:
+        if self.local_cand is not None and (N > 1 or force) and -(-kk // self.R) <= 32:
             return self._query_certified(X, m, k, drop_first)
+        assert self.R == N, "the 2-D layout needs the global-certification protocol"
         idx, dst = self.local_knn(X, kk)
         if N == 1:
             oi, od = self.merge(idx.view(1, m, kk), dst.view(1, m, kk), k, drop_first)
@@ -125,20 +136,22 @@ class ShardedKnn:
         import torch
         d0 = 1 if drop_first else 0
         kk = k + d0
-        N, dev = self.world, self.device
-        Ls = self.candidates_per_shard(kk, N, m)
-        ci, cd, cb = self.local_cand(X, Ls)
+        N, dev, R = self.world, self.device, self.R
+        Ls = self.candidates_per_shard(kk, R, m)
         mr = (m + N - 1) // N
         m_pad = mr * N
-        if m_pad != m:
-            pi = torch.full((m_pad, Ls), -1, dtype=torch.int64, device=dev)
-            pd = torch.full((m_pad, Ls), float("inf"), dtype=torch.float64, device=dev)
-            pb = torch.full((m_pad,), float("inf"), dtype=torch.float64, device=dev)
-            pi[:m], pd[:m], pb[:m] = ci, cd, cb
-            ci, cd, cb = pi, pd, pb
-        recv_i = torch.empty((N, mr, Ls), dtype=torch.int64, device=dev)
-        recv_d = torch.empty((N, mr, Ls), dtype=torch.float64, device=dev)
-        recv_b = torch.empty((N, mr), dtype=torch.float64, device=dev)
+        # my group's slice of the target rows: [s0, s0 + R mr), ms of them exist (R = N: the whole batch)
+        gfirst = (self.rank // R) * R
+        s0, ms_pad = gfirst * mr, R * mr
+        ms = max(0, min(m - s0, ms_pad))
+        ci = torch.full((ms_pad, Ls), -1, dtype=torch.int64, device=dev)
+        cd = torch.full((ms_pad, Ls), float("inf"), dtype=torch.float64, device=dev)
+        cb = torch.full((ms_pad,), float("inf"), dtype=torch.float64, device=dev)
+        if ms > 0:
+            ci[:ms], cd[:ms], cb[:ms] = self.local_cand(X[s0:s0 + ms], Ls)
+        recv_i = torch.empty((R, mr, Ls), dtype=torch.int64, device=dev)
+        recv_d = torch.empty((R, mr, Ls), dtype=torch.float64, device=dev)
+        recv_b = torch.empty((R, mr), dtype=torch.float64, device=dev)
         self._a2a(recv_i.view(-1), ci.contiguous().view(-1))
         self._a2a(recv_d.view(-1), cd.contiguous().view(-1))
         self._a2a(recv_b.view(-1), cb.contiguous().view(-1))
@@ -170,7 +183,8 @@ class ShardedKnn:
             self._gather(gd.view(-1), bd.contiguous().view(-1))
             mine = torch.nonzero((sel >= row0) & (sel < row0 + mr)).view(-1)
             if mine.numel() > 0:
-                fi, fd = self.merge(gi[:, mine, :].contiguous(), gd[:, mine, :].contiguous(), kk, False)
+                # every rank re-solved every refused row on ITS piece: the R parts of my group cover all pieces
+                fi, fd = self.merge(gi[gfirst:gfirst + R][:, mine, :].contiguous(), gd[gfirst:gfirst + R][:, mine, :].contiguous(), kk, False)
                 loc = sel[mine] - row0
                 mi[loc] = fi
                 md[loc] = fd

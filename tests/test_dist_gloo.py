@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir, certified=False, sorted_refs=False):
+def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir, certified=False, sorted_refs=False, ref_shards=None):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -35,7 +35,8 @@ def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir, certified=Fals
     X = pca_like(m, g, seed=12)
     if sorted_refs:                 # neighbours concentrate in one shard: forces the second (exact) round
         Y = Y[np.argsort(Y[:, 0])]
-    lo, hi = shard_bounds(n, world, rank)
+    R = world if ref_shards is None else ref_shards          # 2-D layout: rank r holds piece r % R of R
+    lo, hi = shard_bounds(n, R, rank % R)
 
     def local_cand(Xt, ncand):
         """What nabo_index_query_candidates returns, stated with the oracle: the shard's first ncand
@@ -59,20 +60,24 @@ def _worker(rank, world, port, m, n, g, k, drop, metric, out_dir, certified=Fals
         i, d = merge_numpy(pi.numpy(), pd.numpy(), kq, dropq)
         return torch.from_numpy(i), torch.from_numpy(d)
 
-    sk = ShardedKnn(dist, local_knn, merge, torch.device("cpu"), local_cand=local_cand if certified else None)
+    sk = ShardedKnn(dist, local_knn, merge, torch.device("cpu"), local_cand=local_cand if certified else None,
+                    ref_shards=ref_shards)
     oi, od = sk.query(torch.from_numpy(X), m, k, drop)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), idx=oi.numpy(), dist=od.numpy(), unc=sk.last_uncertified)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,m,n,drop,metric,certified,sorted_refs", [
-    (2, 101, 600, False, 0, False, False), (2, 64, 501, True, 0, False, False), (3, 50, 400, False, 1, False, False),
-    (2, 101, 600, True, 0, True, False),        # global certification, ragged m, positional drop
-    (3, 77, 900, False, 0, True, False),
-    (3, 60, 900, False, 0, True, True),         # one shard holds the neighbours -> second round
+@pytest.mark.parametrize("world,m,n,drop,metric,certified,sorted_refs,ref_shards", [
+    (2, 101, 600, False, 0, False, False, None), (2, 64, 501, True, 0, False, False, None),
+    (3, 50, 400, False, 1, False, False, None),
+    (2, 101, 600, True, 0, True, False, None),        # global certification, ragged m, positional drop
+    (3, 77, 900, False, 0, True, False, None),
+    (3, 60, 900, False, 0, True, True, None),         # one shard holds the neighbours -> second round
+    (4, 101, 900, True, 0, True, False, 2),           # 2-D layout: 2 reference pieces x 2 target slices, ragged, drop
+    (4, 61, 900, False, 0, True, True, 2),            # ... with the second round
 ])
-def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric, certified, sorted_refs):
+def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric, certified, sorted_refs, ref_shards):
     import torch.multiprocessing as mp
     import oracle
     from nabo_amd._synth import pca_like
@@ -80,7 +85,7 @@ def test_sharded_equals_unsharded(tmp_path, world, m, n, drop, metric, certified
     if certified:
         k = 15
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, m, n, g, k, drop, metric, str(tmp_path), certified, sorted_refs),
+    mp.spawn(_worker, args=(world, port, m, n, g, k, drop, metric, str(tmp_path), certified, sorted_refs, ref_shards),
              nprocs=world, join=True)
     Y = pca_like(n, g, seed=11)
     if sorted_refs:
