@@ -7,12 +7,21 @@
 A step = one full k-NN build of the workload: pack the (sharded) references, fused distance + top-k filter on the
 matrix pipe, float64 refine + certification, and for N>1 the RCCL exchange + merge (nabo_sharded_query).  Inputs
 (float64 PCA-like embeddings) are already resident in HBM when the timed region starts.
-Default workload: BASELINE.json configs[2], 1M ref x 1M target, d=50, k=15, Euclidean.
+Default workload: BASELINE.json configs[2], 1M ref x 1M target, d=50, k=15, Euclidean; with N>1 GPUs BASELINE configs[3]:
+the same workload with the reference rows sharded N ways + RCCL exchange ("strong" scaling: total work is fixed).
 
-For N>1 the driver launches this file under torch.distributed.run, one rank per GPU; only the launcher is torch: the
-ranks read RANK / LOCAL_RANK / WORLD_SIZE from the environment, rank 0 hands the RCCL unique id to the others through
-a file (single node), and every collective -- the data path's and the barrier / max-over-ranks of the timing -- goes
-through libnabo_knn.so's C ABI (nabo_comm_*).  Reference rows are sharded, total work is fixed ("strong" scaling).
+N>1 runs however the file is launched:
+  * under a launcher (python -m torch.distributed.run ... bench.py --gpus N: WORLD_SIZE / RANK / LOCAL_RANK in the
+    environment) every process is one rank on its own GPU; only the launcher is torch -- rank 0 hands the RCCL unique id
+    to the others through a file, every collective (the data path's and the barrier / max-over-ranks of the timing) goes
+    through libnabo_knn.so's C ABI (nabo_comm_*);
+  * plain `python bench.py --gpus N` (no launcher environment) drives the N devices from THIS process: one communicator
+    per GPU (nabo_comm_create_all = ncclCommInitAll) and one host thread per rank (nabo_amd.ShardedGroup).  Fewer than
+    N visible GPUs is an error (exit code 2), never a silent one-GPU run.
+The N>1 headline is the layout BASELINE configs[3] names -- references sharded N ways, one piece per rank; the
+2 x N/2 layout (two reference pieces x N/2 target slices) is measured in the same invocation as the
+`alt_layout` block and must give the same bits.  (NABO_BENCH_LOOPBACK=N rehearses all of it with N shard-ranks on ONE
+GPU through the loopback transport.)
 
 The default N=1 line also carries (outside the timed region): `canberra` -- the reference's default target<->reference
 metric (nabo/_mapping.py:122-124) on the same 1M x 1M workload, checked against the oracle on sampled rows;
@@ -41,8 +50,10 @@ PEAK_F16_MFMA_TFLOPS = 2516.6
 # vector ISSUE peak for the mod-Canberra counting pass, MEASURED on this part by tools/issue_lab.hip for the pass's own
 # instruction mix (v_sub_u32, v_sub_u32, v_bitop3_b32, v_bcnt_u32_b32 on independent chains, 8 waves per SIMD):
 # 0.263 wave-instructions per clock and SIMD = 646.9 G/s (v_sub / v_bitop3 alone issue at 0.43 per clock, v_bcnt and
-# the packed-f16 kinds at 0.24; the nominal "one per 4 clocks" would be 614.4) -- profiles/r2_issue_lab.txt
+# the packed-f16 kinds at 0.24) -- profiles/r2_issue_lab.txt.  The NOMINAL rate, one instruction per 4 clocks and SIMD
+# (1024 SIMD x 2.4 GHz / 4), is 614.4 G/s: both fractions are reported.
 PEAK_VALU_GINST = 646.9
+NOMINAL_VALU_GINST = 614.4
 
 
 def _time_knn(oracle, X, Y, k, metric, threads, budget_s):
@@ -98,16 +109,139 @@ def c1_end_to_end(gpu):
     return {"skipped": "no interpreter with h5py"}
 
 
-def pmc_record(kind, workload, so_digest):
+def pmc_record(kind, workload, digest):
     """HBM-side bytes / instruction counts of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/pmc.json, collected with tools/pmc_round.sh in runs of their own).  Only a record taken on THIS build of
-    the library (same .so digest) and workload is reported as a number; anything else is a pointer, never a value."""
+    (profiles/pmc.json, collected in runs of their own: tools/r3_pmc.sh).  A record is reported as a number only when it
+    was taken on THESE SOURCES of the kernel (a digest of the kernel's source files + compiler flags -- reproducible,
+    unlike the bytes of a .so) and on this workload; anything else is a pointer, never a value.  Either way the fields
+    are counters of an EARLIER run of the same code, not of this one: `measured_in_this_run` is false."""
     try:
         rec = json.load(open(os.path.join(REPO, "profiles", "pmc.json")))[kind][workload]
     except Exception:       # noqa: BLE001
         return None
-    return rec if rec.get("so_digest") == so_digest else {"stale": True, "source": rec.get("source"),
-                                                          "so_digest_of_record": rec.get("so_digest")}
+    if rec.get("src_digest") == digest:
+        return dict(rec, measured_in_this_run=False)
+    return {"stale": True, "source": rec.get("source"), "src_digest_of_record": rec.get("src_digest"),
+            "measured_in_this_run": False}
+
+
+class Layout:
+    """One way of running the step: `ranks` shard-ranks as R reference pieces x ranks/R target slices.
+    kind "single": one GPU, no communicator; "launcher": this process is one rank of `world` (one process per GPU);
+    "threads": this process drives `ranks` GPUs, one host thread per rank (ShardedGroup over RCCL);
+    "loopback": `ranks` shard-ranks on ONE GPU (rehearsal)."""
+
+    def __init__(self, a, kind, ranks, R, comm, rank, dev, X, Yfull, metric_id):
+        import nabo_amd
+        from nabo_amd import _knn, _lib, _sharded
+        self.a, self.kind, self.ranks, self.R, self.comm, self.rank, self.dev = a, kind, ranks, R, comm, rank, dev
+        self._lib, self._knn = _lib, _knn
+        m, n, d, k = a.m, a.n, a.d, a.k
+        self.group = self.index = self.sk = None
+        self.stats, self.xstats = [], []
+        if kind in ("threads", "loopback"):
+            devices = [dev] * ranks if kind == "loopback" else list(range(ranks))
+            self.group = _sharded.ShardedGroup(devices, n, d, metric_id, Yfull, ref_shards=R,
+                                               transport="loopback" if kind == "loopback" else "rccl")
+            uniq = sorted(set(devices))
+            self.dX = {dv: _knn.DeviceBuffer(X.nbytes, dv).upload(X) for dv in uniq}
+            self.dI = {dv: _knn.DeviceBuffer(m * k * 8, dv) for dv in uniq}
+            self.dD = {dv: _knn.DeviceBuffer(m * k * 8, dv) for dv in uniq}
+            self.devices = devices
+            self.n_shard = _sharded.shard_bounds(n, R, 0)[1]
+        else:
+            lo, hi = _sharded.shard_bounds(n, R if comm is not None else 1, rank % R if comm is not None else 0)
+            self.n_shard = hi - lo
+            self.dXb = _knn.DeviceBuffer(X.nbytes, dev).upload(X)
+            self.dY = _knn.DeviceBuffer((hi - lo) * d * 8, dev).upload(np.ascontiguousarray(Yfull[lo:hi]))
+            self.dIb, self.dDb = _knn.DeviceBuffer(m * k * 8, dev), _knn.DeviceBuffer(m * k * 8, dev)
+            self.index = nabo_amd.KnnIndex(hi - lo, d, metric=metric_id, dist_factor=0.25, ref_index_base=lo, device=dev)
+            if comm is not None:
+                comm.set_ref_shards(R)
+                force = os.environ.get("NABO_BENCH_FORCE_COMM") == "1"
+                self.sk = _sharded.ShardedIndex(comm, self.index, os.environ.get(
+                    "NABO_BENCH_PROTOCOL", "global" if force and a.metric != "canberra" else "auto"))
+
+    def step(self):
+        a = self.a
+        if self.group is not None:
+            g = self.group
+            g.set_ref()
+            g.query_device([self.dX[dv].ptr for dv in self.devices], a.m, a.k, False,
+                           [self.dI[dv].ptr for dv in self.devices], [self.dD[dv].ptr for dv in self.devices])
+            self.stats.append([ix.last_stats() for ix in g.indices])
+            self.xstats.append([g.last_stats(r) for r in range(self.ranks)])
+        elif self.sk is not None:
+            self.index.set_ref(y_device_ptr=self.dY.ptr)
+            self.sk.query_device(self.dXb.ptr, a.m, a.k, False, self.dIb.ptr, self.dDb.ptr)
+            self.stats.append([self.index.last_stats()])
+            self.xstats.append([self.sk.last_stats()])
+        else:
+            self.index.set_ref(y_device_ptr=self.dY.ptr)
+            self.index.query_device(self.dXb.ptr, a.m, a.k, False, self.dIb.ptr, self.dDb.ptr)
+            self.stats.append([self.index.last_stats()])
+
+    def sync(self):
+        L = self._lib.lib()
+        for dv in (sorted(set(self.devices)) if self.group is not None else [self.dev]):
+            self._lib.check(L.nabo_dev_synchronize(dv))
+        if self.comm is not None:
+            self.comm.barrier()                     # RCCL all-reduce on the communicator's stream + host wait
+            self._lib.check(L.nabo_dev_synchronize(self.dev))
+
+    def run(self):
+        """W untimed steps, then exactly K steps between barrier + device sync on both sides; MAX over ranks."""
+        for _ in range(self.a.warmup):
+            self.step()
+        self.stats, self.xstats = [], []
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(self.a.steps):
+            self.step()
+        self.sync()
+        dt = time.perf_counter() - t0
+        if self.comm is not None:
+            dt = self.comm.allreduce_max(dt)
+        return dt
+
+    def rank_stats(self):
+        """mean over the timed steps, per rank: this process' ranks, or (launcher) the MAX over all ranks through RCCL"""
+        keys_i = ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")
+        keys_x = ("ms_local", "ms_exchange", "ms_merge", "ms_second", "ms_gather", "ms_total")
+        per = []
+        for r in range(len(self.stats[0])):
+            e = {"rank": self.rank + r, "index": {kk: float(np.mean([s[r][kk] for s in self.stats])) for kk in keys_i}}
+            if self.xstats:
+                e["sharded"] = {kk: float(np.mean([s[r][kk] for s in self.xstats])) for kk in keys_x}
+            per.append(e)
+        mx = {}
+        for kk in keys_i:
+            mx[kk] = max(e["index"][kk] for e in per)
+        for kk in keys_x if self.xstats else ():
+            mx[kk if kk != "ms_total" else "ms_sharded_total"] = max(e["sharded"][kk] for e in per)
+        if self.comm is not None:              # every rank enters these collectives; rank 0 prints
+            mx = {kk: self.comm.allreduce_max(v) for kk, v in sorted(mx.items())}
+        return per, mx
+
+    def result(self):
+        a = self.a
+        if self.group is not None:
+            dv = self.devices[0]
+            return self.dI[dv].download((a.m, a.k), np.int64), self.dD[dv].download((a.m, a.k), np.float64)
+        return self.dIb.download((a.m, a.k), np.int64), self.dDb.download((a.m, a.k), np.float64)
+
+    def kernel(self):
+        return (self.group.indices[0] if self.group is not None else self.index).last_kernel()
+
+    def close(self):
+        if self.group is not None:
+            self.group.close()
+            for b in list(self.dX.values()) + list(self.dI.values()) + list(self.dD.values()):
+                b.free()
+        else:
+            self.index.close()
+            for b in (self.dXb, self.dY, self.dIb, self.dDb):
+                b.free()
 
 
 def main():
@@ -123,104 +257,75 @@ def main():
                     help="cosine is an extension (BASELINE configs[4]); canberra is the reference's target<->reference "
                          "metric; the headline workload is euclidean")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the canberra / alt / C1 blocks (profiling runs)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the canberra / alt / alt_layout / C1 blocks (profiling runs)")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # ---- how was this file launched?  (decided BEFORE anything touches a GPU) --------------------------------------
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        a.gpus = world
+    loop = int(os.environ.get("NABO_BENCH_LOOPBACK", "0"))     # rehearsal: N shard-ranks as threads on ONE GPU
+    force_comm = os.environ.get("NABO_BENCH_FORCE_COMM") == "1"      # rehearsal: the launcher code path with one rank
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world > 1:
+        if a.gpus not in (1, env_world):
+            print("bench.py: --gpus %d contradicts WORLD_SIZE=%d of the launcher" % (a.gpus, env_world), file=sys.stderr)
+            sys.exit(2)
+        kind, ranks = "launcher", env_world
+    elif loop > 1:
+        kind, ranks = "loopback", loop
+    elif a.gpus > 1:
+        kind, ranks = "threads", a.gpus
+    else:
+        kind, ranks = ("launcher" if force_comm else "single"), 1
     import nabo_amd
     from nabo_amd import _knn, _lib, _sharded
-    from nabo_amd._sharded import shard_bounds
     from nabo_amd._synth import pca_like
-    if nabo_amd.device_count() < 1:
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    have = nabo_amd.device_count()
+    if have < 1:
+        print("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    need = ranks if kind == "threads" else (local_rank + 1 if kind == "launcher" else 1)
+    if have < need:
+        print("bench.py: --gpus %d needs %d visible GPUs, this process sees %d -- refusing to run (and report) a smaller job"
+              % (a.gpus, need, have), file=sys.stderr)
+        sys.exit(2)
+    n_gpus = 1 if kind in ("single", "loopback") else ranks
 
     m, n, d, k = a.m, a.n, a.d, a.k
-    dev = local_rank if world > 1 else 0
-    loop = int(os.environ.get("NABO_BENCH_LOOPBACK", "0"))     # rehearsal: N shard-ranks as threads on ONE GPU
+    dev = local_rank if kind == "launcher" and env_world > 1 else 0
     metric_id = {"euclidean": nabo_amd.EUCLIDEAN, "cosine": nabo_amd.COSINE, "canberra": nabo_amd.MOD_CANBERRA}[a.metric]
     Yfull = pca_like(n, d, seed=1003)
     X = pca_like(m, d, seed=2003)
-    force_comm = os.environ.get("NABO_BENCH_FORCE_COMM") == "1"      # rehearsal: the N>1 code path with one rank
-    comm = _sharded.Comm.from_env(dev) if (world > 1 or force_comm) else None
-    # Layout of the N ranks: R reference pieces x N / R target slices.  Every row fills a candidate list on
-    # EVERY piece, so that part of a rank's work does not shrink with the piece; a 1M x 50 reference set (0.4 GB of 288)
-    # has no need to be cut eight ways.  Default: two pieces from four ranks on (the exchange / merge / certificate of the
-    # prescribed ref-sharded form inside each pair, the gather over all ranks); NABO_REF_SHARDS=<N> is the 1-D form.
-    # (Modified Canberra shards exchange certified lists: 1-D only.)
-    ranks = max(world, loop, 1)
-    R = int(os.environ.get("NABO_REF_SHARDS", "0"))
-    if R <= 0:
-        R = 2 if (ranks >= 4 and ranks % 2 == 0 and a.metric != "canberra") else ranks
+    comm = _sharded.Comm.from_env(dev) if kind == "launcher" else None
+    # Layout of the N ranks.  Headline: BASELINE configs[3] -- the references sharded N ways, one piece per
+    # rank.  alt_layout: R = 2 pieces x N / 2 target slices (every row fills a candidate list on EVERY piece, so that
+    # part of a rank's work does not shrink with the piece).  NABO_REF_SHARDS=<R> pins the headline's R (experiments).
+    R = int(os.environ.get("NABO_REF_SHARDS", "0")) or ranks
     if ranks % R:
         raise SystemExit("NABO_REF_SHARDS must divide the number of ranks")
-    if comm is not None and R != world:
-        comm.set_ref_shards(R)
-    lo, hi = shard_bounds(n, R if world > 1 else 1, rank % R if world > 1 else 0)
-    dX = _knn.DeviceBuffer(X.nbytes, dev).upload(X)
-    dY = _knn.DeviceBuffer((hi - lo) * d * 8, dev).upload(np.ascontiguousarray(Yfull[lo:hi]))
-    dI = _knn.DeviceBuffer(m * k * 8, dev)
-    dD = _knn.DeviceBuffer(m * k * 8, dev)
-    index = nabo_amd.KnnIndex(hi - lo, d, metric=metric_id, dist_factor=0.25, ref_index_base=lo, device=dev)
-    stats, xstats = [], []
+    lay = Layout(a, kind, ranks, R, comm, rank, dev, X, Yfull, metric_id)
+    dt = lay.run()
+    per_rank, rank_max = lay.rank_stats()
+    kern = lay.kernel()
+    ablate = bool(os.environ.get("NABO_DEBUG_ABLATE"))
+    head = {"fallback_rows": int(max(s["fallback_rows"] for st in lay.stats for s in st)),
+            "candidates": int(lay.xstats[-1][0]["candidates"]) if lay.xstats else None,
+            "second_round_rows": int(max(x[0]["uncertified"] for x in lay.xstats)) if lay.xstats else None}
 
-    if loop > 1:
-        group = _sharded.LoopbackGroup(loop, dev, n, d, metric_id, Yfull, ref_shards=R)
-
-        def step():
-            group.set_ref()
-            group.query_device(dX.ptr, m, k, False, dI.ptr, dD.ptr)
-            stats.append(group.indices[0].last_stats())
-            xstats.append(group.last_stats(0))
-    elif comm is not None:
-        sk = _sharded.ShardedIndex(comm, index, os.environ.get("NABO_BENCH_PROTOCOL", "global" if force_comm and a.metric != "canberra" else "auto"))
-
-        def step():
-            index.set_ref(y_device_ptr=dY.ptr)
-            sk.query_device(dX.ptr, m, k, False, dI.ptr, dD.ptr)
-            stats.append(index.last_stats())
-            xstats.append(sk.last_stats())
-    else:
-        def step():
-            index.set_ref(y_device_ptr=dY.ptr)
-            index.query_device(dX.ptr, m, k, False, dI.ptr, dD.ptr)
-            stats.append(index.last_stats())
-
-    def sync():
-        _lib.check(_lib.lib().nabo_dev_synchronize(dev))
-        if comm is not None:
-            comm.barrier()                     # RCCL all-reduce on the communicator's stream + host wait
-            _lib.check(_lib.lib().nabo_dev_synchronize(dev))
-
-    for _ in range(a.warmup):
-        step()
-    stats.clear()
-    xstats.clear()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    rank_max = {}
-    if comm is not None:
-        dt = comm.allreduce_max(dt)            # MAX over ranks
-        # the slowest rank's phases (every rank enters these collectives; rank 0 prints): a first N>1 record must
-        # show where the time went without a second run
-        for key, src in (("ms_topk", stats), ("ms_total", stats), ("ms_local", xstats), ("ms_exchange", xstats),
-                         ("ms_merge", xstats), ("ms_second", xstats), ("ms_gather", xstats)):
-            rank_max[key] = comm.allreduce_max(float(np.mean([x[key] for x in src])))
-
-    # light self-check outside the timed region: sorted rows, valid indices
+    # self-check outside the timed region: valid, sorted rows; a row sample against the oracle
     gi = gd = None
-    if not os.environ.get("NABO_DEBUG_ABLATE"):
-        gi = dI.download((m, k), np.int64)
-        gd = dD.download((m, k), np.float64)
+    sampled = None
+    if not ablate:
+        gi, gd = lay.result()
         assert gi.min() >= 0 and gi.max() < n and (np.diff(gd[:: max(1, m // 4096)], axis=1) >= 0).all()
-    if os.environ.get("NABO_BENCH_CHECK") == "1" and (comm is not None or loop > 1):
+        if rank == 0:
+            import oracle
+            rows = np.random.default_rng(12).choice(m, min(32, m), replace=False)
+            oi, od = oracle.knn(X[rows], Yfull, k, metric_id, 0.25, nthreads=max(1, min(os.cpu_count() or 1, 16)))
+            sampled = bool(np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od))
+    if os.environ.get("NABO_BENCH_CHECK") == "1" and kind != "single":
         # rehearsal check: the sharded result must equal one unsharded index on the same data
         ref_ix = nabo_amd.KnnIndex(n, d, metric=metric_id, dist_factor=0.25, device=dev).set_ref(Yfull)
         ri, rd = ref_ix.query(X, k)
@@ -229,13 +334,29 @@ def main():
         print("rank %d sharded == unsharded: %s" % (rank, same), flush=True)
         assert same
 
+    # the other layout of the same ranks, same invocation, same bits required (every rank takes part)
+    alt_layout = None
+    want_alt = (ranks >= 4 and ranks % 2 == 0 and R == ranks and a.metric != "canberra" and not a.no_extras and not ablate
+                and not os.environ.get("NABO_REF_SHARDS"))
+    if want_alt:
+        lay.close()
+        lay2 = Layout(a, kind, ranks, 2, comm, rank, dev, X, Yfull, metric_id)
+        dt2 = lay2.run()
+        per2, max2 = lay2.rank_stats()
+        ai, ad = lay2.result()
+        alt_layout = {"layout": {"ref_shards": 2, "target_slices": ranks // 2},
+                      "workload": "refs sharded 2-way x %d target slices" % (ranks // 2),
+                      "ms_per_step": dt2 / a.steps * 1e3, "value": m * n * a.steps / dt2,
+                      "same_bits_as_headline_layout": bool(np.array_equal(ai, gi) and np.array_equal(ad, gd)),
+                      "candidates_per_shard": int(lay2.xstats[-1][0]["candidates"]),
+                      "second_round_rows": int(max(x[0]["uncertified"] for x in lay2.xstats)),
+                      "max_over_ranks_ms": max2, "per_rank_ms": per2}
+        lay = lay2
+
     if rank == 0:
         shards, slices = R, ranks // R
-        so = _lib.so_digest()
-        kern = index.last_kernel() if loop <= 1 else group.indices[0].last_kernel()
         ms_step = dt / a.steps * 1e3
-        t_kernel = float(np.mean([s["ms_topk"] for s in stats])) * 1e-3       # HIP events on the kernel's own stream
-        n_shard = (hi - lo) if loop <= 1 else shard_bounds(n, R, 0)[1]
+        t_kernel = per_rank[0]["index"]["ms_topk"] * 1e-3           # HIP events on the kernel's own stream (rank 0's index)
         workload = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, shards)
         if slices > 1:
             workload += " x %d target slices" % slices
@@ -243,76 +364,85 @@ def main():
             "metric": "cell-pair distances/s (k-NN build, 1Mx1M d=50 k=15)" if (m, n, d, k) == (1000000, 1000000, 50, 15)
                       else "cell-pair distances/s (k-NN build)",
             "value": m * n * a.steps / dt, "unit": "cell-pair distances/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "knn_build_s": dt / a.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if "f32_32x32x2" in kern else ("f16" if "f16" in kern else "f64"), "data": "synthetic",
             "config": {"workload": workload, "parallelism": "ref-shard%d" % shards + ("-slice%d" % slices if slices > 1 else ""),
+                       "launch": {"single": "one process, one GPU", "launcher": "one process per GPU (launcher environment)",
+                                  "threads": "one process, one host thread + one RCCL communicator per GPU",
+                                  "loopback": "%d shard-ranks on ONE GPU, loopback transport (rehearsal)" % ranks}[kind],
                        "arithmetic": "low-precision score filter on the matrix pipe, float64 re-evaluation + certification: "
                                      "indices and distances equal the reference's float64 path"},
-            "phases_ms": {key: float(np.mean([s[key] for s in stats])) for key in
-                          ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
-            "fallback_rows": int(np.max([s["fallback_rows"] for s in stats])),
-            "so_digest": so,
+            "phases_ms": per_rank[0]["index"],
+            "fallback_rows": head["fallback_rows"],
+            "sampled_rows_equal_oracle": sampled,
+            "so_digest": _lib.so_digest(), "src_digest": _lib.src_digest(),
         }
         if a.metric != "canberra":
-            flops = 2.0 * (m / slices) * n_shard * d                          # algorithmic (this rank): the -2XY^T term
+            dig = _lib.src_digest(_lib.KERNEL_SOURCES["euclid"])
+            flops = 2.0 * (m / slices) * lay_n_shard(n, shards) * d                  # algorithmic (one rank): the -2XY^T term
             achieved = flops / t_kernel / 1e12
             f16 = "f16" in kern
             peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_F32_MFMA_TFLOPS
-            rec = pmc_record("traffic", workload, so)
+            rec = pmc_record("traffic", workload, dig)
             line["roofline"] = {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_dtype": "f16 dense MFMA" if f16 else "f32 MFMA",
                 "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS, "frac_of_f16_mfma_peak": achieved / PEAK_F16_MFMA_TFLOPS,
                 "traffic": (rec or {}).get("bytes_per_step"), "traffic_record": rec,
-                "algorithmic_bytes": 4.0 * d * (m + n_shard) + 12.0 * k * m,      # fp32 operands + (i32, f64) results
-                "kernel": kern, "kernel_ms": t_kernel * 1e3,
+                "algorithmic_bytes": 4.0 * d * (m / slices + lay_n_shard(n, shards)) + 12.0 * k * (m / slices),
+                "kernel": kern, "kernel_ms": t_kernel * 1e3, "kernel_src_digest": dig,
                 "matrix_pipe_busy": (rec or {}).get("matrix_pipe_busy"),
                 "clock_ghz_held": (rec or {}).get("clock_ghz_held")}
         else:
-            rec = pmc_record("canberra", workload, so)
-            line["roofline"] = canberra_roofline(rec, t_kernel, kern)
-        if xstats:
-            line["sharded"] = {"world": world, "loopback_ranks": loop if loop > 1 else None,
-                               "layout": {"ref_shards": shards, "target_slices": slices,
-                                          "note": "NABO_REF_SHARDS=%d is the 1-D form (one piece per rank)" % ranks},
-                               "exchange_ms": float(np.mean([x["ms_exchange"] for x in xstats])),
-                               "merge_ms": float(np.mean([x["ms_merge"] for x in xstats])),
-                               "gather_ms": float(np.mean([x["ms_gather"] for x in xstats])),
-                               "second_round_ms": float(np.mean([x["ms_second"] for x in xstats])),
-                               "local_query_ms": float(np.mean([x["ms_local"] for x in xstats])),
-                               "candidates_per_shard": int(xstats[-1]["candidates"]),
-                               "last_uncertified": int(max(x["uncertified"] for x in xstats)),
-                               "rank0_ms_topk": t_kernel * 1e3,
-                               "max_over_ranks_ms": rank_max or None}
-        extras = comm is None and loop <= 1 and not a.no_extras and not os.environ.get("NABO_DEBUG_ABLATE")
+            dig = _lib.src_digest(_lib.KERNEL_SOURCES["canberra"])
+            line["roofline"] = canberra_roofline(pmc_record("canberra", workload, dig), t_kernel, kern)
+        if kind != "single":
+            hx = [s for s in per_rank if "sharded" in s]
+            line["sharded"] = {"world": ranks if kind != "loopback" else 1, "rccl_world": ranks if kind in ("launcher", "threads") else None,
+                               "loopback_ranks": ranks if kind == "loopback" else None,
+                               "layout": {"ref_shards": shards, "target_slices": slices},
+                               "candidates_per_shard": head["candidates"], "second_round_rows": head["second_round_rows"],
+                               "max_over_ranks_ms": rank_max, "per_rank_ms": hx if kind != "launcher" else hx[:1]}
+        if alt_layout is not None:
+            line["alt_layout"] = alt_layout
+        extras = kind == "single" and not a.no_extras and not ablate
         if extras and a.metric == "euclidean" and not os.environ.get("NABO_L2_MODE"):
-            line["alt"] = alt_block(nabo_amd, _knn, index, kern, dev, n, m, d, k, dY, dX, gi, gd, sync)
+            line["alt"] = alt_block(nabo_amd, _knn, kern, dev, n, m, d, k, lay.dY, lay.dXb, gi, gd, lay.sync)
         if extras and a.metric == "euclidean" and (m, n) == (1000000, 1000000):
-            line["canberra"] = canberra_block(nabo_amd, _knn, dev, n, m, d, k, dY, dX, X, Yfull, so, sync)
-        if not a.no_cpu_baseline and comm is None and loop <= 1:
+            line["canberra"] = canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, lay.dY, lay.dXb, X, Yfull, lay.sync)
+        if not a.no_cpu_baseline and kind == "single":
             line["cpu_baseline"] = cpu_baseline(d, k, metric_id)
             if extras:
                 line["cpu_baseline"]["c1_end_to_end"] = c1_end_to_end(gpu=True)
         print(json.dumps(line), flush=True)
+    lay.close()
     if comm is not None:
         comm.barrier()
         comm.close()
 
 
+def lay_n_shard(n, shards):
+    from nabo_amd._sharded import shard_bounds
+    return shard_bounds(n, shards, 0)[1]
+
+
 def canberra_roofline(rec, t_kernel, kern):
     """The mod-Canberra filter is vector-ALU work (no contraction): the bound is the chip's vector ISSUE rate, and what
     is priced against it is the number of vector instructions the kernel ACTUALLY issued (SQ_INSTS_VALU of a
-    rocprofv3 --pmc pass on this build), so the fraction cannot exceed 1."""
+    rocprofv3 --pmc pass on this kernel's sources), so the fraction cannot exceed 1.  `frac` is against the issue peak
+    measured for the counting pass's own instruction mix, `frac_of_nominal_issue_peak` against one instruction per
+    4 clocks and SIMD."""
     insts = (rec or {}).get("valu_insts_per_step")
     ach = insts / t_kernel / 1e9 if insts else None
     return {"bound": "valu-issue", "achieved": ach, "peak": PEAK_VALU_GINST, "unit": "G wave-instructions/s",
-            "frac": ach / PEAK_VALU_GINST if ach else None, "valu_insts_per_step": insts, "pmc_record": rec,
-            "kernel": kern, "kernel_ms": t_kernel * 1e3}
+            "frac": ach / PEAK_VALU_GINST if ach else None,
+            "nominal_peak": NOMINAL_VALU_GINST, "frac_of_nominal_issue_peak": ach / NOMINAL_VALU_GINST if ach else None,
+            "valu_insts_per_step": insts, "pmc_record": rec, "kernel": kern, "kernel_ms": t_kernel * 1e3}
 
 
-def canberra_block(nabo_amd, _knn, dev, n, m, d, k, dY, dX, X, Yfull, so, sync):
+def canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, dY, dX, X, Yfull, sync):
     """The reference's default target<->reference metric on the same workload (outside the headline's timed region)."""
     import oracle
     ix = nabo_amd.KnnIndex(n, d, metric=nabo_amd.MOD_CANBERRA, dist_factor=0.25, device=dev)
@@ -335,14 +465,15 @@ def canberra_block(nabo_amd, _knn, dev, n, m, d, k, dY, dX, X, Yfull, so, sync):
     same = bool(np.array_equal(gi[rows], oi) and np.array_equal(gd[rows], od))
     best = min(ts[1:])
     workload = "%dk ref x %dk target, d=%d, k=%d, canberra, refs sharded 1-way" % (n // 1000, m // 1000, d, k)
+    dig = _lib.src_digest(_lib.KERNEL_SOURCES["canberra"])
     return {"workload": "1M ref x 1M target, d=50, k=15, modified Canberra (nabo/_mapping.py:29-45), dist_factor 0.25",
             "ms_per_step": best * 1e3, "value": m * n / best, "unit": "cell-pair distances/s",
             "phases_ms": {key: st[key] for key in ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
             "fallback_rows": st["fallback_rows"], "sampled_rows_equal_oracle": same,
-            "roofline": canberra_roofline(pmc_record("canberra", workload, so), st["ms_topk"] * 1e-3, kern)}
+            "roofline": canberra_roofline(pmc_record("canberra", workload, dig), st["ms_topk"] * 1e-3, kern)}
 
 
-def alt_block(nabo_amd, _knn, index, kern, dev, n, m, d, k, dY, dX, gi, gd, sync):
+def alt_block(nabo_amd, _knn, kern, dev, n, m, d, k, dY, dX, gi, gd, sync):
     """The same step with the OTHER Euclidean filter kernel (fp32 MFMA <-> f16x3 split); results must be the same bits."""
     other = "f32" if "f16" in kern else "f16x3"
     os.environ["NABO_L2_MODE"] = other

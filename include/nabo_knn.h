@@ -47,6 +47,8 @@ extern "C" {
 #define NABO_E_HIP        -3   /* a HIP runtime call failed                                   */
 #define NABO_E_NOMEM      -4   /* device or host allocation failed                            */
 #define NABO_E_UNSUPPORTED -5  /* size outside what an entry point can address (see each one)  */
+#define NABO_E_COMM       -6   /* a collective failed or timed out, or a peer rank reported an
+                                  error: see "failure semantics" at nabo_sharded_query          */
 
 /* Limits of the instantiated FILTER kernels -- not of the API: the reference accepts any k and use_comps
  * (nabo/_mapping.py:495-524), and so do nabo_knn / nabo_index_query.  Beyond these limits every row is answered
@@ -105,7 +107,7 @@ int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64
                      int32_t k, int32_t drop_first,
                      int64_t *out_idx, double *out_dist, int32_t out_on_device);
 
-/* Shard mode (reference rows sharded over GPUs with GLOBAL certification, nabo_amd/_dist.py): the first
+/* Shard mode (reference rows sharded over GPUs with GLOBAL certification, nabo_sharded_query below): the first
  * n_cand (<= 32) entries of the shard's order rows WITHOUT a local verdict -- out_idx [m,n_cand] (global
  * indices, -1 = absent), out_dist [m,n_cand] (exact float64, +inf = absent) -- and out_bound [m]: a lower
  * bound on the exact SQUARED distance of every reference of this shard that is not in the emitted list
@@ -139,9 +141,9 @@ int nabo_merge_topk(int32_t device, const int64_t *parts_idx, const double *part
 
 /* ---- reference rows sharded over the GPUs of one node ------------------------------------
  * The reference has no multi-device path; the call site served is Mapping.calc_dist (nabo/_mapping.py:441-444).
- * Rank r of N holds reference rows [base_r, base_r + n_r) in its own nabo_index (ref_index_base = base_r, at least
- * k + drop_first rows) and sees ALL m target rows; after the call every rank holds the full [m,k] result, which
- * equals the unsharded index bit for bit.  Transport: RCCL over xGMI (librccl.so is loaded on first use); no torch,
+ * Rank r of N holds reference rows [base_r, base_r + n_r) in its own nabo_index (ref_index_base = base_r; a shard
+ * with fewer than k + drop_first rows takes part with what it has) and sees ALL m target rows; after the call every
+ * rank holds the full [m,k] result, which equals the unsharded index bit for bit.  Transport: RCCL over xGMI (librccl.so is loaded on first use); no torch,
  * no MPI.  A communicator owns a HIP stream and is used by one host thread at a time.
  *
  *   one process per GPU:    rank 0 calls nabo_comm_unique_id, hands the NABO_COMM_ID_BYTES bytes to the other ranks by
@@ -161,6 +163,12 @@ int nabo_comm_create_loopback(nabo_comm **comms /* [n] */, const int32_t *device
 int nabo_comm_destroy(nabo_comm *c);
 int nabo_comm_rank(const nabo_comm *c);
 int nabo_comm_world(const nabo_comm *c);
+/* Give up on a communicator from ANY thread: every rank blocked in one of its collectives (and every later call on
+ * it) returns NABO_E_COMM -- ncclCommAbort for RCCL, the rendezvous' abort flag for the loopback transport.  The
+ * handle must still be destroyed.  nabo_comm_set_timeout: how long a rank waits for its peers inside a collective
+ * before it aborts the communicator itself (seconds; default 600, or NABO_COMM_TIMEOUT_S at creation). */
+int nabo_comm_abort(nabo_comm *c);
+int nabo_comm_set_timeout(nabo_comm *c, double seconds);
 /* Collective helpers for a host that has no other communication layer (bench.py's timing bracket):
  * barrier, and MAX over ranks of one non-negative host double (in place). */
 /* 2-D layout for the sharded query (optional; 0 or the world size = the 1-D form): the references are cut into
@@ -185,9 +193,17 @@ int32_t nabo_candidates_per_shard(int32_t kk, int32_t world, int64_t m);
  * re-solved exactly in a second, small round); 2 = local certification (every shard's certified first k' entries;
  * the only form for the modified Canberra metric).  The positional drop (nabo/_mapping.py:142) is applied after
  * the merge.  Returns after the communicator's stream has drained.
- * Ignored references (ref_mask): with more than one shard a row with fewer than k' unmasked references in the WHOLE
- * reference set ends in absent entries (-1 / NaN); the one-device path continues such a row with the ignored
- * references by index, as numpy.ma's NaN fill does (nabo/_mapping.py:135-146). */
+ * Absent entries: index -1 (the distance beside it is NaN in merged results and +inf in candidate lists -- test the
+ * index).  Ignored references (ref_mask): with more than one shard a row with fewer than k' unmasked references in
+ * the WHOLE reference set ends in absent entries; the one-device path continues such a row with the ignored
+ * references by index, as numpy.ma's NaN fill does (nabo/_mapping.py:135-146).
+ * Failure semantics (the reference is a single process, nabo/_mapping.py:48-148 -- nothing to match; the rule is
+ * that no rank waits for a peer that has given up): what a rank can get wrong ALONE -- its arguments (every rank must
+ * pass the same m, k, drop_first, protocol: checked), a buffer it cannot allocate, its local queries -- is agreed on
+ * by all ranks before anything is exchanged: then EVERY rank returns an error (the failing rank its own status and
+ * message, the others NABO_E_COMM) and the communicator stays usable.  An error inside a collective (RCCL failure, a
+ * peer that never arrives within the timeout, nabo_comm_abort) aborts the communicator: every rank returns
+ * NABO_E_COMM and so does every later call on it. */
 int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
                        int64_t *out_idx, double *out_dist, int32_t protocol);
 /* ms: [0] local query (this rank's shard), [1] exchange, [2] merge + certificate, [3] second round, [4] slice,

@@ -13,7 +13,7 @@ COSINE = 2          # extension: not in the reference (include/nabo_knn.h)
 MAX_COMPS = 128
 MAX_K = 56
 
-E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED = -1, -2, -3, -4, -5
+E_INVALID, E_NODEVICE, E_HIP, E_NOMEM, E_UNSUPPORTED, E_COMM = -1, -2, -3, -4, -5, -6
 
 _lib = None
 
@@ -25,7 +25,7 @@ SYMBOLS = [
     "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
     "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
-    "nabo_comm_rank", "nabo_comm_world", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
+    "nabo_comm_rank", "nabo_comm_world", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
     "nabo_sharded_query", "nabo_sharded_last_stats",
 ]
 
@@ -72,6 +72,8 @@ def lib():
     L.nabo_comm_rank.argtypes = [vp]
     L.nabo_comm_world.argtypes = [vp]
     L.nabo_comm_set_ref_shards.argtypes = [vp, i32]
+    L.nabo_comm_abort.argtypes = [vp]
+    L.nabo_comm_set_timeout.argtypes = [vp, dbl]
     L.nabo_comm_barrier.argtypes = [vp]
     L.nabo_comm_allreduce_max_f64.argtypes = [vp, C.POINTER(dbl)]
     L.nabo_candidates_per_shard.argtypes = [i32, i32, i64]
@@ -89,6 +91,33 @@ def so_digest():
     import hashlib
     with open(SO_PATH, "rb") as f:
         return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+# sources a kernel's counter record depends on (profiles/pmc.json): the kernel, what it includes, the operand packing,
+# the launch logic and the compiler flags
+KERNEL_SOURCES = {
+    "euclid": ["l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "api.hip", "_build.py"],
+    "canberra": ["canberra_f32.hip", "knn_common.h", "api.hip", "_build.py"],
+}
+
+
+def src_digest(names=None):
+    """sha256 (first 16 hex digits) over sources the library is built from -- by default all of nabo_amd/csrc/*.hip,
+    *.h, include/nabo_knn.h and nabo_amd/_build.py (the compiler flags); `names` restricts it (KERNEL_SOURCES).  Unlike
+    the bytes of the .so it is the same after a rebuild on another box: profiles/pmc.json keys its records by it."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(HERE, "csrc")
+    if names is None:
+        files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+        files += [os.path.join(HERE, "..", "include", "nabo_knn.h"), os.path.join(HERE, "_build.py")]
+    else:
+        files = [os.path.join(HERE if f.endswith(".py") else csrc, f) for f in sorted(names)]
+    for fn in files:
+        h.update(os.path.basename(fn).encode())
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def check(rc):

@@ -261,14 +261,19 @@ class Mapping:
     :param ref_pca_fn: HDF5 file with the reference PCA data (one dataset per cell)
     :param ref_pca_grp_name: Group inside ref_pca_fn holding the data
     :param overwrite: start from scratch, deleting everything saved in mapping_h5_fn
-    Extensions (keyword only, defaults = reference behaviour): device, devices, layout, target_metric.
+    Extensions (keyword only, defaults = reference behaviour): device, devices, layout, target_metric, store_k.
     `devices=[0, 1, ...]` shards the reference rows over several GPUs of this node (one host thread and one RCCL
-    communicator per GPU behind nabo_sharded_query, include/nabo_knn.h; results equal the one-GPU run bit for bit);
-    every shard must hold at least k+1 reference cells.
+    communicator per GPU behind nabo_sharded_query, include/nabo_knn.h; results equal the one-GPU run bit for bit as
+    long as at least k (+1 for the reference graph) reference cells are not ignored -- with fewer the one-GPU path
+    continues a row with the ignored cells, as numpy.ma does, and the sharded one raises a ValueError).
+    `store_k`: keep max(k, store_k) entries of every order row, so that `use_stored_distances=True` still works after
+    `set_parameters` RAISED k up to store_k -- the reference keeps full rows (nabo/_mapping.py:139-145) and therefore
+    serves any later k (:537-541, :596-607); the filter's candidate lists already hold more than k entries, so a
+    store_k of about 2k costs no kernel time.
     """
 
     def __init__(self, mapping_h5_fn, ref_name, ref_pca_fn, ref_pca_grp_name, overwrite=False, *,
-                 device=0, devices=None, layout="per_cell", target_metric=None, shard_transport="rccl"):
+                 device=0, devices=None, layout="per_cell", target_metric=None, shard_transport="rccl", store_k=None):
         self._h5Fn = mapping_h5_fn
         if ref_name.find("__") != -1:
             raise ValueError("ERROR: Underscores are not allowed in the value for `ref_name` parameter")
@@ -288,6 +293,9 @@ class Mapping:
         self._device = self._devices[0]
         self._shardTransport = shard_transport       # "rccl", or "loopback" (device-to-device copies; devices may repeat)
         self._layout = layout
+        if store_k is not None and int(store_k) < 1:
+            raise ValueError("ERROR: store_k must be a positive integer")
+        self._storeK = None if store_k is None else int(store_k)
         self._check_h5(self._refPcaFn, self._refPcaGrp)
         self.refCells = []
         self._nameStash = {}
@@ -368,9 +376,9 @@ class Mapping:
         modified Canberra distance (> 0); chunk_size: kept for API compatibility -- the GPU
         path streams tiles from HBM and does not need a host-side chunk size.
 
-        Storage note: calc_dist keeps the first k entries of every order row (and their distances), not the
-        reference's full rows (nabo/_mapping.py:102-103,145 -- 16 TB at 1M x 1M).  `use_stored_distances=True`
-        therefore works for the k the distances were computed with or a smaller one; after RAISING k call
+        Storage note: calc_dist keeps the first max(k, store_k) entries of every order row (and their distances), not
+        the reference's full rows (nabo/_mapping.py:102-103,145 -- 16 TB at 1M x 1M).  `use_stored_distances=True`
+        therefore works for any later k up to that length (`Mapping(..., store_k=...)`); beyond it call
         make_ref_graph() / map_target(..., overwrite=True) without use_stored_distances to recompute (calc_snn
         raises a ValueError that says so when the stored lists are too short)."""
         self._useComps = use_comps
@@ -437,13 +445,19 @@ class Mapping:
             mask = np.array([c in ign for c in self.refCells], dtype=np.uint8)
         drop = 1 if intra_ref else 0
         n_ref = ref.shape[0]
-        k_store = min(self._k if self._k is not None else 1, n_ref - drop)
+        k_store = min(max(self._k if self._k is not None else 1, self._storeK or 1), n_ref - drop)
         if k_store < 1:
             raise ValueError("ERROR: not enough reference cells")
         metric = EUCLIDEAN if intra_ref else self._targetMetric
         if len(self._devices) > 1:
             # reference rows sharded over the GPUs (nabo/_mapping.py:441-444 is the call site this replaces)
             from ._sharded import ShardedGroup
+            n_ign = int(mask.sum()) if mask is not None else 0
+            if n_ref - n_ign < k_store + drop:
+                # one GPU continues such rows with the ignored cells by index (numpy.ma's NaN fill, :135-146); shards
+                # cannot (an ignored cell of one shard would enter the merge as a neighbour): absent entries instead
+                raise ValueError("ERROR: only %d reference cells are not ignored, fewer than the %d neighbours to keep: "
+                                 "map on one device (devices=None) or ignore fewer cells" % (n_ref - n_ign, k_store + drop))
             grp = ShardedGroup(self._devices, n_ref, self._useComps, metric, ref, dist_factor=float(self._distFactor),
                                ref_mask=mask, transport=self._shardTransport)
             try:

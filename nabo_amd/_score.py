@@ -39,7 +39,7 @@ def _target_uid(h5, target):
 
 def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0, weighted=True, by_cluster=False,
                       sorted_names_only=False, top_n_only=None, all_nodes=True, score_multiplier=1000,
-                      ignore_nodes=None, include_nodes=None, remove_suffix=False, verbose=False):
+                      ignore_nodes=None, include_nodes=None, remove_suffix=False, verbose=False, clusters=None):
     """Mapping score of one mapped target, read straight from the mapping file: same parameters, defaults,
     return shapes and errors as nabo.Graph.get_mapping_score (nabo/_graph.py:555-697), which needs the whole
     networkx graph in memory; `mapping_h5_fn, ref_name` stand for the Graph object (what `load_from_h5`
@@ -54,13 +54,14 @@ def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0
         scores >= min_score, otherwise smaller scores are reset to 0 (:689-692);
       * `remove_suffix=True` returns a LIST of cell names in both the sorted and the dict form -- the
         reference iterates the dict there (:693-694), kept as is;
-      * `by_cluster` needs `Graph.make_clusters` / `import_clusters`, which are not on the mapping hot path
-        (out of scope): ValueError, as the reference raises when no clusters exist.
+      * `by_cluster=True` returns {cluster: [scores of its reference nodes]} (:655-671).  The Graph object keeps the
+        clusters as node attributes, set by `make_clusters` (out of scope: SURVEY.md section 2) or `import_clusters`;
+        here they arrive as `clusters` = the dict `import_clusters` takes ({reference node: cluster}, :334-356: values
+        become strings, reference nodes the dict does not name get 'NA').  Without `clusters` no node has one and
+        every score lands in 'NA' -- what the reference returns on a fresh Graph (its guard at :603 compares a set
+        with a string and never fires).
     """
     import h5py
-    if by_cluster:
-        raise ValueError('ERROR: Calculate clusters first using "make_clusters" or import clusters using '
-                         '"import_clusters"')
     with h5py.File(mapping_h5_fn, "r") as h5:
         if h5["name_stash/ref_name"][0].decode("UTF-8") != ref_name:
             raise KeyError("ERROR: The reference is not named %s in the mapping file" % ref_name)
@@ -104,6 +105,22 @@ def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0
     # raw scores (no min_score reset yet: the sorted forms filter on the raw value)
     sc = mapping_score_from_edges(len(ref_nodes), ridx, w, len(inc), min_weight, -np.inf, weighted, score_multiplier)
     score = dict(zip(ref_nodes, sc.tolist()))
+    if by_cluster:
+        cluster_dict = {} if clusters is None else {n: str(clusters[n]) if n in clusters else "NA" for n in ref_nodes}
+        cluster_values = {x: [] for x in set(cluster_dict.values())}
+        na_cluster_score = []
+        for node in score:
+            if node in cluster_dict:
+                cluster_values[cluster_dict[node]].append(score[node])
+            else:
+                na_cluster_score.append(score[node])
+        if len(na_cluster_score) > 0:
+            if "NA" not in cluster_values:
+                cluster_values["NA"] = []
+            else:
+                print("WARNING: 'NA' cluster already exists. Appending value to it")
+            cluster_values["NA"].extend(na_cluster_score)
+        return cluster_values
     if sorted_names_only:
         if top_n_only is not None:
             if top_n_only > len(score):

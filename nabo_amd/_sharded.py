@@ -34,6 +34,7 @@ def candidates_per_shard(kk, world, m=None):
 # ---- communicators and the sharded query through the C ABI ------------------------------------------------------
 import ctypes as C      # noqa: E402
 import os               # noqa: E402
+import queue            # noqa: E402
 import threading        # noqa: E402
 import time             # noqa: E402
 
@@ -45,27 +46,58 @@ ID_BYTES = 128
 PROTOCOLS = {"auto": 0, "global": 1, "local": 2}
 
 
-def exchange_unique_id(rank, world, make_id, path=None, timeout=300.0):
+def _launcher_start_time():
+    """Wall-clock time the launcher (this rank's parent process) was started at, or 0.0 when /proc does not say."""
+    try:
+        with open("/proc/%d/stat" % os.getppid()) as f:
+            ticks = float(f.read().rsplit(")", 1)[1].split()[19])          # field 22: starttime, in clock ticks since boot
+        with open("/proc/stat") as f:
+            btime = next(float(ln.split()[1]) for ln in f if ln.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:      # noqa: BLE001
+        return 0.0
+
+
+def id_file_path():
+    """Where the ranks of ONE launch on ONE node meet: a private directory (mode 0700, per user) and a name built from
+    what the launcher gives every rank identically -- MASTER_PORT, the launcher's pid and, under torchrun, the run id
+    and the restart count (a restarted worker group must not pick up the id of the group that died)."""
+    d = os.environ.get("NABO_ID_DIR") or os.path.join("/tmp", "nabo-%d" % os.getuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    tag = "%s_%d_%s_%s" % (os.environ.get("MASTER_PORT", "0"), os.getppid(),
+                           os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    return os.path.join(d, "rccl_%s.id" % "".join(ch if ch.isalnum() or ch in "_-" else "-" for ch in tag))
+
+
+def exchange_unique_id(rank, world, make_id, path=None, timeout=300.0, not_before=None):
     """One process per GPU on ONE node: rank 0 creates the RCCL unique id (`make_id()` -> 128 bytes) and publishes it
-    through a file (written under a temporary name, then renamed: readers never see a partial file); the other ranks
-    poll for it.  The name is built from what the launcher gives every rank identically -- MASTER_PORT and the parent
-    (launcher) pid -- and rank 0 removes it when the communicator is closed.  Any other channel works as well
-    (nabo_comm_create only needs the bytes)."""
+    through a file; the other ranks poll for it.  Rank 0 removes whatever is left under that name first, writes under
+    a temporary name (O_EXCL, mode 0600) and renames: readers never see a partial or foreign file.  A reader accepts
+    only a file written after `not_before` -- by default the start of the launcher process, which precedes every rank
+    of this launch and follows every earlier job that could have used the same name.  Rank 0 removes the file when
+    the communicator is closed.  Any other channel works as well (nabo_comm_create only needs the bytes)."""
     if path is None:
-        path = os.path.join(os.environ.get("NABO_ID_DIR", "/tmp"), "nabo_rccl_%s_%d.id"
-                            % (os.environ.get("MASTER_PORT", "0"), os.getppid()))
+        path = id_file_path()
     if rank == 0:
         blob = bytes(make_id())
         assert len(blob) == ID_BYTES
+        try:
+            os.remove(path)                                    # a leftover of a crashed job
+        except OSError:
+            pass
         tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
             f.write(blob)
         os.replace(tmp, path)
         return blob, path
+    if not_before is None:
+        not_before = _launcher_start_time()
     t0 = time.time()
     while True:
         try:
-            if time.time() - os.path.getmtime(path) < 600.0:          # not a leftover of an older job
+            st = os.stat(path)
+            if st.st_mtime >= not_before - 1.0 and st.st_uid == os.getuid():
                 with open(path, "rb") as f:
                     blob = f.read()
                 if len(blob) == ID_BYTES:
@@ -126,6 +158,16 @@ class Comm:
         self.ref_shards = int(ref_shards)
         return self
 
+    def set_timeout(self, seconds):
+        """How long this rank waits for its peers inside a collective before it aborts the communicator."""
+        _lib.check(_lib.lib().nabo_comm_set_timeout(self._h, float(seconds)))
+        return self
+
+    def abort(self):
+        """Give up on the communicator (any thread): ranks blocked in one of its collectives return an error."""
+        if self._h is not None and self._h.value:
+            _lib.lib().nabo_comm_abort(self._h)
+
     def barrier(self):
         _lib.check(_lib.lib().nabo_comm_barrier(self._h))
 
@@ -174,51 +216,93 @@ class ShardedIndex:
 class ShardedGroup:
     """One process, several ranks: rank i = (device[i], shard i of the references), each driven by its own host thread
     (the C calls release the GIL; the collectives inside nabo_sharded_query rendezvous the threads).
-    transport "rccl": one GPU per rank, ncclCommInitAll; "loopback": device-to-device copies, devices may repeat."""
+    transport "rccl": one GPU per rank, ncclCommInitAll; "loopback": device-to-device copies, devices may repeat.
+    A shard may hold fewer than k + drop_first reference cells (it takes part with absent entries)."""
 
     def __init__(self, devices, n_ref, g, metric, Y, dist_factor=0.25, ref_mask=None, transport="rccl", protocol="auto",
-                 ref_shards=None):
+                 ref_shards=None, timeout=None):
         """ref_shards (optional, divides the number of ranks): the 2-D layout of nabo_comm_set_ref_shards -- the
         references in ref_shards pieces (rank r holds piece r % ref_shards), the target rows in len(devices) / ref_shards
-        slices; None = one piece per rank."""
+        slices; None = one piece per rank.  timeout (seconds; default NABO_COMM_TIMEOUT_S or 600): how long a rank waits
+        for its peers inside a collective, and how long a call of this object waits for its rank threads, before the
+        group is torn down with an error instead of hanging."""
         from ._knn import KnnIndex
         self.devices = [int(d) for d in devices]
         N = len(self.devices)
         R = N if ref_shards is None else int(ref_shards)
         if R < 1 or N % R:
             raise ValueError("ref_shards must divide the number of ranks")
+        if transport != "loopback" and _lib.device_count() < len(set(self.devices)):
+            raise _lib.NaboError("%d ranks over RCCL need %d GPUs, %d visible" % (N, len(set(self.devices)), _lib.device_count()))
+        self.timeout = float(timeout if timeout is not None else os.environ.get("NABO_COMM_TIMEOUT_S") or 600.0)
         self.comms = Comm.loopback(self.devices) if transport == "loopback" else Comm.all_devices(self.devices)
         for c in self.comms:
             c.set_ref_shards(R)
+            c.set_timeout(self.timeout)
+        self.ref_shards = R
         self.indices, self._Y, self._mask = [], [], []
         for r in range(N):
             lo, hi = shard_bounds(n_ref, R, r % R)
+            if hi <= lo:
+                raise ValueError("ERROR: %d reference cells cannot be cut into %d pieces" % (n_ref, R))
             self.indices.append(KnnIndex(hi - lo, g, metric=metric, dist_factor=dist_factor, ref_index_base=lo,
                                          device=self.devices[r]))
-            self._Y.append(np.ascontiguousarray(Y[lo:hi], dtype=np.float64))
+            # the rank's reference rows live in HBM from here on (set_ref borrows them: a step of bench.py re-packs
+            # the shard, it does not re-upload it)
+            from ._knn import DeviceBuffer
+            ys = np.ascontiguousarray(Y[lo:hi], dtype=np.float64)
+            self._Y.append(DeviceBuffer(ys.nbytes, self.devices[r]).upload(ys))
             self._mask.append(None if ref_mask is None else np.ascontiguousarray(ref_mask[lo:hi], dtype=np.uint8))
         self.shards = [ShardedIndex(c, ix, protocol) for c, ix in zip(self.comms, self.indices)]
+        # one persistent host thread per rank (a step of bench.py must not pay for thread creation)
+        self._jobs = [queue.Queue() for _ in range(N)]
+        self._done = queue.Queue()
+        self._threads = [threading.Thread(target=self._worker, args=(r,), daemon=True) for r in range(N)]
+        for t in self._threads:
+            t.start()
 
-    def _each(self, fn):
-        errs = [None] * len(self.shards)
-
-        def run(r):
+    def _worker(self, r):
+        while True:
+            fn = self._jobs[r].get()
+            if fn is None:
+                return
             try:
                 fn(r)
+                self._done.put((r, None))
             except BaseException as e:      # noqa: BLE001
-                errs[r] = e
+                self._done.put((r, e))
 
-        th = [threading.Thread(target=run, args=(r,)) for r in range(len(self.shards))]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        for e in errs:
-            if e is not None:
-                raise e
+    def _each(self, fn):
+        """fn(r) on every rank's thread.  If a rank has not come back after `timeout` (+ the C side's own deadline for
+        a missing peer) every communicator is aborted, which releases the ranks blocked in a collective; the first
+        error is raised."""
+        N = len(self.shards)
+        for q in self._jobs:
+            q.put(fn)
+        errs, left = [None] * N, N
+        deadline = time.time() + self.timeout + 30.0
+        aborted = False
+        while left:
+            try:
+                r, e = self._done.get(timeout=max(0.05, deadline - time.time()))
+            except queue.Empty:
+                if aborted:
+                    raise _lib.NaboError("sharded group: %d rank thread(s) did not return after the communicators were aborted" % left)
+                for c in self.comms:
+                    c.abort()
+                aborted, deadline = True, time.time() + 60.0
+                continue
+            errs[r], left = e, left - 1
+        if aborted:
+            raise _lib.NaboError("sharded group: a rank did not return within %.0f s; the communicators were aborted (%s)"
+                                 % (self.timeout, next((str(e) for e in errs if e is not None), "no rank reported an error")))
+        # the rank that failed on its own carries the message that explains the others' NABO_E_COMM
+        own = [e for e in errs if e is not None and "a peer failed" not in str(e)]
+        for e in own + [e for e in errs if e is not None]:
+            raise e
 
     def set_ref(self):
-        self._each(lambda r: self.indices[r].set_ref(self._Y[r], ref_mask=self._mask[r]))
+        self._each(lambda r: self.indices[r].set_ref(y_device_ptr=self._Y[r].ptr, ref_mask=self._mask[r]))
         return self
 
     def query_device(self, x_ptrs, m, k, drop_first, out_idx_ptrs, out_dist_ptrs):
@@ -256,10 +340,23 @@ class ShardedGroup:
         return self.shards[r].last_stats()
 
     def close(self):
+        for q in getattr(self, "_jobs", []):
+            q.put(None)
+        for t in getattr(self, "_threads", []):
+            t.join(timeout=5.0)
+        self._jobs, self._threads = [], []
         for ix in self.indices:
             ix.close()
+        for y in self._Y:
+            y.free()
         for c in self.comms:
             c.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
 
 
 class LoopbackGroup(ShardedGroup):

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/nabo_knn.h"
+#include "knn_common.h"
 
 namespace nabo {
 // kernels (pack.hip, l2_topk.hip, refine.hip, canberra.hip)
@@ -247,6 +248,7 @@ int api_fail(int code, const char *fmt, ...)
 }
 int index_device(const nabo_index *ix) { return ix->device; }
 int index_g(const nabo_index *ix) { return ix->g; }
+int64_t index_n(const nabo_index *ix) { return ix->n; }
 int index_metric(const nabo_index *ix) { return ix->metric; }
 bool index_can_emit_candidates(const nabo_index *ix) { return ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0; }
 void index_set_shard_mode(nabo_index *ix, bool on) { ix->shard_mode = on; }
@@ -255,7 +257,7 @@ void index_set_shard_mode(nabo_index *ix, bool on) { ix->shard_mode = on; }
 // Entries of the masked-reference list a row may continue with when it has fewer than k' unmasked references
 // (numpy.ma's NaN fill sorts the ignored references last, by index: nabo/_mapping.py:135-146).  A SHARD must not do
 // that: its masked references would enter the global merge as if they were neighbours (found by the randomised
-// sweep: 40-reference shards, 60 % masked) -- there the tail is left absent (-1 / NaN), which the merge skips.
+// sweep: 40-reference shards, 60 % masked) -- there the tail is left absent (index -1), which the merge skips.
 static int tail_len(const nabo_index *ix) { return ix->shard_mode ? 0 : ix->n_masked_list; }
 
 // Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernels (K-concatenated f16 tiles).
@@ -753,7 +755,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                              ix->cand_tau2.as<float>(), st));
         }
         HIP_TRY(hipEventRecord(ix->ev[2], st));
-        if (env_int("NABO_DEBUG_ABLATE", 0) != 0) {     // kernel-timing experiments only: results are garbage
+        if (nabo::debug_ablate() != 0) {     // -DNABO_EXPERIMENTS builds only: kernel-timing runs, results are garbage
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             HIP_TRY(hipEventRecord(ix->ev[4], st));
             HIP_TRY(hipEventRecord(ix->ev[5], st));
@@ -927,7 +929,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 if ((rc = ix->cand_tau2.reserve((size_t)rows_tail * SL2 * sizeof(float) + 16))) return rc;
             }
             if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
-            const bool dbg_counts = (env_int("NABO_DEBUG_ABLATE", 0) & 4) != 0;
+            const bool dbg_counts = (nabo::debug_ablate() & 4) != 0;
             if (dbg_counts) HIP_TRY(hipMemsetAsync(ix->cand_tau.as<float>() + (size_t)rows_main * SL, 0, 8, st));
             HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
             unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();

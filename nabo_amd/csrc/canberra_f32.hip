@@ -510,10 +510,9 @@ static hipError_t cbf_launch_one(const float *xq, const void *xh, int64_t m, con
                                        (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)((m + T - 1) / T), S), block(64);
-    const char *dbg = getenv("NABO_DEBUG_ABLATE");          // timing experiments only (results are garbage)
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const float2 *>(xq),
                        reinterpret_cast<const uint2 *>(xh), m, ycf, reinterpret_cast<const uint32_t *>(ych), n, g, mask,
-                       n_chunks, cps, slack, plateau, cand_idx, cand_tau, dbg ? atoi(dbg) : 0);
+                       n_chunks, cps, slack, plateau, cand_idx, cand_tau, debug_ablate());
     return hipGetLastError();
 }
 

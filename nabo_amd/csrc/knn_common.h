@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace nabo {
 
@@ -9,6 +10,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WAVE = 64;
+
+// NABO_DEBUG_ABLATE (kernel-timing experiments whose RESULTS ARE GARBAGE: no-hit runs, L2-resident streams, counters)
+// exists only in builds made with -DNABO_EXPERIMENTS (tools/ab, tools/r*_call*.sh build such variants next to the
+// product through `python -m nabo_amd._build --out ...`); the shipped library never reads the variable.
+static inline int debug_ablate()
+{
+#ifdef NABO_EXPERIMENTS
+    static const int v = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    return v;
+#else
+    return 0;
+#endif
+}
 constexpr int TILE = 32;                 // cells per MFMA tile (32x32x2 f32)
 
 // ---------------------------------------------------------------------------------------

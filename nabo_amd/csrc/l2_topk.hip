@@ -246,7 +246,7 @@ template <int KSTEPS, int R, int EPL, int ROWN>
 static hipError_t launch_one(const float *Xpk, const float *Ypk, int tiles_per_split, int S, int gx, int64_t tile_off,
                              int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
-    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    const int dbg = debug_ablate();
     const size_t lds = (size_t)4 * ListCfg<EPL, ROWN, R, l2_nrec(R, EPL)>::BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2_topk_kernel<KSTEPS, R, EPL, ROWN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

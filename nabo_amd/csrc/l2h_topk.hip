@@ -192,7 +192,7 @@ static hipError_t hlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               int64_t pad_tile, hipStream_t st)
 {
-    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, R, L2H_NREC>::BYTES;
     static_assert(lds <= 163840, "LDS budget");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2h_topk_kernel<KC, R, EPL, ROWN>),

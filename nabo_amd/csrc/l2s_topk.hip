@@ -362,7 +362,7 @@ static hipError_t slaunch_sync(const unsigned char *Xpk, const unsigned char *Yp
                                int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                                hipStream_t st)
 {
-    static const int dbg = getenv("NABO_DEBUG_ABLATE") ? atoi(getenv("NABO_DEBUG_ABLATE")) : 0;
+    const int dbg = debug_ablate();
     constexpr int ROWN = l2s_row_entries(KC);
     constexpr size_t lds = (size_t)L2S_NBUF * KC * 1024 + (size_t)L2S_WAVES * ListCfg<1, ROWN, L2S_R, L2S_NREC>::BYTES + 64;
     static_assert(lds <= 163840, "LDS budget");

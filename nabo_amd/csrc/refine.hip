@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         emit_masked_tail(x, Y, g, MET, cb_f, masked_list, n_masked_list, nreal, k, drop, base, oi, od);
 }
 
-// Shard mode (reference rows sharded over GPUs, global certification -- nabo_amd/_dist.py): no local
+// Shard mode (reference rows sharded over GPUs, global certification -- sharded.hip): no local
 // verdict.  Emits the row's candidates in exact float64 order (first `kout`, absent = idx -1 / +inf) and
 // `bound`, a lower bound on the exact SQUARED distance of every reference of this shard that is NOT among
 // the emitted candidates: min over splits of (tau * scale + ||x~||^2 - E), and additionally the squared

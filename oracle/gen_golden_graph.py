@@ -7,7 +7,8 @@ same loader as oracle/gen_golden.py; needs no GPU):
 
     /opt/conda/bin/python3.9 oracle/gen_golden_graph.py
 
-Writes tests/golden/score_options.npz and tests/golden/dump_roundtrip.npz (data only, no reference source).
+Writes tests/golden/score_options.npz, tests/golden/score_by_cluster.npz and tests/golden/dump_roundtrip.npz (data
+only, no reference source).
 
 1. score_options: the reference's Mapping is run on the `mapping_small` inputs (400 refs, targets ME and IG),
    the reference's Graph loads the file and `get_mapping_score` is called with a spread of options; every call
@@ -133,6 +134,24 @@ def main():
                             calls=np.array(json.dumps(calls)), node_sets=np.array(json.dumps(sets)),
                             errors=np.array(json.dumps(errors)), ref_nodes=np.array(list(g.refNodes)))
         print("score_options.npz written (%d calls)" % len(calls))
+        # ---- 1b. by_cluster (nabo/_graph.py:602-606,655-671): a fresh Graph (no node has a cluster), then clusters
+        # imported through import_clusters (:334-356) for part of the reference nodes, unknown names included
+        rng = np.random.default_rng(78)
+        rnodes = list(g.refNodes)
+        cdict = {rnodes[i]: int(rng.integers(1, 6)) for i in sorted(rng.choice(len(rnodes), 300, replace=False))}
+        cdict["ghost_WT"] = 3
+        bc = []
+        with redirect_stdout(buf):
+            bc.append({"clusters": None, "kwargs": {}, "result": g.get_mapping_score("ME", by_cluster=True)})
+            g.import_clusters(cdict)
+            for kw in ({}, {"min_weight": 0.1, "weighted": False}, {"include_nodes": "INC_BIG", "score_multiplier": 1}):
+                real = {a: (sets[b] if isinstance(b, str) and b in sets else b) for a, b in kw.items()}
+                bc.append({"clusters": "CDICT", "kwargs": kw, "result": g.get_mapping_score("ME", by_cluster=True, **real)})
+        np.savez_compressed(os.path.join(OUT, "score_by_cluster.npz"), calls=np.array(json.dumps(bc)),
+                            cdict=np.array(json.dumps(cdict)), node_sets=np.array(json.dumps(sets)))
+        print("score_by_cluster.npz written (%d calls)" % len(bc))
+        if "--by-cluster-only" in sys.argv:
+            return
 
         # ---- 2. our writer, the reference's reader ---------------------------------------
         import nabo_amd

@@ -125,6 +125,21 @@ def main():
                 if type(ex).__name__ != e["raises"]:
                     errs.append((e, type(ex).__name__))
         out["score_errors_differ"] = errs
+        # by_cluster (nabo/_graph.py:655-671): {cluster: [scores of its reference nodes, in refNodes order]}
+        bc = np.load(os.path.join(GOLD, "score_by_cluster.npz"))
+        cdict = json.loads(str(bc["cdict"]))
+        bsets = json.loads(str(bc["node_sets"]))
+        bad = []
+        for i, call in enumerate(json.loads(str(bc["calls"]))):
+            kw = {a: (bsets[b] if isinstance(b, str) and b in bsets else b) for a, b in call["kwargs"].items()}
+            got = nabo_amd.get_mapping_score(fn, "WT", "ME", by_cluster=True, clusters=cdict if call["clusters"] else None, **kw)
+            want = call["result"]
+            ok = set(got) == set(want) and all(len(got[c]) == len(want[c]) and all(
+                abs(a - b) <= 1e-12 * max(1.0, abs(a)) for a, b in zip(want[c], got[c])) for c in want)
+            if not ok:
+                bad.append((i, call["kwargs"]))
+        out["by_cluster_calls_checked"] = len(json.loads(str(bc["calls"])))
+        out["by_cluster_calls_differ"] = bad
     print("RESULT " + json.dumps(out))
 
 

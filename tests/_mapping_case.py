@@ -167,6 +167,32 @@ def run_case(tag):
             m2.make_ref_graph(use_stored_distances=True)
         _, edges2, _ = read_graph_like_reference(map_fn, "WT", "reference")
         out["stored_distances_same_graph"] = edges2 == edges
+        # store_k: distances computed at a SMALLER k keep max(k, store_k) entries per row, so a later, larger k is served
+        # from the stored lists like the reference's full rows serve it (nabo/_mapping.py:537-541); without store_k
+        # the lists are too short and calc_snn says so
+        k_small = max(2, k - 3)
+        for layout in ("per_cell", "columnar"):
+            map7 = os.path.join(td, "mapping_storek_%s.h5" % layout)
+            with redirect_stdout(buf):
+                m7 = nabo_amd.Mapping(map7, "WT", ref_fn, "data", overwrite=True, store_k=k + 6, layout=layout)
+                m7.set_parameters(uc, k_small, f, chunk)
+                m7.make_ref_graph()
+                m7 = nabo_amd.Mapping(map7, "WT", ref_fn, "data", store_k=k + 6, layout=layout)      # a later session
+                m7.set_parameters(uc, k, f, chunk)
+                m7.make_ref_graph(use_stored_distances=True)
+            _, edges7, _ = read_graph_like_reference(map7, "WT", "reference")
+            out["store_k_serves_larger_k_%s" % layout] = edges7 == edges
+        map8 = os.path.join(td, "mapping_nostorek.h5")
+        with redirect_stdout(buf):
+            m8 = nabo_amd.Mapping(map8, "WT", ref_fn, "data", overwrite=True)
+            m8.set_parameters(uc, k_small, f, chunk)
+            m8.make_ref_graph()
+            m8.set_parameters(uc, k, f, chunk)
+        try:
+            m8.make_ref_graph(use_stored_distances=True)
+            out["no_store_k_raises"] = False
+        except ValueError:
+            out["no_store_k_raises"] = True
         # columnar layout gives the same graph
         map2 = os.path.join(td, "mapping_col.h5")
         with redirect_stdout(buf):

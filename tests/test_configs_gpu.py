@@ -1,9 +1,9 @@
 """BASELINE.json configs[3] and configs[4] at their full shapes on ONE MI355X.
 
 configs[3]: 1M ref x 1M target, d=50, k=15, references sharded 8 ways.  The driver measures the real 8-GPU run;
-here every shard's share runs through the C ABI on one GPU, one after the other (nabo_index_query_candidates per
-shard -> nabo_merge_topk -> the owner's certificate -> second round for what it refuses), and the result must equal
-the unsharded index on ALL rows bit for bit and the oracle on a row sample.
+here the product's own sharded entry point (nabo_sharded_query: candidate query, grouped exchange, merge, the owner's
+certificate, second round, gather) runs with 8 loopback ranks on the one GPU, in the 1-D form and in the 2 x 4 layout,
+and every rank's result must equal the unsharded index on ALL rows bit for bit and the oracle on a row sample.
 
 configs[4]: 5M ref x 5M target, d=100, k=50, cosine + 1000-permutation null (both EXTENSIONS: the reference has
 neither, parity is pinned by this build's own oracle only).  One rank's share at full size (625k references x
@@ -74,9 +74,32 @@ def _second_round(gpu_lib, X, Y, k, N, metric, bad, mi, md):
         b.free()
 
 
-@pytest.mark.parametrize("N", [8, 2])
-def test_baseline_configs3_1M_sharded_equals_unsharded(gpu_lib, N):
-    """BASELINE configs[3]: 1M x 1M, d=50, k=15, N reference shards (full size, all rows)."""
+def _loopback_all_ranks(N, R, X, Y, k, metric=0, drop=False):
+    """nabo_sharded_query itself (certify_kernel, adopt_kernel, the grouped exchange, the ragged-slice fill) with N
+    shard-ranks on this one GPU: every rank writes its own copy of the [m,k] result."""
+    from nabo_amd import _sharded
+    m = X.shape[0]
+    grp = _sharded.LoopbackGroup(N, 0, Y.shape[0], Y.shape[1], metric, Y, ref_shards=R).set_ref()
+    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
+    outs = [(_knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)) for _ in range(N)]
+    try:
+        grp.query_device(dx.ptr, m, k, drop, [a.ptr for a, _ in outs], [b.ptr for _, b in outs])
+        st = [grp.last_stats(r) for r in range(N)]
+        kern = grp.indices[0].last_stats()
+        res = [(a.download((m, k), np.int64), b.download((m, k), np.float64)) for a, b in outs]
+    finally:
+        grp.close()
+        dx.free()
+        for a, b in outs:
+            a.free(); b.free()
+    return res, st, kern
+
+
+@pytest.mark.parametrize("N,R", [(8, 8), (8, 2), (2, 2)])
+def test_baseline_configs3_1M_sharded_query_equals_unsharded(gpu_lib, N, R):
+    """BASELINE configs[3] at full size THROUGH THE PRODUCT'S ENTRY POINT: 1M x 1M, d=50, k=15, nabo_sharded_query with
+    N loopback ranks -- the 1-D form (one reference piece per rank: the layout BASELINE names) and the 2 x 4 layout.
+    Every rank's copy of every row equals the unsharded index, a row sample equals the oracle."""
     n = m = 1000000
     d, k = 50, 15
     Y = pca_like(n, d, seed=1003)
@@ -84,23 +107,22 @@ def test_baseline_configs3_1M_sharded_equals_unsharded(gpu_lib, N):
     ix = gpu_lib.KnnIndex(n, d, metric=0).set_ref(Y)
     ri, rd = ix.query(X, k)
     ix.close()
-    Ls = candidates_per_shard(k, N, m)
-    mi, md, ok, stats, _ = _protocol_one_gpu(gpu_lib, X, Y, k, N, 0, Ls)
-    bad = np.nonzero(~ok)[0]
-    assert bad.size < 100, "the list-length rule expects < 0.1 uncertified rows per batch, got %d" % bad.size
-    _second_round(gpu_lib, X, Y, k, N, 0, bad, mi, md)
-    assert np.array_equal(mi, ri) and np.array_equal(md, rd)                  # EVERY row, indices and distances
+    res, st, kern = _loopback_all_ranks(N, R, X, Y, k)
+    for gi, gd in res:
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd)              # EVERY row, indices and distances
     rows = np.random.default_rng(8).choice(m, 32, replace=False)
     oi, od = oracle.knn(X[rows], Y, k, 0, nthreads=8)
-    assert np.array_equal(mi[rows], oi) and np.array_equal(md[rows], od)
-    # the short-stream kernel variant (one row-block per wave, three waves per SIMD) is what a shard runs from N = 4 on
-    if N == 8:
-        assert all(s["list_len"] == 32 for s in stats)
+    assert np.array_equal(res[0][0][rows], oi) and np.array_equal(res[0][1][rows], od)
+    assert all(s["protocol"] == "global" for s in st)
+    assert st[0]["candidates"] == candidates_per_shard(k, R, m)
+    assert st[0]["uncertified"] < 100, "the list-length rule expects < 0.1 uncertified rows per batch"
+    assert len({s["uncertified"] for s in st}) == 1
 
 
 def test_baseline_configs3_sorted_references_take_the_second_round(gpu_lib):
     """References ordered along the first component: a target's neighbours sit in ONE shard, which then holds more
-    than Ls of the global top-k; the owner must refuse those rows and the second round must repair them."""
+    than Ls of the global top-k; the owners must refuse those rows (certify_kernel) and the second round must repair
+    them (adopt_kernel) -- 200k target rows through nabo_sharded_query, 8 ranks, every rank's copy compared."""
     n, m, d, k, N = 1000000, 200000, 50, 15, 8
     Y = pca_like(n, d, seed=1003)
     Y = np.ascontiguousarray(Y[np.argsort(Y[:, 0], kind="stable")])
@@ -108,13 +130,10 @@ def test_baseline_configs3_sorted_references_take_the_second_round(gpu_lib):
     ix = gpu_lib.KnnIndex(n, d, metric=0).set_ref(Y)
     ri, rd = ix.query(X, k)
     ix.close()
-    Ls = candidates_per_shard(k, N, 1000000)
-    mi, md, ok, _, _ = _protocol_one_gpu(gpu_lib, X, Y, k, N, 0, Ls)
-    bad = np.nonzero(~ok)[0]
-    assert bad.size > 100, "sorted references should defeat the exchangeable-shard list length (%d rows)" % bad.size
-    assert np.array_equal(mi[ok], ri[ok]) and np.array_equal(md[ok], rd[ok])    # what the owner accepts is final
-    _second_round(gpu_lib, X, Y, k, N, 0, bad, mi, md)
-    assert np.array_equal(mi, ri) and np.array_equal(md, rd)
+    res, st, _ = _loopback_all_ranks(N, N, X, Y, k)
+    assert st[0]["uncertified"] > 100, "sorted references should defeat the exchangeable-shard list length (%d rows)" % st[0]["uncertified"]
+    for gi, gd in res:
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
 
 
 def test_baseline_configs4_one_ranks_share_and_protocol_sample(gpu_lib):

@@ -11,6 +11,7 @@ import socket
 import subprocess
 import sys
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -48,6 +49,44 @@ def test_unique_id_reaches_every_rank_through_a_file(tmp_path):
     assert got == [want] * world
     with pytest.raises(_lib.NaboError):
         _sharded.exchange_unique_id(1, 2, None, path=str(tmp_path / "never"), timeout=0.05)
+
+
+def test_unique_id_left_by_an_older_job_is_not_accepted(tmp_path):
+    """A crashed job leaves its id file behind; a restart under the same launcher pid and port must not hand that id to
+    the non-zero ranks while rank 0 is still creating the new one: readers only take a file written
+    after the launcher started, rank 0 removes the leftover before it publishes, files are private to the user."""
+    path = str(tmp_path / "id")
+    stale, fresh = bytes([7]) * 128, bytes(range(128))
+    with open(path, "wb") as f:
+        f.write(stale)
+    old = time.time() - 3600.0
+    os.utime(path, (old, old))
+    with pytest.raises(_lib.NaboError):                      # a reader alone never accepts the leftover
+        _sharded.exchange_unique_id(1, 2, None, path=path, timeout=0.2, not_before=time.time() - 60.0)
+    got = {}
+
+    def reader():
+        got["blob"] = _sharded.exchange_unique_id(1, 2, None, path=path, timeout=20, not_before=time.time() - 60.0)[0]
+
+    t = threading.Thread(target=reader)
+    t.start()
+    time.sleep(0.1)
+    assert _sharded.exchange_unique_id(0, 2, lambda: fresh, path=path)[0] == fresh
+    t.join()
+    assert got["blob"] == fresh
+    assert (os.stat(path).st_mode & 0o077) == 0
+    # the default name carries the launcher's pid, the port, torchrun's run id and restart count, in a 0700 directory
+    os.environ["NABO_ID_DIR"] = str(tmp_path / "ids")
+    try:
+        a = _sharded.id_file_path()
+        os.environ["TORCHELASTIC_RESTART_COUNT"] = "1"
+        b = _sharded.id_file_path()
+    finally:
+        os.environ.pop("NABO_ID_DIR", None)
+        os.environ.pop("TORCHELASTIC_RESTART_COUNT", None)
+    assert a != b and str(os.getppid()) in a
+    assert (os.stat(str(tmp_path / "ids")).st_mode & 0o077) == 0
+    assert 0 < _sharded._launcher_start_time() <= time.time()
 
 
 def test_product_and_bench_never_import_torch():
@@ -125,6 +164,116 @@ def test_shards_with_fewer_unmasked_references_than_k_do_not_leak_ignored_ones(g
     oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, nthreads=8)
     assert np.array_equal(gi, oi) and np.array_equal(gd, od)
     assert not mask[gi].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("metric,protocol", [(0, "auto"), (0, "local"), (1, "auto"), (2, "global")])
+def test_a_shard_with_fewer_references_than_k_takes_part_with_absent_entries(gpu_lib, metric, protocol):
+    """58 references over 5 shards = 11, 12, 11, 12, 12 rows, k' = 12: nabo_index_query refuses k' > n_ref, so shards 0
+    and 2 used to fail alone while their peers waited in the exchange.  They now answer with what
+    they have; the forced second round (protocol "global" on references sorted along a component) takes the same path."""
+    n, m, g, k, N = 58, 300, 9, 11, 5
+    Y = pca_like(n, g, seed=58)
+    Y = np.ascontiguousarray(Y[np.argsort(Y[:, 0], kind="stable")])
+    X = Y[:m % n + 40].copy()
+    X = np.concatenate([X, pca_like(m - X.shape[0], g, seed=59)])
+    sizes = [hi - lo for lo, hi in (_sharded.shard_bounds(n, N, r) for r in range(N))]
+    assert min(sizes) < k + 1 <= max(sizes)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, metric, Y, protocol=protocol).set_ref()
+    gi, gd = grp.query(X, k, drop_first=True)
+    gi2, gd2 = grp.query(X[:7], k + 20)                       # k' beyond EVERY shard (but not beyond the reference set)
+    grp.close()
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, drop_first=True, nthreads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    oi, od = oracle.knn(X[:7], Y, k + 20, metric, 0.25, nthreads=8)
+    assert np.array_equal(gi2, oi) and np.array_equal(gd2, od)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", ["k", "m", "null", "protocol"])
+def test_a_rank_handed_a_bad_argument_fails_every_rank_and_the_group_stays_usable(gpu_lib, fault):
+    """Failure semantics (include/nabo_knn.h): what a rank gets wrong ALONE is agreed on before anything is
+    exchanged -- every rank returns an error within seconds, nobody waits in a collective for the rank that gave up,
+    and the communicators remain usable for the next (correct) call."""
+    from nabo_amd import _knn
+    N, m, n, g, k = 4, 900, 6000, 16, 9
+    Y, X = pca_like(n, g, seed=81), pca_like(m, g, seed=82)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, 0, Y, timeout=30.0).set_ref()
+    dx, di, dd = _knn.DeviceBuffer(X.nbytes).upload(X), _knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)
+    errs = [None] * N
+
+    def call(r):
+        kw = {"k": k, "m": m, "x": dx.ptr, "protocol": grp.shards[r].protocol}
+        if r == 2:
+            kw.update({"k": {"k": 0}, "m": {"m": m - 1}, "null": {"x": 0}, "protocol": {"protocol": 7}}[fault])
+        rc = _lib.lib().nabo_sharded_query(grp.comms[r]._h, grp.indices[r]._h, kw["x"], kw["m"], kw["k"], 0, di.ptr, dd.ptr,
+                                           kw["protocol"])
+        errs[r] = (rc, _lib.lib().nabo_last_error().decode())
+
+    t0 = time.time()
+    grp._each(call)
+    assert time.time() - t0 < 20.0
+    assert all(rc != 0 for rc, _ in errs), errs
+    if fault == "m":                                          # nobody's argument is wrong by itself: the mismatch is the error
+        assert all(rc == _lib.E_INVALID and "different arguments" in msg for rc, msg in errs), errs
+    else:
+        assert errs[2][0] == _lib.E_INVALID and all(rc == _lib.E_COMM and "peer failed" in msg for rc, msg in errs[:2] + errs[3:]), errs
+    gi, gd = grp.query(X, k)                                  # the same communicators, next call
+    grp.close()
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+
+
+@pytest.mark.gpu
+def test_a_missing_rank_times_out_into_an_error_on_every_rank(gpu_lib):
+    """One of four ranks never enters the collective: the other three give up after the communicator's timeout and
+    return NABO_E_COMM, the group is dead afterwards (every later call fails at once) -- no hang."""
+    from nabo_amd import _knn
+    N, m, n, g, k = 4, 500, 4000, 12, 7
+    Y, X = pca_like(n, g, seed=83), pca_like(m, g, seed=84)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, 0, Y, timeout=2.0).set_ref()
+    dx, di, dd = _knn.DeviceBuffer(X.nbytes).upload(X), _knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)
+    errs = [None] * N
+
+    def call(r):
+        if r == 1:
+            return                                            # this rank "died"
+        rc = _lib.lib().nabo_sharded_query(grp.comms[r]._h, grp.indices[r]._h, dx.ptr, m, k, 0, di.ptr, dd.ptr, 0)
+        errs[r] = (rc, _lib.lib().nabo_last_error().decode())
+
+    t0 = time.time()
+    grp._each(call)
+    assert time.time() - t0 < 15.0
+    assert all(errs[r][0] == _lib.E_COMM for r in (0, 2, 3)), errs
+    with pytest.raises(_lib.NaboError):
+        grp.query(X, k)
+    grp.close()
+
+
+@pytest.mark.gpu
+def test_abort_from_another_thread_releases_the_waiting_ranks(gpu_lib):
+    """nabo_comm_abort (what ShardedGroup._each calls when a rank thread does not come back): ranks blocked in a
+    collective return NABO_E_COMM at once."""
+    from nabo_amd import _knn
+    N, m, n, g, k = 3, 400, 3000, 10, 5
+    Y, X = pca_like(n, g, seed=85), pca_like(m, g, seed=86)
+    grp = _sharded.LoopbackGroup(N, 0, n, g, 0, Y, timeout=120.0).set_ref()
+    dx, di, dd = _knn.DeviceBuffer(X.nbytes).upload(X), _knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)
+    errs = [None] * N
+
+    def call(r):
+        if r == 0:
+            time.sleep(1.0)
+            grp.comms[0].abort()
+            return
+        rc = _lib.lib().nabo_sharded_query(grp.comms[r]._h, grp.indices[r]._h, dx.ptr, m, k, 0, di.ptr, dd.ptr, 0)
+        errs[r] = (rc, _lib.lib().nabo_last_error().decode())
+
+    t0 = time.time()
+    grp._each(call)
+    assert time.time() - t0 < 10.0
+    assert all(errs[r][0] == _lib.E_COMM for r in (1, 2)), errs
+    grp.close()
 
 
 @pytest.mark.gpu
@@ -223,6 +372,38 @@ def test_bench_sharded_code_path_with_loopback_ranks():
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "sharded == unsharded: True" in r.stdout and '"candidates_per_shard"' in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_asked_for_more_gpus_than_visible_exits_loudly():
+    """`python bench.py --gpus N` without a launcher drives N devices itself (nabo_comm_create_all, one thread per rank);
+    on a box with fewer GPUs it must refuse -- a line saying n_gpus: 1 for a --gpus 8 request is worse than no line."""
+    import nabo_amd
+    have = nabo_amd.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NABO_BENCH_LOOPBACK")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0", "--targets", "2000",
+           "--refs", "5000", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, timeout=600, cwd=REPO)
+    assert r.returncode == 2, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "n_gpus" not in r.stdout and "refusing" in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_prints_the_baseline_layout_as_headline_and_the_2d_layout_beside_it():
+    """N>1: the headline is BASELINE configs[3]'s layout (references sharded N ways); the 2 x N/2 layout runs in the same
+    invocation as `alt_layout` and must give the same bits.  Eight loopback ranks on the one GPU."""
+    import json
+    env = dict(os.environ, NABO_BENCH_LOOPBACK="8", NABO_BENCH_CHECK="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "1", "--targets", "30001",
+           "--refs", "60000", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "refs sharded 8-way" in line["config"]["workload"] and "slices" not in line["config"]["workload"]
+    assert line["sharded"]["layout"] == {"ref_shards": 8, "target_slices": 1} and len(line["sharded"]["per_rank_ms"]) == 8
+    assert line["alt_layout"]["layout"] == {"ref_shards": 2, "target_slices": 4}
+    assert line["alt_layout"]["same_bits_as_headline_layout"] is True and line["sampled_rows_equal_oracle"] is True
+    assert all("ms_exchange" in e["sharded"] and "ms_topk" in e["index"] for e in line["sharded"]["per_rank_ms"])
 
 
 @pytest.mark.gpu
