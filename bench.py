@@ -207,7 +207,7 @@ class Layout:
     def rank_stats(self):
         """mean over the timed steps, per rank: this process' ranks, or (launcher) the MAX over all ranks through RCCL"""
         keys_i = ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")
-        keys_x = ("ms_local", "ms_exchange", "ms_merge", "ms_second", "ms_gather", "ms_total")
+        keys_x = ("ms_local", "ms_topk_local", "ms_exchange", "ms_merge", "ms_second", "ms_gather", "ms_total")
         per = []
         for r in range(len(self.stats[0])):
             e = {"rank": self.rank + r, "index": {kk: float(np.mean([s[r][kk] for s in self.stats])) for kk in keys_i}}
@@ -356,7 +356,9 @@ def main():
     if rank == 0:
         shards, slices = R, ranks // R
         ms_step = dt / a.steps * 1e3
-        t_kernel = per_rank[0]["index"]["ms_topk"] * 1e-3           # HIP events on the kernel's own stream (rank 0's index)
+        # HIP events on the kernel's own stream (rank 0's index; for a shard the candidate query's kernel -- the index's
+        # own record may belong to a second-round query)
+        t_kernel = (per_rank[0]["sharded"]["ms_topk_local"] if "sharded" in per_rank[0] else per_rank[0]["index"]["ms_topk"]) * 1e-3
         workload = "%dk ref x %dk target, d=%d, k=%d, %s, refs sharded %d-way" % (n // 1000, m // 1000, d, k, a.metric, shards)
         if slices > 1:
             workload += " x %d target slices" % slices

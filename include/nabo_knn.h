@@ -207,7 +207,7 @@ int32_t nabo_candidates_per_shard(int32_t kk, int32_t world, int64_t m);
 int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m, int32_t k, int32_t drop_first,
                        int64_t *out_idx, double *out_dist, int32_t protocol);
 /* ms: [0] local query (this rank's shard), [1] exchange, [2] merge + certificate, [3] second round, [4] slice,
- * [5] final all-gather, [6] total on the communicator's stream.  counters: [0] rows re-solved in the second round
+ * [5] final all-gather, [6] total on the communicator's stream, [7] the distance + top-k kernel of [0].  counters: [0] rows re-solved in the second round
  * (all ranks), [1] candidates per shard (0 under local certification), [2] unused, [3] protocol used (1 / 2). */
 int nabo_sharded_last_stats(const nabo_comm *c, double ms[8], int64_t counters[4]);
 

@@ -209,7 +209,7 @@ class ShardedIndex:
         cn = (C.c_int64 * 4)()
         _lib.check(_lib.lib().nabo_sharded_last_stats(self.comm._h, ms, cn))
         return {"ms_local": ms[0], "ms_exchange": ms[1], "ms_merge": ms[2], "ms_second": ms[3], "ms_slice": ms[4],
-                "ms_gather": ms[5], "ms_total": ms[6], "uncertified": int(cn[0]), "candidates": int(cn[1]),
+                "ms_gather": ms[5], "ms_total": ms[6], "ms_topk_local": ms[7], "uncertified": int(cn[0]), "candidates": int(cn[1]),
                 "protocol": {1: "global", 2: "local"}.get(int(cn[3]), "?")}
 
 

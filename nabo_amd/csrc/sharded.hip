@@ -880,6 +880,11 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
         if (!rc) rc = local_topk(c, ix, X, m, kk, c->ci.as<int64_t>(), c->cd.as<double>());
     }
     (void)hipSetDevice(c->device);
+    if (!rc) {          // the dominant kernel of this rank's share (a second round would overwrite the index's own record)
+        double ims[5] = {0, 0, 0, 0, 0};
+        (void)nabo_index_last_stats(ix, ims, nullptr);
+        c->ms[7] = ims[1];
+    }
     if ((rc = agree(c, rc, "local query"))) return rc;
     HIP_TRY(hipEventRecord(c->ev[1], st));
 
@@ -1001,7 +1006,8 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
     }
     HIP_TRY(hipEventRecord(c->ev[6], st));
     if ((rc = stream_wait(c))) return rc;
-    // ms: [0] local query, [1] exchange, [2] merge + certificate, [3] second round, [4] slice, [5] gather, [6] total
+    // ms: [0] local query, [1] exchange, [2] merge + certificate, [3] second round, [4] slice, [5] gather, [6] total,
+    // [7] the distance + top-k kernel inside [0]
     for (int i = 0; i < 6; ++i) c->ms[i] = ev_ms(c, i, i + 1);
     c->ms[6] = ev_ms(c, 0, 6);
     return NABO_OK;

@@ -170,7 +170,7 @@ def run_case(tag):
         # store_k: distances computed at a SMALLER k keep max(k, store_k) entries per row, so a later, larger k is served
         # from the stored lists like the reference's full rows serve it (nabo/_mapping.py:537-541); without store_k
         # the lists are too short and calc_snn says so
-        k_small = max(2, k - 3)
+        k_small = k - 3 if k - 3 >= 3 else k          # (k = 2 divides by zero in the reference's weight, :194)
         for layout in ("per_cell", "columnar"):
             map7 = os.path.join(td, "mapping_storek_%s.h5" % layout)
             with redirect_stdout(buf):
