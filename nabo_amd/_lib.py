@@ -96,7 +96,7 @@ def so_digest():
 # sources a kernel's counter record depends on (profiles/pmc.json): the kernel, what it includes, the operand packing,
 # the launch logic and the compiler flags
 KERNEL_SOURCES = {
-    "euclid": ["l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "api.hip", "_build.py"],
+    "euclid": ["l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "order.hip", "api.hip", "_build.py"],
     "canberra": ["canberra_f32.hip", "knn_common.h", "api.hip", "_build.py"],
 }
 

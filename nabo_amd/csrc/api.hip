@@ -33,13 +33,21 @@ int l2h_pick_kc(int g);
 // f16x3 variant with K-concatenated operands and reference tiles shared per workgroup through an LDS ring (l2s_topk.hip)
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
-                            bool layout16, hipStream_t st);
+                            bool layout16, hipStream_t st, const uint32_t *perm = nullptr);
 hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
-                              int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st);
+                              int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st,
+                              const uint32_t *perm = nullptr);
 // the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st);
+                           int64_t pad_tile, hipStream_t st, const int32_t *wave_start = nullptr);
+// locality order of the streamed cells (order.hip)
+int loc_key_bits(int g);
+hipError_t loc_sort_temp_bytes(int64_t n, int nb, size_t *bytes);
+hipError_t loc_order_launch(const double *V, int64_t n, int g, const double *centre, uint32_t *keys_a, uint32_t *pos_a,
+                            uint32_t *keys_sorted, uint32_t *perm, void *temp, size_t temp_bytes, hipStream_t st);
+hipError_t wave_start_launch(const uint32_t *tkeys, int64_t m, int rows_per_wave, const uint32_t *rkeys, int64_t n,
+                             int64_t n_waves, int32_t *start, hipStream_t st);
 void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 hipError_t l2s_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st);
@@ -52,12 +60,13 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total, const uint32_t *masked_list,
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
                          unsigned int *fail_count, hipStream_t st, int metric = 0, double cb_f = 0.0,
-                         float cb_plateau = 0.0f, int lvalid = 0);
+                         float cb_plateau = 0.0f, int lvalid = 0, const uint32_t *rperm = nullptr,
+                         const uint32_t *tperm = nullptr);
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
                               int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0,
-                              int lvalid = 0);
+                              int lvalid = 0, const uint32_t *rperm = nullptr, const uint32_t *tperm = nullptr);
 hipError_t normalise_rows_launch(const double *X, int64_t m, int g, double *out, hipStream_t st);
 hipError_t exact_rows_launch(const double *X, const double *Y, int64_t n, int g, int metric, double f,
                              const uint8_t *mask, const uint32_t *rows, unsigned int nrows, int k, int drop,
@@ -214,6 +223,11 @@ struct nabo_index {
     double fscale = 1.0;           // power-of-two input scale of the fp32 path: max |y~| * fscale in (1/2, 1]
     int ksteps = 0;
     DevBuf centre, ypk, ycpk, normmax;
+    // locality order (order.hip; l2q kernel only): reference keys / permutation (resident), target keys / permutation and
+    // the waves' start tiles (per query), sort scratch
+    bool order = false;            // decided at creation (NABO_L2Q_ORDER=0 streams in caller order: same results)
+    bool ref_ordered = false;      // the packed f16 tiles are in key order
+    DevBuf rkeys, rperm, tkeys, tperm, wstart, okeys, opos, otemp;
     bool packed_f32 = false, packed_c16 = false;
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
     double ymax_sqrt = 0.0, ymax_sqrt_c = 0.0;
@@ -260,6 +274,20 @@ void index_set_shard_mode(nabo_index *ix, bool on) { ix->shard_mode = on; }
 // sweep: 40-reference shards, 60 % masked) -- there the tail is left absent (index -1), which the merge skips.
 static int tail_len(const nabo_index *ix) { return ix->shard_mode ? 0 : ix->n_masked_list; }
 
+// Locality order of `n` rows of V (order.hip): sorted keys and the permutation, on the index's stream.
+static int order_rows(nabo_index *ix, const double *V, int64_t n, DevBuf &keys, DevBuf &perm)
+{
+    int rc;
+    size_t tb = 0;
+    HIP_TRY(nabo::loc_sort_temp_bytes(n, nabo::loc_key_bits(ix->g), &tb));
+    if ((rc = ix->okeys.reserve((size_t)n * 4)) || (rc = ix->opos.reserve((size_t)n * 4)) || (rc = keys.reserve((size_t)n * 4)) ||
+        (rc = perm.reserve((size_t)n * 4)) || (rc = ix->otemp.reserve(tb + 16)))
+        return rc;
+    HIP_TRY(nabo::loc_order_launch(V, n, ix->g, ix->centre.as<double>(), ix->okeys.as<uint32_t>(), ix->opos.as<uint32_t>(),
+                                   keys.as<uint32_t>(), perm.as<uint32_t>(), ix->otemp.p, tb, ix->stream));
+    return NABO_OK;
+}
+
 // Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernels (K-concatenated f16 tiles).
 static int ensure_packed(nabo_index *ix, bool want_h)
 {
@@ -287,9 +315,15 @@ static int ensure_packed(nabo_index *ix, bool want_h)
         if ((rc = ix->ycpk.reserve((size_t)ix->ref_tiles_alloc * ix->kc * 1024 + 128))) return rc;
         // |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
         ix->hscale = scale = std::ldexp(1.0, e2 + 12);
+        ix->ref_ordered = false;
+        if (ix->order) {
+            if ((rc = order_rows(ix, ix->dYp, ix->n, ix->rkeys, ix->rperm))) return rc;
+            ix->ref_ordered = true;
+        }
         HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc,
                                        ix->ref_tiles_alloc, ix->dmask, ix->ycpk.as<unsigned char>(),
-                                       ix->normmax.as<unsigned int>(), ix->q16, st));
+                                       ix->normmax.as<unsigned int>(), ix->q16, st,
+                                       ix->ref_ordered ? ix->rperm.as<uint32_t>() : nullptr));
     } else {
         const int Q = (ix->ksteps + 3) / 4;
         const size_t tile_bytes = ((size_t)Q * 256 + 32) * sizeof(float);
@@ -388,6 +422,7 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
             // default: the 16x16x32 MFMA shape (l2q_topk.hip; the chip holds a higher clock on it); =f16x3h pins the
             // 32x32x16 per-wave kernel, =f16x3s the shared-tile one (both use the 32x32 operand layout)
             ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0));
+            ix->order = ix->q16 && env_int("NABO_L2Q_ORDER", 1) != 0;
         }
     }
     int cus = 0;
@@ -410,7 +445,8 @@ int nabo_index_destroy(nabo_index *ix)
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->ycpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d, &ix->fails2,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
-                      &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound};
+                      &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound, &ix->rkeys, &ix->rperm, &ix->tkeys, &ix->tperm, &ix->wstart, &ix->okeys,
+                      &ix->opos, &ix->otemp};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
         if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
@@ -708,9 +744,24 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if ((rc = ix->fails.reserve((size_t)m * sizeof(uint32_t)))) return rc;
         if ((rc = ix->failcnt.reserve(sizeof(unsigned int)))) return rc;
         HIP_TRY(hipMemsetAsync(ix->failcnt.p, 0, sizeof(unsigned int), st));
+        // locality order (order.hip): the l2q kernel streams key-ordered references; the targets are packed in key order
+        // too and every wave starts its stream at its rows' neighbourhood
+        const bool ordered = use_h && !use_c && ix->q16 && ix->ref_ordered;
+        const uint32_t *rperm = nullptr, *tperm = nullptr;
+        const int32_t *wstart = nullptr;
+        if (ordered) {
+            if ((rc = order_rows(ix, dXp, m, ix->tkeys, ix->tperm))) return rc;
+            const int64_t n_waves = rows_pad / 128;
+            if ((rc = ix->wstart.reserve((size_t)n_waves * 4))) return rc;
+            HIP_TRY(nabo::wave_start_launch(ix->tkeys.as<uint32_t>(), m, 128, ix->rkeys.as<uint32_t>(), ix->n, n_waves,
+                                            ix->wstart.as<int32_t>(), st));
+            rperm = ix->rperm.as<uint32_t>();
+            tperm = ix->tperm.as<uint32_t>();
+            wstart = ix->wstart.as<int32_t>();
+        }
         if (use_h)
             HIP_TRY(nabo::pack_cquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->kc, rows_pad / 32,
-                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), ix->q16, st));
+                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), ix->q16, st, tperm));
         else
             HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->fscale, ix->ksteps, rows_pad / 32,
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
@@ -728,12 +779,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if (gx_main > 0)
                 HIP_TRY(nabo::l2q_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
                                               (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
-                                              ix->cand_tau.as<float>(), ix->ref_tiles_alloc - 1, st));
+                                              ix->cand_tau.as<float>(), ix->ref_tiles_alloc - 1, st, wstart));
             if (gx_tail > 0)
                 HIP_TRY(nabo::l2q_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
                                               (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
-                                              ix->ref_tiles_alloc - 1, st));
+                                              ix->ref_tiles_alloc - 1, st, wstart));
         } else if (use_h) {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
@@ -776,12 +827,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (cand_mode) {
             HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(),
                                              S, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
-                                             n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0, lkeep));
+                                             n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0, lkeep, rperm, tperm));
             if (gx_tail > 0)
                 HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                                  ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                                  ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st,
-                                                 cosine ? 2 : 0, lkeep));
+                                                 cosine ? 2 : 0, lkeep, rperm, tperm));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
             HIP_TRY(hipEventRecord(ix->ev[4], st));
             HIP_TRY(hipEventRecord(ix->ev[5], st));
@@ -803,13 +854,13 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f,
-                                    lkeep));
+                                    lkeep, rperm, tperm));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
-                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep));
+                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep, rperm, tperm));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

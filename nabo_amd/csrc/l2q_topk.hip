@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
                                                           uint32_t *__restrict__ cand_idx,
                                                           float *__restrict__ cand_key,
-                                                          float *__restrict__ cand_tau, int64_t pad_tile, int dbg)
+                                                          float *__restrict__ cand_tau, int64_t pad_tile, int dbg,
+                                                          const int32_t *__restrict__ wave_start)
 {
     constexpr int KS = KC / 2;                         // steps of 32 slots
     constexpr int NB = 8;                              // row-blocks of 16 targets per wave
@@ -195,9 +196,22 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
+    // Locality order (order.hip): the wave streams its split CYCLICALLY from the tile that holds its rows' neighbourhood
+    // (wave_start, per 128 target rows; a start outside this split's range means "from the split's first tile").  Step t
+    // of the loops below is tile tmap(t).
+    int off = 0;
+    if (wave_start) {
+        off = __builtin_amdgcn_readfirstlane(wave_start[ttile0 / (NB / 2)]) - t_begin;
+        if (off < 0 || off >= tiles_per_split) off = 0;
+    }
+    auto tmap = [&](int t) {
+        const int tw = t + off;
+        return tw >= t_end ? tw - tiles_per_split : tw;
+    };
     // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop always runs two steps
-    auto tile_ptr = [&](int t) {
-        const int64_t tc = t < t_end ? (int64_t)t : pad_tile;
+    auto tile_ptr = [&](int ts) {
+        const int t = tmap(ts);
+        const int64_t tc = ts < t_end ? (int64_t)t : pad_tile;
         // dbg & 2 / dbg & 4 (timing experiments, garbage results): the stream wraps inside a window of 128 tiles (stays in
         // the XCD's L2) / of 2 tiles (stays in the CU's vector L1)
         return Ypk + ((dbg & 2) ? (int64_t)(t_begin + ((t - t_begin) & 127)) : (dbg & 4) ? (int64_t)(t_begin + ((t - t_begin) & 1)) : tc) * TB;
@@ -227,22 +241,22 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
         {
             const qverdict v = qfilter_eval<NB>(accP, 2 * (NP - 1), tauv);
             accA = NABO_Q3(0);
-            qfilter_stage<C, EPL, NB, NREC>(accP, v, 2 * (NP - 1), (uint32_t)((t - 1) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
+            qfilter_stage<C, EPL, NB, NREC>(accP, v, 2 * (NP - 1), (uint32_t)(tmap(t - 1) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
         }
         {
             const qverdict v = qfilter_eval<NB>(accA, 0, tauv);
             accP = NABO_Q3(1);
-            qfilter_stage<C, EPL, NB, NREC>(accA, v, 0, (uint32_t)(t * 32 + 4 * lq), wl, scnt, lkeep, tauv);
+            qfilter_stage<C, EPL, NB, NREC>(accA, v, 0, (uint32_t)(tmap(t) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
         }
         {
             const qverdict v = qfilter_eval<NB>(accP, 2, tauv);
             accA = NABO_Q3(2);
-            qfilter_stage<C, EPL, NB, NREC>(accP, v, 2, (uint32_t)(t * 32 + 4 * lq), wl, scnt, lkeep, tauv);
+            qfilter_stage<C, EPL, NB, NREC>(accP, v, 2, (uint32_t)(tmap(t) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
         }
         {
             const qverdict v = qfilter_eval<NB>(accA, 4, tauv);
             accP = NABO_Q3(3);
-            qfilter_stage<C, EPL, NB, NREC>(accA, v, 4, (uint32_t)(t * 32 + 4 * lq), wl, scnt, lkeep, tauv);
+            qfilter_stage<C, EPL, NB, NREC>(accA, v, 4, (uint32_t)(tmap(t) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
         }
 #undef NABO_Q3
     };
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
         tile_step(a1, a0, t + 1);
         tile_step(a2, a1, t + 2);
     }
-    qfilter<C, EPL, NB, NREC>(accP, NB - 2, (uint32_t)((t - 1) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
+    qfilter<C, EPL, NB, NREC>(accP, NB - 2, (uint32_t)(tmap(t - 1) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
 #else
     f16x8 a0[2][KS], a1[2][KS];
     {
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int prev = (p + NP - 1) % NP;
-            const uint32_t jbp = (uint32_t)((p == 0 ? t - 1 : t) * 32 + 4 * lq);
+            const uint32_t jbp = (uint32_t)(tmap(p == 0 ? t - 1 : t) * 32 + 4 * lq);     // (a padding step stages nothing)
             if (p & 1) {
 #ifndef NABO_L2H_NOFILTER
                 const qverdict v = qfilter_eval<NB>(accA, 2 * prev, tauv);
@@ -320,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
     }
     {
         const int tl = t_begin + ((tiles_per_split + 1) & ~1) - 1;          // the last step run (t_end - 1 or the padding step)
-        qfilter<C, EPL, NB, NREC>(accP, NB - 2, (uint32_t)(tl * 32 + 4 * lq), wl, scnt, lkeep, tauv);
+        qfilter<C, EPL, NB, NREC>(accP, NB - 2, (uint32_t)(tmap(tl) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
     }
 
 #endif
@@ -331,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
 template <int KC, int EPL, int ROWN>
 static hipError_t qlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              int64_t pad_tile, hipStream_t st)
+                              int64_t pad_tile, hipStream_t st, const int32_t *wave_start)
 {
     const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, 8, L2Q_NREC, 16>::BYTES;
@@ -341,7 +355,7 @@ static hipError_t qlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(256);
     hipLaunchKernelGGL((l2q_topk_kernel<KC, EPL, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off,
-                       lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg);
+                       lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg, wave_start);
 #ifdef NABO_LISTS_PROF
     {
         unsigned long long h[8];
@@ -368,9 +382,9 @@ void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st)
+                           int64_t pad_tile, hipStream_t st, const int32_t *wave_start)
 {
-#define NABO_Q(KCV) case KCV: return qlaunch_one<KCV, 1, L2Q_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
+#define NABO_Q(KCV) case KCV: return qlaunch_one<KCV, 1, L2Q_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, wave_start);
     switch (kc) {
         NABO_Q(2) NABO_Q(4) NABO_Q(6) NABO_Q(8) NABO_Q(10) NABO_Q(12)
     default: return hipErrorInvalidValue;

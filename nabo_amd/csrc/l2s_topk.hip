@@ -267,7 +267,8 @@ __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restric
                                                          const double *__restrict__ centre, double scale, int kc,
                                                          int64_t ntiles_total, const uint8_t *__restrict__ mask,
                                                          unsigned char *__restrict__ out, double *__restrict__ norm64,
-                                                         unsigned int *__restrict__ norm_max_bits)
+                                                         unsigned int *__restrict__ norm_max_bits,
+                                                         const uint32_t *__restrict__ perm)
 {
     const int64_t tile = blockIdx.x;
     if (tile >= ntiles_total) return;
@@ -281,11 +282,13 @@ __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restric
         const int c = L16 ? 16 * hc + (lane & 15) : lane & 31;
         const int64_t cell = tile * 32 + c;
         const bool live = cell < ncell;
+        // locality order (order.hip): packed position `cell` holds caller row perm[cell]; norm64 is indexed by POSITION
+        const int64_t src = (live && perm) ? (int64_t)perm[cell] : cell;
         // whole-row pass: range check and ||rep||^2 (every lane of a cell computes the same)
         bool bad = false;
         double ss = 0.0;
         for (int e = 0; e < g && live; ++e) {
-            const float f = (float)((V[cell * g + e] - centre[e]) * scale);
+            const float f = (float)((V[src * g + e] - centre[e]) * scale);
             bad = bad || !(fabsf(f) <= 30000.0f);                 // f16 range (targets carry a factor 2); NaN / inf input
             const _Float16 h = (_Float16)f;
             const _Float16 l = (_Float16)(f - (float)h);
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restric
         float nh = 0.0f, nl = 0.0f;
         if (IS_REF) {
             float nf = __builtin_inff();
-            if (live && !bad && !(mask && mask[cell])) {
+            if (live && !bad && !(mask && mask[src])) {
                 nf = (float)ss * 3.0517578125e-05f;                // ||y~||^2 (scaled units) * 2^-15
                 if (grp == 0) atomicMax(norm_max_bits, __float_as_uint((float)ss));
             }
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restric
                     if (e == g) {
                         val = seg == 0 ? nh : seg == 1 ? nl : 0.0f;
                     } else if (live && !bad) {
-                        const float f = (float)((V[cell * g + e] - centre[e]) * scale);
+                        const float f = (float)((V[src * g + e] - centre[e]) * scale);
                         const _Float16 h = (_Float16)f;
                         const float lo = (float)(_Float16)(f - (float)h);
                         const bool want_lo = IS_REF ? seg == 1 : seg == 2;
@@ -334,26 +337,27 @@ __global__ __launch_bounds__(64) void pack_ctiles_kernel(const double *__restric
 
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
-                            bool layout16, hipStream_t st)
+                            bool layout16, hipStream_t st, const uint32_t *perm)
 {
     if (layout16)
         hipLaunchKernelGGL((pack_ctiles_kernel<true, true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre,
-                           scale, kc, ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
+                           scale, kc, ntiles_total, mask, out, (double *)nullptr, norm_max_bits, perm);
     else
         hipLaunchKernelGGL((pack_ctiles_kernel<true, false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, Y, n, g, centre,
-                           scale, kc, ntiles_total, mask, out, (double *)nullptr, norm_max_bits);
+                           scale, kc, ntiles_total, mask, out, (double *)nullptr, norm_max_bits, perm);
     return hipGetLastError();
 }
 
 hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
-                              int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st)
+                              int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st,
+                              const uint32_t *perm)
 {
     if (layout16)
         hipLaunchKernelGGL((pack_ctiles_kernel<false, true>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre,
-                           scale, kc, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
+                           scale, kc, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr, perm);
     else
         hipLaunchKernelGGL((pack_ctiles_kernel<false, false>), dim3((unsigned)ntiles_total), dim3(64), 0, st, X, m, g, centre,
-                           scale, kc, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr);
+                           scale, kc, ntiles_total, (const uint8_t *)nullptr, out, xnorm, (unsigned int *)nullptr, perm);
     return hipGetLastError();
 }
 

@@ -152,13 +152,19 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                                                      const uint32_t *__restrict__ masked_list, int n_masked_list,
                                                      int64_t *__restrict__ out_idx, double *__restrict__ out_dist,
                                                      uint32_t *__restrict__ fail_rows,
-                                                     unsigned int *__restrict__ fail_count, int stage_rows)
+                                                     unsigned int *__restrict__ fail_count, int stage_rows,
+                                                     const uint32_t *__restrict__ rperm,
+                                                     const uint32_t *__restrict__ tperm)
 {
-    // rows [row0, m) of X; candidate arrays are indexed by the row LOCAL to this launch
+    // rows [row0, m) of the filter's row order; candidate arrays are indexed by the row LOCAL to this launch.
+    // Locality order (order.hip): the filter worked on permuted rows -- position prow holds target row tperm[prow]
+    // (xnorm is indexed by position), candidate value c is reference row rperm[c]; both are mapped back HERE, before
+    // the sort by (distance, index), so order rows and indices are the caller's.
     const int lane = lane_id();
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t row = row0 + lrow;
-    if (row >= m) return;
+    const int64_t prow = row0 + lrow;
+    if (prow >= m) return;
+    const int64_t row = tperm ? (int64_t)tperm[prow] : prow;
     const double *x = X + row * g;
     const int ncand = S * L;
     double key[NCL];
@@ -167,7 +173,8 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         extern __shared__ __attribute__((aligned(16))) unsigned char refine_smem[];
         const int gp = g | 1;                                  // odd row stride (in doubles): lanes spread over the banks
         double *stg = reinterpret_cast<double *>(refine_smem) + (size_t)(threadIdx.x >> 6) * stage_rows * gp;
-        const uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
+        uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
+        if (rperm && myj != 0xFFFFFFFFu) myj = rperm[myj];
         // valid candidates are packed into the first stage_rows LDS rows (the lists hold <= lkeep of their L entries:
         // sizing the block for all S * L kept the kernel at three waves per SIMD)
         uint64_t live = __builtin_amdgcn_ballot_w64(myj != 0xFFFFFFFFu);
@@ -192,8 +199,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             key[r] = __builtin_inf();
             val[r] = 0xFFFFFFFFu;
             if (e < ncand) {
-                const uint32_t j = cand_idx[lrow * ncand + e];
+                uint32_t j = cand_idx[lrow * ncand + e];
                 if (j != 0xFFFFFFFFu) {
+                    if (rperm) j = rperm[j];
                     val[r] = j;
                     key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, cb_f);
                 }
@@ -253,9 +261,9 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                 }
             }
         } else {
-            const double sx = sqrt(xnorm[row]);
+            const double sx = sqrt(xnorm[prow]);
             const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
-            const double bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);   // tau in score units
+            const double bound = ((double)tmin * tau_scale + xnorm[prow] - E) * (1.0 - 1e-12);   // tau in score units
             certified = MET == 2 ? (0.5 * bound - 2e-13 > dk) : (bound > dk * dk * (1.0 + 1e-12));
         }
     } else {
@@ -297,12 +305,14 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
                                                           double ymax_sqrt, double tau_scale, int kout, int64_t base,
                                                           int64_t n_valid_total, int64_t *__restrict__ out_idx,
                                                           double *__restrict__ out_dist, double *__restrict__ out_bound,
-                                                          int stage_rows)
+                                                          int stage_rows, const uint32_t *__restrict__ rperm,
+                                                          const uint32_t *__restrict__ tperm)
 {
     const int lane = lane_id();
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t row = row0 + lrow;
-    if (row >= m) return;
+    const int64_t prow = row0 + lrow;                          // position in the filter's row order (refine_kernel)
+    if (prow >= m) return;
+    const int64_t row = tperm ? (int64_t)tperm[prow] : prow;
     const double *x = X + row * g;
     const int ncand = S * L;
     double key[NCL];
@@ -311,7 +321,8 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
         extern __shared__ __attribute__((aligned(16))) unsigned char refine_smem[];
         const int gp = g | 1;
         double *stg = reinterpret_cast<double *>(refine_smem) + (size_t)(threadIdx.x >> 6) * stage_rows * gp;
-        const uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
+        uint32_t myj = lane < ncand ? cand_idx[lrow * ncand + lane] : 0xFFFFFFFFu;
+        if (rperm && myj != 0xFFFFFFFFu) myj = rperm[myj];
         // valid candidates are packed into the first stage_rows LDS rows (the lists hold <= lkeep of their L entries:
         // sizing the block for all S * L kept the kernel at three waves per SIMD)
         uint64_t live = __builtin_amdgcn_ballot_w64(myj != 0xFFFFFFFFu);
@@ -336,8 +347,9 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
             key[r] = __builtin_inf();
             val[r] = 0xFFFFFFFFu;
             if (e < ncand) {
-                const uint32_t j = cand_idx[lrow * ncand + e];
+                uint32_t j = cand_idx[lrow * ncand + e];
                 if (j != 0xFFFFFFFFu) {
+                    if (rperm) j = rperm[j];
                     val[r] = j;
                     key[r] = exact_dist(MET, x, Y + (int64_t)j * g, g, 0.0);
                 }
@@ -357,9 +369,9 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
     // that value (cosine distances are >= -1e-15, squaring keeps the order once the value is positive).
     double bound = __builtin_inf();
     if (tmin != __builtin_inff()) {
-        const double sx = sqrt(xnorm[row]);
+        const double sx = sqrt(xnorm[prow]);
         const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
-        bound = ((double)tmin * tau_scale + xnorm[row] - E) * (1.0 - 1e-12);
+        bound = ((double)tmin * tau_scale + xnorm[prow] - E) * (1.0 - 1e-12);
         if (MET == 2) {
             const double c = 0.5 * bound - 2e-13;
             bound = c > 0.0 ? c * c * (1.0 - 1e-12) : -__builtin_inf();
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
             if ((kout >> 6) == r) dn = __shfl(key[r], kout & 63, 64);
         bound = fmin(bound, dn * dn * (1.0 - 1e-12));
     }
-    if (!(xnorm[row] == xnorm[row])) bound = -__builtin_inf();      // target outside the filter's range (pack.hip)
+    if (!(xnorm[prow] == xnorm[prow])) bound = -__builtin_inf();      // target outside the filter's range (pack.hip)
 #pragma unroll
     for (int r = 0; r < NCL; ++r) {
         const int e = r * 64 + lane;
@@ -604,7 +616,8 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          double ymax_sqrt, double tau_scale, int k, int drop, int64_t base, int64_t n_valid_total,
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
                          uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st, int metric = 0,
-                         double cb_f = 0.0, float cb_plateau = 0.0f, int lvalid = 0)
+                         double cb_f = 0.0, float cb_plateau = 0.0f, int lvalid = 0, const uint32_t *rperm = nullptr,
+                         const uint32_t *tperm = nullptr)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
@@ -617,7 +630,7 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
 #define NABO_RF2(N, MV, SV)                                                                                          \
     hipLaunchKernelGGL((refine_kernel<N, MV, SV>), grid, block, SV ? stage_bytes : 0, st, X, row0, m, Y, g, cand_idx,   \
                        cand_tau, S, L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,       \
-                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count, stage_rows)
+                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count, stage_rows, rperm, tperm)
 #define NABO_RF(N)                                                                                               \
     do {                                                                                                         \
         if (metric == 1) NABO_RF2(N, 1, false);                                                                  \
@@ -644,7 +657,7 @@ hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const do
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
                               int64_t *out_idx, double *out_dist, double *out_bound, hipStream_t st, int metric = 0,
-                              int lvalid = 0)
+                              int lvalid = 0, const uint32_t *rperm = nullptr, const uint32_t *tperm = nullptr)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
@@ -655,7 +668,7 @@ hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const do
 #define NABO_RC2(N, MV, SV)                                                                                             \
     hipLaunchKernelGGL((refine_cand_kernel<N, MV, SV>), grid, block, SV ? stage_bytes : 0, st, X, row0, m, Y, g, cand_idx, \
                        cand_tau, S, L, xnorm, err_coef, ymax_sqrt, tau_scale, kout, base, n_valid_total, out_idx,       \
-                       out_dist, out_bound, stage_rows)
+                       out_dist, out_bound, stage_rows, rperm, tperm)
 #define NABO_RC(N)                                                                                                  \
     do {                                                                                                            \
         if (metric == 2) NABO_RC2(N, 2, false);                                                                     \
