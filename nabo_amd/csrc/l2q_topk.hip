@@ -30,6 +30,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int L2Q_NREC = 64;        // staging records (8 scores each) per wave
 constexpr int L2Q_ROW = 33;         // list entries per row (odd)
+#ifndef L2Q_HOME
+#define L2Q_HOME 8                   // tiles of the home pre-pass (locality order)
+#endif
 
 struct qacc { f32x4 v[2][2]; };     // [row-block of the pair][reference half]
 
@@ -196,17 +199,22 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
-    // Locality order (order.hip): the wave streams its split CYCLICALLY from the tile that holds its rows' neighbourhood
-    // (wave_start, per 128 target rows; a start outside this split's range means "from the split's first tile").  Step t
-    // of the loops below is tile tmap(t).
-    int off = 0;
-    if (wave_start) {
-        off = __builtin_amdgcn_readfirstlane(wave_start[ttile0 / (NB / 2)]) - t_begin;
-        if (off < 0 || off >= tiles_per_split) off = 0;
+    // Locality order (order.hip): before the common stream a wave visits L2Q_HOME tiles around the tile that holds its
+    // rows' neighbourhood (wave_start, per 128 target rows): its thresholds are near their final values when the stream
+    // proper begins, and that stream still runs from the split's first tile in step with every other wave of the XCD
+    // (one copy of the stream in L2 -- a cyclic start per wave gave 4x fewer episodes and a 14 % SLOWER kernel: every wave
+    // then streams its own window).  Step ts of the loops below is tile tmap(ts): the home tiles, then the split's tiles
+    // in order without them.
+    int h0 = t_begin, H = 0;
+    if (wave_start && tiles_per_split >= 4 * L2Q_HOME) {
+        H = L2Q_HOME;
+        h0 = __builtin_amdgcn_readfirstlane(wave_start[ttile0 / (NB / 2)]) - L2Q_HOME / 2;
+        h0 = h0 < t_begin ? t_begin : (h0 > t_end - L2Q_HOME ? t_end - L2Q_HOME : h0);
     }
-    auto tmap = [&](int t) {
-        const int tw = t + off;
-        return tw >= t_end ? tw - tiles_per_split : tw;
+    auto tmap = [&](int ts) {
+        if (ts - t_begin < H) return h0 + (ts - t_begin);
+        const int j = ts - H;
+        return j < h0 ? j : j + H;
     };
     // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop always runs two steps
     auto tile_ptr = [&](int ts) {

@@ -10,10 +10,11 @@
 //   key(cell)  = the sign bits of its first NB centred components, component 0 most significant (NB = min(g, 16));
 //   references = sorted by key (stable LSD radix sort: rocPRIM, a library call off the hot path) and packed in that
 //                order; targets likewise, so the 128 rows of a wave share a neighbourhood;
-//   wave start = the tile holding the first reference whose key is >= the key of the wave's middle row; the wave
-//                streams its split cyclically from there.
-// Measured on the bench's synthetic embeddings (n = 250k, L = 23): 238 -> 149 updates per row with one start per 128
-// rows.  It is an ORDER only: every reference is still visited, results are the same bits (the refine step maps
+//   wave home  = the tile holding the first reference whose key is >= the key of the wave's middle row; the wave
+//                visits a few tiles around it first, then the stream proper from its first tile (l2q_topk.hip: tmap).
+// Simulated on the bench's synthetic embeddings (n = 250k, L = 23, 128 rows per home): 238 updates per row in caller
+// order, 149 streaming cyclically from home, 155 with 8 home tiles and then the key-ordered stream from its start.
+// It is an ORDER only: every reference is still visited, results are the same bits (the refine step maps
 // positions back to caller indices before it sorts by (distance, index)).
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
