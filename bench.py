@@ -399,7 +399,7 @@ def main():
                 "clock_ghz_held": (rec or {}).get("clock_ghz_held")}
         else:
             dig = _lib.src_digest(_lib.KERNEL_SOURCES["canberra"])
-            line["roofline"] = canberra_roofline(pmc_record("canberra", workload, dig), t_kernel, kern)
+            line["roofline"] = canberra_roofline(pmc_record("canberra", workload, dig), t_kernel, kern, dig)
         if kind != "single":
             hx = [s for s in per_rank if "sharded" in s]
             line["sharded"] = {"world": ranks if kind != "loopback" else 1, "rccl_world": ranks if kind in ("launcher", "threads") else None,
@@ -430,7 +430,7 @@ def lay_n_shard(n, shards):
     return shard_bounds(n, shards, 0)[1]
 
 
-def canberra_roofline(rec, t_kernel, kern):
+def canberra_roofline(rec, t_kernel, kern, dig=None):
     """The mod-Canberra filter is vector-ALU work (no contraction): the bound is the chip's vector ISSUE rate, and what
     is priced against it is the number of vector instructions the kernel ACTUALLY issued (SQ_INSTS_VALU of a
     rocprofv3 --pmc pass on this kernel's sources), so the fraction cannot exceed 1.  `frac` is against the issue peak
@@ -441,7 +441,8 @@ def canberra_roofline(rec, t_kernel, kern):
     return {"bound": "valu-issue", "achieved": ach, "peak": PEAK_VALU_GINST, "unit": "G wave-instructions/s",
             "frac": ach / PEAK_VALU_GINST if ach else None,
             "nominal_peak": NOMINAL_VALU_GINST, "frac_of_nominal_issue_peak": ach / NOMINAL_VALU_GINST if ach else None,
-            "valu_insts_per_step": insts, "pmc_record": rec, "kernel": kern, "kernel_ms": t_kernel * 1e3}
+            "valu_insts_per_step": insts, "pmc_record": rec, "kernel": kern, "kernel_ms": t_kernel * 1e3,
+            "kernel_src_digest": dig}
 
 
 def canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, dY, dX, X, Yfull, sync):
@@ -472,7 +473,7 @@ def canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, dY, dX, X, Yfull, sync
             "ms_per_step": best * 1e3, "value": m * n / best, "unit": "cell-pair distances/s",
             "phases_ms": {key: st[key] for key in ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
             "fallback_rows": st["fallback_rows"], "sampled_rows_equal_oracle": same,
-            "roofline": canberra_roofline(pmc_record("canberra", workload, dig), st["ms_topk"] * 1e-3, kern)}
+            "roofline": canberra_roofline(pmc_record("canberra", workload, dig), st["ms_topk"] * 1e-3, kern, dig)}
 
 
 def alt_block(nabo_amd, _knn, kern, dev, n, m, d, k, dY, dX, gi, gd, sync):

@@ -251,6 +251,67 @@ def _component_labels(n, a, b):
         lab = new
 
 
+# ---- columnar graph layout (opt-in extension; the reference's per-node layout is the default) ---------------------
+_G_NODES, _G_PTR, _G_NBR, _G_W = "__graph_nodes", "__graph_ptr", "__graph_nbr", "__graph_w"
+
+
+def write_columnar_graph(grp, node_names, ptr, nbr, w):
+    """CSR by node: node i has neighbours nbr[ptr[i]:ptr[i+1]] (positions in `ref_cells/ref_cells`) with weights w[...],
+    rows in the order the per-node datasets would list them."""
+    grp.create_dataset(_G_NODES, data=np.array([n.encode("ascii") for n in node_names]))
+    grp.create_dataset(_G_PTR, data=np.asarray(ptr, dtype=np.int64))
+    grp.create_dataset(_G_NBR, data=np.asarray(nbr, dtype=np.int32))
+    grp.create_dataset(_G_W, data=np.asarray(w, dtype=np.float64))
+
+
+def read_graph_csr(grp, ref_pos):
+    """(node names, ptr int64 [n+1], neighbour reference positions int64 [E], weights float64 [E]) of a `<uid>_graph`
+    group in either layout; ref_pos maps a reference NODE name to its position in `ref_cells/ref_cells`."""
+    if _G_PTR in grp:
+        return ([x.decode("UTF-8") for x in grp[_G_NODES][:]], grp[_G_PTR][:].astype(np.int64),
+                grp[_G_NBR][:].astype(np.int64), grp[_G_W][:])
+    nodes, ptr, nbr, w = [], [0], [], []
+    for node in grp:
+        nodes.append(node)
+        for row in grp[node]:
+            nbr.append(ref_pos[row[0].decode("UTF-8")])
+            w.append(float(row[1].decode("UTF-8")))      # the weight as the reference parses it (nabo/_graph.py:105-106)
+        ptr.append(len(nbr))
+    return nodes, np.array(ptr, dtype=np.int64), np.array(nbr, dtype=np.int64), np.array(w, dtype=np.float64)
+
+
+def expand_graph(mapping_h5_fn, name):
+    """Rewrite the columnar graph of `name` (the reference's or a target's name) in the reference's per-node wire format
+    (nabo/_mapping.py:252-273), in place, so that `Graph.load_from_h5` (nabo/_graph.py:31-116) can read it."""
+    h5py = _h5py()
+    with h5py.File(mapping_h5_fn, mode="a") as h5:
+        ref_name = h5["name_stash/ref_name"][0].decode("UTF-8")
+        uid = h5["name_stash/ref_name"][1].decode("UTF-8") if name == ref_name else None
+        if uid is None:
+            for i in h5["name_stash/target_names"][:]:
+                if i[0].decode("UTF-8") == name:
+                    uid = i[1].decode("UTF-8")
+        if uid is None:
+            raise ValueError("ERROR: %s not present in graph" % name)
+        grp = h5[uid + "_graph"]
+        if _G_PTR not in grp:
+            return
+        nodes, ptr, nbr, w = read_graph_csr(grp, None)
+        ref_nodes = np.array([(x.decode("UTF-8") + "_" + ref_name).encode("ascii") for x in h5["ref_cells/ref_cells"][:]])
+        del h5[uid + "_graph"]
+        out = h5.create_group(uid + "_graph")
+        for i, node in enumerate(nodes):
+            a, b = int(ptr[i]), int(ptr[i + 1])
+            if a == b:
+                out.create_dataset(node, data=np.empty((0,), dtype=np.float64))
+                continue
+            width = max(32, max(len(x) for x in ref_nodes[nbr[a:b]]))
+            rows = np.empty((b - a, 2), dtype="S%d" % width)
+            rows[:, 0] = ref_nodes[nbr[a:b]]
+            rows[:, 1] = [repr(float(x)).encode("ascii") for x in w[a:b]]
+            out.create_dataset(node, data=rows)
+
+
 class Mapping:
     """
     Cell mapping on the GPU.  Same constructor and methods as the reference class
@@ -266,6 +327,10 @@ class Mapping:
     communicator per GPU behind nabo_sharded_query, include/nabo_knn.h; results equal the one-GPU run bit for bit as
     long as at least k (+1 for the reference graph) reference cells are not ignored -- with fewer the one-GPU path
     continues a row with the ignored cells, as numpy.ma does, and the sharded one raises a ValueError).
+    `graph_layout="columnar"`: the SNN graphs as four arrays per graph (node names, row pointers, neighbour positions,
+    weights) instead of the reference's one dataset per node (nabo/_mapping.py:252-273) -- at 1M cells the per-node
+    format IS the run time (23 of 28 s); `nabo_amd.get_mapping_score*` read either, `nabo_amd.expand_graph` rewrites a
+    columnar graph in the reference's format for `Graph.load_from_h5`.
     `store_k`: keep max(k, store_k) entries of every order row, so that `use_stored_distances=True` still works after
     `set_parameters` RAISED k up to store_k -- the reference keeps full rows (nabo/_mapping.py:139-145) and therefore
     serves any later k (:537-541, :596-607); the filter's candidate lists already hold more than k entries, so a
@@ -273,7 +338,8 @@ class Mapping:
     """
 
     def __init__(self, mapping_h5_fn, ref_name, ref_pca_fn, ref_pca_grp_name, overwrite=False, *,
-                 device=0, devices=None, layout="per_cell", target_metric=None, shard_transport="rccl", store_k=None):
+                 device=0, devices=None, layout="per_cell", target_metric=None, shard_transport="rccl", store_k=None,
+                 graph_layout="per_node"):
         self._h5Fn = mapping_h5_fn
         if ref_name.find("__") != -1:
             raise ValueError("ERROR: Underscores are not allowed in the value for `ref_name` parameter")
@@ -293,6 +359,9 @@ class Mapping:
         self._device = self._devices[0]
         self._shardTransport = shard_transport       # "rccl", or "loopback" (device-to-device copies; devices may repeat)
         self._layout = layout
+        if graph_layout not in ("per_node", "columnar"):
+            raise ValueError("ERROR: graph_layout must be 'per_node' or 'columnar'")
+        self._graphLayout = graph_layout
         if store_k is not None and int(store_k) < 1:
             raise ValueError("ERROR: store_k must be a positive integer")
         self._storeK = None if store_k is None else int(store_k)
@@ -615,6 +684,12 @@ class Mapping:
         node_k, nb_k, w_keep = node_k[o2], nb_k[o2], w_keep[o2]
         counts = np.bincount(node_k, minlength=n_t)
         starts = np.concatenate([[0], np.cumsum(counts)])
+        if self._graphLayout == "columnar":
+            with h5py.File(self._h5Fn, mode="a") as h5:
+                if out_grp in h5:
+                    del h5[out_grp]
+                write_columnar_graph(h5.create_group(out_grp), t_nodes_s, starts, nb_k, w_keep)
+            return
         # weights take few distinct values: format each once (numpy's float -> bytes coercion is repr)
         uw, winv = np.unique(w_keep, return_inverse=True)
         wtxt = np.array([repr(float(x)).encode("ascii") for x in uw]) if len(uw) else np.empty(0, dtype="S1")

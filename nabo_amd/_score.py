@@ -71,28 +71,47 @@ def get_mapping_score(mapping_h5_fn, ref_name, target, min_weight=0, min_score=0
         if ignore_nodes is not None and include_nodes is not None:
             raise ValueError("ERROR: PLease provide only one of either 'ignore_nodes' or 'include_nodes' at a time")
         ref_uid = h5["name_stash/ref_name"][1].decode("UTF-8")
-        if ref_uid + "_graph" in h5:
+        if ref_uid + "_graph" in h5 and "__graph_ptr" in h5[ref_uid + "_graph"]:
+            # columnar reference graph: the per-node group would list its nodes in HDF5 (byte) name order
+            ref_nodes = sorted(x.decode("UTF-8") for x in h5[ref_uid + "_graph/__graph_nodes"][:])
+        elif ref_uid + "_graph" in h5:
             ref_nodes = [n for n in h5[ref_uid + "_graph"]]            # load order of Graph.refNodes
         else:
             ref_nodes = sorted(x.decode("UTF-8") + "_" + ref_name for x in h5["ref_cells/ref_cells"][:])
         pos = {n: i for i, n in enumerate(ref_nodes)}
         grp = h5[uid + "_graph"]
-        t_nodes = [n for n in grp]
+        from ._mapping import _G_PTR, read_graph_csr
+        if _G_PTR in grp:
+            # columnar graph (Mapping(graph_layout="columnar")): neighbour positions refer to ref_cells/ref_cells
+            cells_pos = np.array([pos[x.decode("UTF-8") + "_" + ref_name] for x in h5["ref_cells/ref_cells"][:]], dtype=np.int64)
+            t_nodes, ptr, nbr, wts = read_graph_csr(grp, None)
+            nbr = cells_pos[nbr]
+        else:
+            t_nodes, ptr, nbr, wts = None, None, None, None
+        if t_nodes is None:
+            t_nodes = [n for n in grp]
         tset = {n: None for n in t_nodes}
         ign = set(n for n in (ignore_nodes or []) if n in tset)
         inc = list(t_nodes) if include_nodes is None else [n for n in include_nodes if n in tset]
         inc = set(inc).difference(ign)
         ridx, w = [], []
         n_iso_t = 0
-        for node in t_nodes:
-            if node not in inc:
-                continue
-            rows = grp[node]
-            if rows.shape[0] == 0:
-                n_iso_t += 1
-            for row in rows:
-                ridx.append(pos[row[0].decode("UTF-8")])
-                w.append(float(row[1].decode("UTF-8")))
+        if ptr is not None:
+            keep = np.array([n in inc for n in t_nodes], dtype=bool)
+            deg = np.diff(ptr)
+            n_iso_t = int(((deg == 0) & keep).sum())
+            sel = np.repeat(keep, deg)
+            ridx, w = nbr[sel].tolist(), wts[sel].tolist()
+        else:
+            for node in t_nodes:
+                if node not in inc:
+                    continue
+                rows = grp[node]
+                if rows.shape[0] == 0:
+                    n_iso_t += 1
+                for row in rows:
+                    ridx.append(pos[row[0].decode("UTF-8")])
+                    w.append(float(row[1].decode("UTF-8")))
     if verbose:
         hit = np.zeros(len(ref_nodes), dtype=bool)
         hit[np.asarray(ridx, dtype=np.int64)] = True
@@ -180,16 +199,10 @@ def _read_target_edges(h5, ref_name, target, pos):
             uid = i[1].decode("UTF-8")
     if uid is None:
         raise ValueError("ERROR: %s not present in graph" % target)
-    grp = h5[uid + "_graph"]
-    t, r, w = [], [], []
-    n_nodes = 0
-    for node in grp:
-        for row in grp[node]:
-            t.append(n_nodes)
-            r.append(pos[row[0].decode("UTF-8")])
-            w.append(float(row[1].decode("UTF-8")))
-        n_nodes += 1
-    return n_nodes, np.array(t, dtype=np.int64), np.array(r, dtype=np.int64), np.array(w)
+    from ._mapping import read_graph_csr
+    nodes, ptr, nbr, w = read_graph_csr(h5[uid + "_graph"], pos)           # either graph layout
+    t = np.repeat(np.arange(len(nodes), dtype=np.int64), np.diff(ptr))
+    return len(nodes), t, nbr, w
 
 
 def get_mapping_score_null(mapping_h5_fn, ref_name, target, background, n_perm=1000, seed=0, score_multiplier=1000,

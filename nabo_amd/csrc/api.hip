@@ -226,6 +226,7 @@ struct nabo_index {
     // locality order (order.hip; l2q kernel only): reference keys / permutation (resident), target keys / permutation and
     // the waves' start tiles (per query), sort scratch
     bool order = false;            // decided at creation (NABO_L2Q_ORDER=0 streams in caller order: same results)
+    int order_flags = 0;
     bool ref_ordered = false;      // the packed f16 tiles are in key order
     DevBuf rkeys, rperm, tkeys, tperm, wstart, okeys, opos, otemp;
     bool packed_f32 = false, packed_c16 = false;
@@ -422,7 +423,12 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
             // default: the 16x16x32 MFMA shape (l2q_topk.hip; the chip holds a higher clock on it); =f16x3h pins the
             // 32x32x16 per-wave kernel, =f16x3s the shared-tile one (both use the 32x32 operand layout)
             ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0));
-            ix->order = ix->q16 && env_int("NABO_L2Q_ORDER", 1) != 0;
+            // NABO_L2Q_ORDER (bit flags; every setting gives the same results): 1 = references packed in key order,
+            // 2 = targets packed in key order, 4 = home pre-pass of every wave; 0 = caller order, the DEFAULT: key order
+            // cuts the list updates by 30 % and the hit episodes by 70 %, and the kernel is 20 % SLOWER on it -- sorted
+            // operands cost more clock than the hit path they save (order.hip, profiles/r3_order_experiment.txt)
+            ix->order_flags = ix->q16 ? env_int("NABO_L2Q_ORDER", 0) : 0;
+            ix->order = (ix->order_flags & 1) != 0;
         }
     }
     int cus = 0;
@@ -747,16 +753,19 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // locality order (order.hip): the l2q kernel streams key-ordered references; the targets are packed in key order
         // too and every wave starts its stream at its rows' neighbourhood
         const bool ordered = use_h && !use_c && ix->q16 && ix->ref_ordered;
+        const bool t_ordered = use_h && !use_c && ix->q16 && (ix->order_flags & 2) != 0;
         const uint32_t *rperm = nullptr, *tperm = nullptr;
         const int32_t *wstart = nullptr;
-        if (ordered) {
+        if (ordered) rperm = ix->rperm.as<uint32_t>();
+        if (t_ordered) {
             if ((rc = order_rows(ix, dXp, m, ix->tkeys, ix->tperm))) return rc;
+            tperm = ix->tperm.as<uint32_t>();
+        }
+        if (ordered && t_ordered && (ix->order_flags & 4) != 0) {
             const int64_t n_waves = rows_pad / 128;
             if ((rc = ix->wstart.reserve((size_t)n_waves * 4))) return rc;
             HIP_TRY(nabo::wave_start_launch(ix->tkeys.as<uint32_t>(), m, 128, ix->rkeys.as<uint32_t>(), ix->n, n_waves,
                                             ix->wstart.as<int32_t>(), st));
-            rperm = ix->rperm.as<uint32_t>();
-            tperm = ix->tperm.as<uint32_t>();
             wstart = ix->wstart.as<int32_t>();
         }
         if (use_h)

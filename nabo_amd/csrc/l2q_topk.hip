@@ -53,22 +53,10 @@ __device__ __forceinline__ qacc qchain(f16x8 (&a)[2][KS], const f16x8 (&b0)[KS],
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-#ifdef NABO_L2Q_SPREAD2
-        for (int s = 0; s < KS + ((RELOAD && c >= 2) ? 1 : 0); ++s) {
-#else
         for (int s = 0; s < KS + ((RELOAD && c == 3) ? 1 : 0); ++s) {
-#endif
             if (s < KS)
                 acc.v[c >> 1][c & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[c & 1][s], (c >> 1) ? b1[s] : b0[s], acc.v[c >> 1][c & 1], 0, 0, 0);
 #ifndef NABO_L2H_NORELOAD
-#ifdef NABO_L2Q_SPREAD2
-            // experiment: a[0][s] is free after the THIRD accumulator's step s -- one load behind each of the last 2 KS MFMAs
-            if (RELOAD && c >= 2 && s >= 1) {
-                __builtin_amdgcn_sched_barrier(0);
-                a[c - 2][s - 1] = reinterpret_cast<const f16x8 *>(next)[((c - 2) * KS + s - 1) * 64 + lane];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#else
             if (RELOAD && c == 3) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (s < KS) a[0][s] = reinterpret_cast<const f16x8 *>(next)[s * 64 + lane];
@@ -76,32 +64,6 @@ __device__ __forceinline__ qacc qchain(f16x8 (&a)[2][KS], const f16x8 (&b0)[KS],
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
-#endif
-        }
-    }
-    return acc;
-}
-
-// The same chain for the ring of THREE register sets (NABO_L2Q_RING3): no set is refilled in place -- while tile t is
-// contracted out of `a`, tile t + 2 streams into the set tile t - 1 left free, its 2 KS loads spread over the NP chains
-// of the tile (registers [L0, L1) of the flattened [2][KS] set in this chain, one load behind every MFMA of the first
-// accumulator) instead of 2 KS loads fenced into the last KS MFMAs.
-template <int KS, int L0, int L1>
-__device__ __forceinline__ qacc qchain3(const f16x8 (&a)[2][KS], const f16x8 (&b0)[KS], const f16x8 (&b1)[KS],
-                                        f16x8 (&nx)[2][KS], const unsigned char *__restrict__ next, int lane)
-{
-    qacc acc;
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) acc.v[r][h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            acc.v[c >> 1][c & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[c & 1][s], (c >> 1) ? b1[s] : b0[s], acc.v[c >> 1][c & 1], 0, 0, 0);
-            const int l = L0 + c * KS + s;                  // at most one load behind each MFMA
-            if (l < L1) nx[l / KS][l % KS] = reinterpret_cast<const f16x8 *>(next)[l * 64 + lane];
         }
     }
     return acc;
@@ -225,64 +187,6 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
         return Ypk + ((dbg & 2) ? (int64_t)(t_begin + ((t - t_begin) & 127)) : (dbg & 4) ? (int64_t)(t_begin + ((t - t_begin) & 1)) : tc) * TB;
     };
 
-#ifdef NABO_L2Q_RING3
-    // ---- ring of three register sets --------------------------------------------------------------------------------
-    f16x8 a0[2][KS], a1[2][KS], a2[2][KS];
-    {
-        const f16x8 *p0 = reinterpret_cast<const f16x8 *>(tile_ptr(t_begin)), *p1 = reinterpret_cast<const f16x8 *>(tile_ptr(t_begin + 1));
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int s = 0; s < KS; ++s) { a0[h][s] = p0[(h * KS + s) * 64 + lane]; a1[h][s] = p1[(h * KS + s) * 64 + lane]; }
-    }
-    qacc accP;
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) accP.v[r][h] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
-    // all NP pair-chains of tile t out of `a`; tile t + 2 streams into `nx` meanwhile (2 KS loads over NP chains)
-    auto tile_step = [&](const f16x8(&a)[2][KS], f16x8(&nx)[2][KS], int t) {
-        const unsigned char *next2 = tile_ptr(t + 2);
-        qacc accA;
-        constexpr int NL = 2 * KS;
-#define NABO_Q3(P) qchain3<KS, (NL * (P)) / NP, (NL * ((P) + 1)) / NP>(a, xb[2 * (P)], xb[2 * (P) + 1], nx, next2, lane)
-        {
-            const qverdict v = qfilter_eval<NB>(accP, 2 * (NP - 1), tauv);
-            accA = NABO_Q3(0);
-            qfilter_stage<C, EPL, NB, NREC>(accP, v, 2 * (NP - 1), (uint32_t)(tmap(t - 1) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
-        }
-        {
-            const qverdict v = qfilter_eval<NB>(accA, 0, tauv);
-            accP = NABO_Q3(1);
-            qfilter_stage<C, EPL, NB, NREC>(accA, v, 0, (uint32_t)(tmap(t) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
-        }
-        {
-            const qverdict v = qfilter_eval<NB>(accP, 2, tauv);
-            accA = NABO_Q3(2);
-            qfilter_stage<C, EPL, NB, NREC>(accP, v, 2, (uint32_t)(tmap(t) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
-        }
-        {
-            const qverdict v = qfilter_eval<NB>(accA, 4, tauv);
-            accP = NABO_Q3(3);
-            qfilter_stage<C, EPL, NB, NREC>(accA, v, 4, (uint32_t)(tmap(t) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
-        }
-#undef NABO_Q3
-    };
-    static_assert(NP == 4, "tile_step is written out for four pairs");
-    // steps in threes (tiles past the split's end are the all-padding tile: +inf norms, nothing passes)
-    // (a peeled first group: the wait hipcc places at the loop head is the strictest over every way into the loop, and
-    // the prologue's interleaved loads would make it vmcnt(0) -- every group would wait for its own newest refills)
-    tile_step(a0, a2, t_begin);
-    tile_step(a1, a0, t_begin + 1);
-    tile_step(a2, a1, t_begin + 2);
-    int t = t_begin + 3;
-    for (; t < t_end; t += 3) {
-        tile_step(a0, a2, t);
-        tile_step(a1, a0, t + 1);
-        tile_step(a2, a1, t + 2);
-    }
-    qfilter<C, EPL, NB, NREC>(accP, NB - 2, (uint32_t)(tmap(t - 1) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
-#else
     f16x8 a0[2][KS], a1[2][KS];
     {
         const f16x8 *p0 = reinterpret_cast<const f16x8 *>(tile_ptr(t_begin)), *p1 = reinterpret_cast<const f16x8 *>(tile_ptr(t_begin + 1));
@@ -344,8 +248,6 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
         const int tl = t_begin + ((tiles_per_split + 1) & ~1) - 1;          // the last step run (t_end - 1 or the padding step)
         qfilter<C, EPL, NB, NREC>(accP, NB - 2, (uint32_t)(tmap(tl) * 32 + 4 * lq), wl, scnt, lkeep, tauv);
     }
-
-#endif
 
     lists_flush<C, EPL, NB>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }

@@ -16,6 +16,18 @@
 // order, 149 streaming cyclically from home, 155 with 8 home tiles and then the key-ordered stream from its start.
 // It is an ORDER only: every reference is still visited, results are the same bits (the refine step maps
 // positions back to caller indices before it sorts by (distance, index)).
+//
+// MEASURED (round 3, 1M x 1M x 50, k = 15, one MI355X, profiles/r3_order_experiment.txt) -- and therefore OFF by default
+// (NABO_L2Q_ORDER=7 switches it on; parity-tested either way):
+//   list counters (-DNABO_LISTS_PROF): episodes 88.4M -> 25.2M, staged records 193M -> 110M, list entries written
+//   244M -> 172M, drains 3.0M -> 1.7M -- as simulated; kernel 239 ms -> 287 ms.  Piece by piece on one box: references in
+//   key order alone 329 ms (a row approaches its own cluster through ever closer cells: an adversarial order), targets in
+//   key order alone 258 ms with the references untouched -- the hit counts of a random stream do not depend on the
+//   target order at all, so those 8 % are not list work: rows of a wave that resemble each other make the 16 columns of
+//   every MFMA switch in step, and the part, which is power-limited under this kernel, holds a lower
+//   clock on such operands.  Both orders + the home pre-pass: 287 ms; a cyclic start per wave instead of the pre-pass:
+//   284 ms (every wave then streams its own window of the references: no sharing in L2).  What the lists save, the
+//   clock takes back twice over.  Caller order -- cells in the random order of a count matrix -- is the fast order.
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>

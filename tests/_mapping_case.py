@@ -193,6 +193,32 @@ def run_case(tag):
             out["no_store_k_raises"] = k_small == k              # (nothing to raise when k could not be lowered)
         except ValueError:
             out["no_store_k_raises"] = k_small < k
+        # columnar GRAPH layout (opt-in): same scores straight from the columnar file, and expand_graph() rewrites it in
+        # the reference's per-node wire format -- the same datasets, byte for byte, as the default writer's
+        map9 = os.path.join(td, "mapping_gcol.h5")
+        tn9, names9, data9, ign9 = targets[0]
+        with redirect_stdout(buf):
+            m9 = nabo_amd.Mapping(map9, "WT", ref_fn, "data", overwrite=True, graph_layout="columnar")
+            m9.set_parameters(uc, k, f, chunk)
+            m9.make_ref_graph()
+            m9.map_target(tn9, os.path.join(td, "t_%s.h5" % tn9), "data", ignore_ref_cells=ign9)
+        sc_a = nabo_amd.get_mapping_score(map_fn, "WT", tn9)
+        sc_b = nabo_amd.get_mapping_score(map9, "WT", tn9)
+        out["columnar_graph_same_scores"] = (list(sc_a) == list(sc_b)) and all(sc_a[n] == sc_b[n] for n in sc_a)
+        if len(targets) >= 2:
+            with redirect_stdout(buf):
+                m9.map_target(targets[1][0], os.path.join(td, "t_%s.h5" % targets[1][0]), "data", ignore_ref_cells=targets[1][3])
+            na = nabo_amd.get_mapping_score_null(map_fn, "WT", targets[0][0], targets[1][0], n_perm=32, seed=5)
+            nb_ = nabo_amd.get_mapping_score_null(map9, "WT", targets[0][0], targets[1][0], n_perm=32, seed=5)
+            out["columnar_graph_same_null"] = na == nb_
+        nabo_amd.expand_graph(map9, "WT")
+        nabo_amd.expand_graph(map9, tn9)
+        _, _, ruid9 = read_graph_like_reference(map9, "WT", "reference")
+        _, _, tuid9 = read_graph_like_reference(map9, tn9, "target")
+        _, _, ruid0 = read_graph_like_reference(map_fn, "WT", "reference")
+        _, _, tuid0 = read_graph_like_reference(map_fn, tn9, "target")
+        out["columnar_graph_expands_to_the_wire_format"] = (read_graph_raw(map9, ruid9) == read_graph_raw(map_fn, ruid0) and
+                                                            read_graph_raw(map9, tuid9) == read_graph_raw(map_fn, tuid0))
         # columnar layout gives the same graph
         map2 = os.path.join(td, "mapping_col.h5")
         with redirect_stdout(buf):

@@ -407,6 +407,48 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     assert kernels["f16x3"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels                 # the default f16x3 kernel
 
 
+@pytest.mark.parametrize("flags", ["7", "3", "1", "2"])
+@pytest.mark.parametrize("m,n,g,k,drop,metric,masked", [
+    (140000, 20000, 50, 15, False, 0, False),        # 274 workgroups on 256 slots: main launch + split tail round
+    (3000, 70000, 30, 11, False, 0, True),           # few rows: reference splits, every split with its own home pre-pass
+    (2500, 2500, 20, 9, True, 0, False),             # positional drop
+    (5000, 40000, 40, 12, False, 2, False),          # cosine (extension): keys from the unit-length rows, no centring
+    (900, 600, 7, 20, False, 0, True),               # fewer tiles than four pre-passes: no pre-pass
+])
+def test_locality_ordered_streaming_gives_the_same_bits(gpu_lib, flags, m, n, g, k, drop, metric, masked):
+    """order.hip (NABO_L2Q_ORDER, off by default -- measured slower, profiles/r3_order_experiment.txt): references and /
+    or targets packed in key order, home pre-pass per wave; positions are mapped back in the refine step, so indices,
+    distances, tie order, the ignore mask and the candidate-mode outputs are the caller's."""
+    from nabo_amd import _knn
+    Y = pca_like(n, g, seed=3100 + n)
+    Y[7] = Y[3]                                            # an exact tie: (distance, ORIGINAL index) order must survive the permutation
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=3200 + m)
+    mask = None
+    if masked:
+        mask = (np.random.default_rng(n).random(n) < 0.3).astype(np.uint8)
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, drop_first=drop, nthreads=8)
+    os.environ["NABO_L2Q_ORDER"] = flags
+    try:
+        ix = gpu_lib.KnnIndex(n, g, metric=metric, ref_index_base=1000).set_ref(Y, ref_mask=mask)
+    finally:
+        os.environ.pop("NABO_L2Q_ORDER", None)
+    gi, gd = ix.query(X, k, drop_first=drop)
+    assert "l2q_topk" in ix.last_kernel()
+    _check(gi - 1000, gd, oi, od)
+    # shard mode: the first entries of the order rows + a bound that really bounds the rest
+    nc = min(k, 12)
+    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
+    di, dd, db = _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * 8)
+    ix.query_candidates_device(dx.ptr, m, nc, di.ptr, dd.ptr, db.ptr)
+    ci, cd, cb = di.download((m, nc), np.int64), dd.download((m, nc), np.float64), db.download((m,), np.float64)
+    ix.close()
+    for b in (dx, di, dd, db):
+        b.free()
+    o2i, o2d = oracle.knn(X, Y, nc + 1, metric, 0.25, ref_mask=mask, nthreads=8)
+    assert np.array_equal(ci - 1000, o2i[:, :nc]) and np.array_equal(cd, o2d[:, :nc])
+    assert (cb <= o2d[:, nc] ** 2 * (1 + 1e-12)).all()
+
+
 @pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3s", 274), ("f16x3h", 274), ("f16x3q", 274)])
 def test_tail_round_split_rows_are_exact(gpu_lib, mode, full_round):
     """More target workgroups than resident slots: the last, partially filled round is launched with its

@@ -61,5 +61,7 @@ def test_mapping_end_to_end_vs_reference_outputs(mode):
     assert res["sharded_devices_same_graphs"]
     assert res["store_k_serves_larger_k_per_cell"] and res["store_k_serves_larger_k_columnar"] and res["no_store_k_raises"]
     assert res["target_metric_euclidean"]
+    assert res["columnar_graph_same_scores"] and res["columnar_graph_expands_to_the_wire_format"]
+    assert res.get("columnar_graph_same_null", True)
     if "null_obs_is_mapping_score" in res:
         assert res["null_obs_is_mapping_score"] and res["null_pvalues_in_range"]
