@@ -268,8 +268,15 @@ def read_graph_csr(grp, ref_pos):
     """(node names, ptr int64 [n+1], neighbour reference positions int64 [E], weights float64 [E]) of a `<uid>_graph`
     group in either layout; ref_pos maps a reference NODE name to its position in `ref_cells/ref_cells`."""
     if _G_PTR in grp:
-        return ([x.decode("UTF-8") for x in grp[_G_NODES][:]], grp[_G_PTR][:].astype(np.int64),
-                grp[_G_NBR][:].astype(np.int64), grp[_G_W][:])
+        # nodes in HDF5 (byte) name order, as iterating a per-node group yields them: float64 sums over a reference
+        # node's edges (mapping scores) then add up in the same order whichever layout the file uses
+        names = grp[_G_NODES][:]
+        ptr, nbr, w = grp[_G_PTR][:].astype(np.int64), grp[_G_NBR][:].astype(np.int64), grp[_G_W][:]
+        order = np.argsort(names, kind="stable")
+        deg = np.diff(ptr)[order]
+        optr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        idx = np.arange(int(optr[-1]), dtype=np.int64) - np.repeat(optr[:-1], deg) + np.repeat(ptr[:-1][order], deg)
+        return [x.decode("UTF-8") for x in names[order]], optr, nbr[idx], w[idx]
     nodes, ptr, nbr, w = [], [0], [], []
     for node in grp:
         nodes.append(node)

@@ -116,7 +116,9 @@ __device__ __forceinline__ void qfilter(const qacc &acc, int rb0, uint32_t jb, u
 }
 
 // Grid: x = target super-blocks (4 waves x 128 rows), y = reference splits.
-template <int KC, int EPL, int ROWN>
+// HOMEP: the locality-ordered form (order.hip; off by default) -- compiled separately so that the default kernel carries
+// none of its per-tile index arithmetic.
+template <int KC, int EPL, int ROWN, bool HOMEP = false>
 __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *__restrict__ Xpk,
                                                           const unsigned char *__restrict__ Ypk,
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
@@ -168,12 +170,13 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
     // then streams its own window).  Step ts of the loops below is tile tmap(ts): the home tiles, then the split's tiles
     // in order without them.
     int h0 = t_begin, H = 0;
-    if (wave_start && tiles_per_split >= 4 * L2Q_HOME) {
+    if (HOMEP && wave_start && tiles_per_split >= 4 * L2Q_HOME) {
         H = L2Q_HOME;
         h0 = __builtin_amdgcn_readfirstlane(wave_start[ttile0 / (NB / 2)]) - L2Q_HOME / 2;
         h0 = h0 < t_begin ? t_begin : (h0 > t_end - L2Q_HOME ? t_end - L2Q_HOME : h0);
     }
     auto tmap = [&](int ts) {
+        if (!HOMEP) return ts;
         if (ts - t_begin < H) return h0 + (ts - t_begin);
         const int j = ts - H;
         return j < h0 ? j : j + H;
@@ -252,19 +255,19 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
     lists_flush<C, EPL, NB>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }
 
-template <int KC, int EPL, int ROWN>
-static hipError_t qlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
-                              int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              int64_t pad_tile, hipStream_t st, const int32_t *wave_start)
+template <int KC, int EPL, int ROWN, bool HOMEP>
+static hipError_t qlaunch_k(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                            int64_t pad_tile, hipStream_t st, const int32_t *wave_start)
 {
     const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, 8, L2Q_NREC, 16>::BYTES;
     static_assert(lds <= 163840, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2q_topk_kernel<KC, EPL, ROWN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2q_topk_kernel<KC, EPL, ROWN, HOMEP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(256);
-    hipLaunchKernelGGL((l2q_topk_kernel<KC, EPL, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off,
+    hipLaunchKernelGGL((l2q_topk_kernel<KC, EPL, ROWN, HOMEP>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off,
                        lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg, wave_start);
 #ifdef NABO_LISTS_PROF
     {
@@ -276,6 +279,17 @@ static hipError_t qlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk
     }
 #endif
     return hipGetLastError();
+}
+
+template <int KC, int EPL, int ROWN>
+static hipError_t qlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                              int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                              int64_t pad_tile, hipStream_t st, const int32_t *wave_start)
+{
+    return wave_start ? qlaunch_k<KC, EPL, ROWN, true>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
+                                                       cand_tau, pad_tile, st, wave_start)
+                      : qlaunch_k<KC, EPL, ROWN, false>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
+                                                        cand_tau, pad_tile, st, nullptr);
 }
 
 // 512 rows per workgroup, one workgroup per CU (one wave per SIMD with the whole register file), lists of <= 32 kept

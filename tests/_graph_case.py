@@ -46,15 +46,15 @@ def write_pca(fn, grp, names, data):
             g.create_dataset(str(n), data=v)
 
 
-def build_file(td, gold):
+def build_file(td, gold, graph_layout="per_node", tag="ours"):
     """the mapping file of `mapping_small`, written by this build's writer without a GPU"""
     uc, k, chunk = [int(v) for v in gold["params"]]
     ref_fn = os.path.join(td, "ref.h5")
     write_pca(ref_fn, "data", [str(x) for x in gold["ref_names"]], gold["ref"])
-    fn = os.path.join(td, "ours.h5")
+    fn = os.path.join(td, tag + ".h5")
     buf = io.StringIO()
     with redirect_stdout(buf):
-        om = nabo_amd.Mapping(fn, "WT", ref_fn, "data", overwrite=True)
+        om = nabo_amd.Mapping(fn, "WT", ref_fn, "data", overwrite=True, graph_layout=graph_layout)
         om.set_parameters(uc, k, float(gold["dist_factor"]), chunk)
     r_idx = gold["ref_idx"][:, :k].astype(np.int64)
 
@@ -138,6 +138,16 @@ def main():
                 abs(a - b) <= 1e-12 * max(1.0, abs(a)) for a, b in zip(want[c], got[c])) for c in want)
             if not ok:
                 bad.append((i, call["kwargs"]))
+        # columnar graph layout (opt-in extension): same scores straight from the columnar file; expand_graph() rewrites it
+        # in the reference's per-node wire format, same digest as the default writer (and thus as the reference's file)
+        fn2, uids2, _ = build_file(td, gold, "columnar", "ours_columnar")
+        sc1, sc2 = nabo_amd.get_mapping_score(fn, "WT", "ME"), nabo_amd.get_mapping_score(fn2, "WT", "ME")
+        out["columnar_graph_same_scores"] = list(sc1) == list(sc2) and all(sc1[n] == sc2[n] for n in sc1)
+        for name in ("WT", "ME", "IG"):
+            nabo_amd.expand_graph(fn2, name)
+        with h5py.File(fn2, "r") as h5:
+            mine2 = {t: graph_digest(h5, uids2[t] + "_graph") for t in uids2}
+        out["columnar_graph_expands_to_same_digest"] = mine2 == mine
         out["by_cluster_calls_checked"] = len(json.loads(str(bc["calls"])))
         out["by_cluster_calls_differ"] = bad
     print("RESULT " + json.dumps(out))

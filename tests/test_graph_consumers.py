@@ -24,3 +24,4 @@ def test_writer_bytes_and_score_options_vs_reference():
     assert res["score_calls_checked"] >= 18 and res["score_calls_differ"] == [], res
     assert res["score_errors_differ"] == [], res
     assert res["by_cluster_calls_checked"] >= 4 and res["by_cluster_calls_differ"] == [], res
+    assert res["columnar_graph_same_scores"] and res["columnar_graph_expands_to_same_digest"], res

