@@ -97,7 +97,7 @@ def so_digest():
 # the launch logic and the compiler flags
 KERNEL_SOURCES = {
     "euclid": ["l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "order.hip", "api.hip", "_build.py"],
-    "canberra": ["canberra_f32.hip", "knn_common.h", "api.hip", "_build.py"],
+    "canberra": ["canberra_f32.hip", "canberra_bits.hip", "knn_common.h", "api.hip", "_build.py"],
 }
 
 

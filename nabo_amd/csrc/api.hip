@@ -2,6 +2,7 @@
 // buffer management, kernel sequencing on the index's HIP stream, HIP-event timing.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -99,6 +100,18 @@ hipError_t cbf_colminmax_launch(const double *Y, int64_t n, int g, unsigned int 
 hipError_t cbf_pack_refs8_launch(const double *Y, int64_t n, int g, int gp, const double *quant, void *ych, hipStream_t st);
 hipError_t cbf_pack_targets8_launch(const double *X, int64_t m, int g, int gp, double f, const double *quant, void *xh,
                                     hipStream_t st);
+// the counting pass on per-bucket bitmaps (canberra_bits.hip)
+int cbb_buckets();
+int cbb_rows_per_wg();
+bool cbb_available(int g, int gp, int epl);
+size_t cbb_table_bytes(int64_t n, int g);
+size_t cbb_valid_bytes(int64_t n);
+hipError_t cbb_pack_table_launch(const double *Y, int64_t n, int g, const double *edges, uint32_t *tab, hipStream_t st);
+hipError_t cbb_valid_launch(const uint8_t *mask, int64_t n, uint32_t *vbits, hipStream_t st);
+hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, const double *edges, uint32_t *rowoff,
+                                   hipStream_t st);
+hipError_t cbb_filter_launch(int gp, const float *xq, const uint32_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
+                             const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st);
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
 hipError_t iota_launch(uint32_t *out, int64_t n, hipStream_t st);
 hipError_t scatter_rows_launch(const int64_t *si, const double *sd, const uint32_t *rows, int64_t nrows, int k,
@@ -236,6 +249,9 @@ struct nabo_index {
     DevBuf yt, ycf, yrow, cbflag, ych, cbscale, xh;    // ych/xh: 7-bit operands of the counting pass, cbscale [2g] doubles (min, 1/step)
     int cb_gp = 0;
     bool cb_f32 = false;          // filter usable for these references (fits fp32, g <= 128)
+    // bit-sliced counting pass (canberra_bits.hip): quantile edges [g][B-1], cumulative bitmaps, valid bits, target row numbers
+    DevBuf cbedges, cbtab, cbvalid, cbrow;
+    bool cb_bits = false;
 
     // query workspace
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
@@ -452,7 +468,7 @@ int nabo_index_destroy(nabo_index *ix)
     DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->ycpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d, &ix->fails2,
                       &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
                       &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound, &ix->rkeys, &ix->rperm, &ix->tkeys, &ix->tperm, &ix->wstart, &ix->okeys,
-                      &ix->opos, &ix->otemp};
+                      &ix->opos, &ix->otemp, &ix->cbedges, &ix->cbtab, &ix->cbvalid, &ix->cbrow};
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
         if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
@@ -500,8 +516,9 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         HIP_TRY(nabo::transpose_ref_launch(ix->dY, ix->n, ix->g, ix->yt.as<double>(), st));
         ix->cb_gp = nabo::cbf_pick_gp(ix->g);
         ix->cb_f32 = false;
-        const char *cm = getenv("NABO_CANBERRA_MODE");
-        if (ix->cb_gp > 0 && !(cm && strcmp(cm, "exact") == 0)) {
+        ix->cb_bits = false;
+        const char *cmode = getenv("NABO_CANBERRA_MODE");
+        if (ix->cb_gp > 0 && !(cmode && strcmp(cmode, "exact") == 0)) {
             unsigned int flag = 0;
             if ((rc = ix->ycf.reserve((size_t)chunks * 64 * ix->cb_gp * sizeof(float)))) return rc;      // chunk-major (range check)
             if ((rc = ix->yrow.reserve((size_t)ix->n * ix->cb_gp * sizeof(float)))) return rc;           // row-major (bound pass)
@@ -540,6 +557,39 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                 HIP_TRY(nabo::cbf_pack_refs_rows_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->yrow.as<float>(), st));
                 HIP_TRY(nabo::cbf_pack_refs8_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
                 HIP_TRY(hipStreamSynchronize(st));      // sc goes out of scope
+                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 16 blocks
+                // (NABO_CANBERRA_MODE=swar pins the 7-bit SWAR pass, =bits the bitmaps at any size): per-dimension
+                // QUANTILE bucket edges from a strided sample of the references (any edges give correct results -- they
+                // only decide how sharp the count is), cumulative bitmaps per block of 2048 references.
+                ix->cb_bits = false;
+                const bool want_bits = cmode ? strcmp(cmode, "bits") == 0 : ix->n >= 16 * 2048;
+                if (want_bits && nabo::cbb_available(G, ix->cb_gp, 1)) {
+                    const int B = nabo::cbb_buckets();
+                    int64_t ns = ix->n < 8192 ? ix->n : 8192;
+                    const int64_t stride = ix->n / ns;
+                    std::vector<double> smp((size_t)ns * G), col((size_t)ns), edges((size_t)G * (B - 1));
+                    HIP_TRY(hipMemcpy2DAsync(smp.data(), (size_t)G * sizeof(double), ix->dY, (size_t)stride * G * sizeof(double),
+                                             (size_t)G * sizeof(double), (size_t)ns, hipMemcpyDeviceToHost, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                    for (int k = 0; k < G; ++k) {
+                        size_t nf = 0;
+                        for (int64_t i = 0; i < ns; ++i) {
+                            const double v = smp[(size_t)i * G + k];
+                            if (std::isfinite(v)) col[nf++] = v;
+                        }
+                        std::sort(col.begin(), col.begin() + nf);
+                        for (int b = 1; b < B; ++b)
+                            edges[(size_t)k * (B - 1) + (b - 1)] = nf ? col[(size_t)((double)b * nf / B)] : 0.0;
+                    }
+                    if ((rc = ix->cbedges.reserve(edges.size() * sizeof(double)))) return rc;
+                    if ((rc = ix->cbtab.reserve(nabo::cbb_table_bytes(ix->n, G)))) return rc;
+                    if ((rc = ix->cbvalid.reserve(nabo::cbb_valid_bytes(ix->n)))) return rc;
+                    HIP_TRY(hipMemcpyAsync(ix->cbedges.p, edges.data(), edges.size() * sizeof(double), hipMemcpyHostToDevice, st));
+                    HIP_TRY(nabo::cbb_pack_table_launch(ix->dY, ix->n, G, ix->cbedges.as<double>(), ix->cbtab.as<uint32_t>(), st));
+                    HIP_TRY(nabo::cbb_valid_launch(ix->dmask, ix->n, ix->cbvalid.as<uint32_t>(), st));
+                    HIP_TRY(hipStreamSynchronize(st));      // edges goes out of scope
+                    ix->cb_bits = true;
+                }
             }
         }
         HIP_TRY(hipStreamSynchronize(st));
@@ -555,6 +605,10 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
     int rc = use_device(ix->device);
     if (rc) return rc;
     if ((rc = apply_mask(ix, ref_mask))) return rc;
+    if (ix->metric == NABO_METRIC_MOD_CANBERRA && ix->cb_bits) {
+        HIP_TRY(nabo::cbb_valid_launch(ix->dmask, ix->n, ix->cbvalid.as<uint32_t>(), ix->stream));
+        HIP_TRY(hipStreamSynchronize(ix->stream));
+    }
     if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0) {       // masked cells carry ||y||^2 = +inf in the packed tiles
         ix->packed_f32 = ix->packed_c16 = false;
         if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
@@ -934,16 +988,23 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // fp32 lower-bound filter -> float64 refine + certification -> exact re-solve of uncertified rows
             float slack, plateau;
             nabo::cbf_constants(g, &slack, &plateau);
-            snprintf(ix->kernel, sizeof(ix->kernel), "cbf_filter_kernel<%d> (7-bit integer count + fp32 lower bound)", ix->cb_gp);
+            // which counting pass: bitmaps (canberra_bits.hip) where built and instantiated (32-entry lists), else SWAR
+            const bool bits = ix->cb_bits && epl == 1;
+            if (bits) snprintf(ix->kernel, sizeof(ix->kernel), "cbb_filter_kernel<%d> (bit-sliced count on %d-bucket bitmaps + fp32 lower bound)", ix->cb_gp, nabo::cbb_buckets());
+            else snprintf(ix->kernel, sizeof(ix->kernel), "cbf_filter_kernel<%d> (7-bit integer count + fp32 lower bound)", ix->cb_gp);
             // filter geometry: T rows per workgroup, 2 workgroups per CU resident; every (row, split) ends
             // with `lists` candidate lists (one per wave).  Splits fill the chip when there are few rows and
             // trim the last, partially filled round of workgroups when there are many.
             const int lists = nabo::cbf_lists_per_split();
-            const int64_t gxf = (m + nabo::cbf_rows_per_wg(epl) - 1) / nabo::cbf_rows_per_wg(epl);
+            const int rpw = bits ? nabo::cbb_rows_per_wg() : nabo::cbf_rows_per_wg(epl);
+            const int64_t gxf = (m + rpw - 1) / rpw;
             const int64_t slots = (int64_t)ix->n_cu * 8;                 // one-wave workgroups, 2 per SIMD
             int Sf = env_int("NABO_SPLITS", 0);
             int s_max = 1024 / (lists * L);                   // refine handles <= 1024 candidates per row
-            if (s_max > n_chunks / (8 * lists)) s_max = (int)(n_chunks / (8 * lists));
+            if (bits) {                                       // splits are ranges of 2048-reference blocks, >= 2 each
+                const int64_t nb2 = ((ix->n + 2047) / 2048) / 2;
+                if (s_max > nb2) s_max = (int)nb2;
+            } else if (s_max > n_chunks / (8 * lists)) s_max = (int)(n_chunks / (8 * lists));
             if (s_max < 1) s_max = 1;
             if (Sf <= 0) {
                 Sf = 1;
@@ -958,7 +1019,6 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if (Sf > s_max) Sf = s_max;
             // "tail round": with many rows the last, partially filled round of workgroups gets its own (larger)
             // split factor so that it takes a fraction of a round -- same idea as in the Euclidean launch above
-            const int rpw = nabo::cbf_rows_per_wg(epl);
             int64_t gx_main = gxf, gx_tail = 0;
             int S2 = 1;
             if (env_int("NABO_SPLITS", 0) <= 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && gxf > slots && gxf % slots != 0 &&
@@ -994,16 +1054,30 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(hipMemsetAsync(ix->cbflag.p, 0, 4 * sizeof(unsigned int), st));
             unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();
             HIP_TRY(nabo::cbf_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->xpk.as<float>(), d_flag, st));
-            HIP_TRY(nabo::cbf_pack_targets8_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbscale.as<double>(), ix->xh.p, st));
-            HIP_TRY(hipEventRecord(ix->ev[1], st));
-            HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), ix->xh.p, rows_main, ix->yrow.as<float>(),
-                                            ix->ych.p, ix->n, g, ix->dmask, Sf, ix->cand_idx.as<uint32_t>(),
-                                            ix->cand_tau.as<float>(), st));
-            if (rows_tail > 0)
-                HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>() + (size_t)rows_main * ix->cb_gp * 2,
-                                                ix->xh.as<unsigned char>() + (size_t)rows_main * ix->cb_gp * 2, rows_tail,
-                                                ix->yrow.as<float>(), ix->ych.p, ix->n, g, ix->dmask, S2,
-                                                ix->cand_idx2.as<uint32_t>(), ix->cand_tau2.as<float>(), st));
+            if (bits) {
+                if ((rc = ix->cbrow.reserve((size_t)m * ix->cb_gp * sizeof(uint32_t)))) return rc;
+                HIP_TRY(nabo::cbb_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbedges.as<double>(), ix->cbrow.as<uint32_t>(), st));
+                HIP_TRY(hipEventRecord(ix->ev[1], st));
+                HIP_TRY(nabo::cbb_filter_launch(ix->cb_gp, ix->xpk.as<float>(), ix->cbrow.as<uint32_t>(), rows_main,
+                                                ix->yrow.as<float>(), ix->cbtab.as<uint32_t>(), ix->cbvalid.as<uint32_t>(), ix->n, g,
+                                                Sf, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), st));
+                if (rows_tail > 0)
+                    HIP_TRY(nabo::cbb_filter_launch(ix->cb_gp, ix->xpk.as<float>() + (size_t)rows_main * ix->cb_gp * 2,
+                                                    ix->cbrow.as<uint32_t>() + (size_t)rows_main * ix->cb_gp, rows_tail,
+                                                    ix->yrow.as<float>(), ix->cbtab.as<uint32_t>(), ix->cbvalid.as<uint32_t>(),
+                                                    ix->n, g, S2, ix->cand_idx2.as<uint32_t>(), ix->cand_tau2.as<float>(), st));
+            } else {
+                HIP_TRY(nabo::cbf_pack_targets8_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbscale.as<double>(), ix->xh.p, st));
+                HIP_TRY(hipEventRecord(ix->ev[1], st));
+                HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>(), ix->xh.p, rows_main, ix->yrow.as<float>(),
+                                                ix->ych.p, ix->n, g, ix->dmask, Sf, ix->cand_idx.as<uint32_t>(),
+                                                ix->cand_tau.as<float>(), st));
+                if (rows_tail > 0)
+                    HIP_TRY(nabo::cbf_filter_launch(ix->cb_gp, epl, ix->xpk.as<float>() + (size_t)rows_main * ix->cb_gp * 2,
+                                                    ix->xh.as<unsigned char>() + (size_t)rows_main * ix->cb_gp * 2, rows_tail,
+                                                    ix->yrow.as<float>(), ix->ych.p, ix->n, g, ix->dmask, S2,
+                                                    ix->cand_idx2.as<uint32_t>(), ix->cand_tau2.as<float>(), st));
+            }
             HIP_TRY(hipEventRecord(ix->ev[2], st));
             if (dbg_counts) {
                 unsigned int c2[2] = {0, 0};

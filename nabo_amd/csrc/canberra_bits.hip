@@ -1,0 +1,418 @@
+// canberra_bits.hip -- the counting pass of the modified-Canberra filter as BIT-SLICED arithmetic on per-bucket bitmaps.
+//
+// Context (canberra_f32.hip): _mod_canberra_dist (nabo/_mapping.py:29-45) adds exactly 1 for every dimension whose
+// |x - y| is outside the window f |x| and a quotient in [0, 1) otherwise, so `distance >= number of dimensions PROVEN out
+// of window`; a pair whose count already reaches the row's threshold is dropped, the survivors get the fp32 lower bound,
+// the kept candidates the exact float64 expression (refine.hip).  The SWAR form of the count (7-bit integers, four
+// dimensions per word: v_sub, v_sub, v_bitop3, v_bcnt per four dimensions and ONE reference per lane) issues 1.22 vector
+// instructions per pair and dimension and runs at 88 % of the vector issue peak: it cannot get faster, only smaller.
+//
+// This file turns the count by 90 degrees: a lane holds 32 REFERENCES as the bits of a word.
+//   * Per dimension the references' values are cut into CBB_B = 32 QUANTILE buckets (edges from a sample of the
+//     references, api.hip); b(v) = #{edges <= v} is a non-decreasing step function, so for any window (lo, hi)
+//     y in (lo, hi)  =>  b(lo) <= b(y) <= b(hi): counting "may be in window" on bucket numbers can only err towards IN.
+//   * Index side (once per set_ref): for every block of 2048 references, dimension d and bucket row r the word
+//     tab[block][d][r][w] holds, for the 32 references of word w, the bits "b(y_d) <= r - 1" (row 0 is the empty set):
+//     cumulative bitmaps, 50 x 33 x 64 words per block = 206 bytes per reference.
+//   * Query side: a target's window in dimension d is two row numbers (lo_row = b(lo), hi_row = b(hi) + 1, 16 bits each,
+//     one word per (target, dimension)), and the 32 references of a word that MAY be in the window are
+//         tab[hi_row] & ~tab[lo_row]                      two coalesced 256-byte loads + one vector instruction per 2048 pairs.
+//     The per-reference count over the dimensions is a carry-save adder tree on the bit planes (Harley-Seal: seven 3:2
+//     compressors -- v_bitop3 0x96 / 0xE8 -- per eight dimensions, then a ripple into the 8 / 16 / 32 planes), the
+//     comparison with the row's integer threshold a bit-sliced comparator: ~3.5 vector instructions per dimension and
+//     32 pairs -- 0.11 per pair and dimension against 1.22.
+//   * Survivors (7e-3 of the pairs with 32 quantile buckets, simulated on the bench's data; 2.2e-3 for the 128 uniform
+//     buckets of the SWAR pass) leave through the same wave-private work ring, fp32 lower bound, candidate lists and
+//     certificate as before -- results are the reference's bits either way (tests/test_knn_gpu.py: canberra cases run
+//     both kernels).
+// The wave owns T = 32 target rows (lists, row numbers and thresholds in LDS: 8 waves per CU) and streams the blocks of
+// its reference split; what bounds the pass is the vector L1 (two 256-byte loads per 3.5 vector instructions).
+#include <cstdlib>
+#include <type_traits>
+#include "knn_common.h"
+
+namespace nabo {
+
+constexpr int CBB_B = 32;                 // quantile buckets per dimension
+constexpr int CBB_ROWS = CBB_B + 1;       // cumulative rows per dimension (row 0: empty set)
+constexpr int CBB_BLK = 2048;             // references per block: 64 lanes x 32 bits
+constexpr int CBB_T = 32;                 // target rows per wave
+
+int cbb_buckets() { return CBB_B; }
+int cbb_rows_per_wg() { return CBB_T; }
+size_t cbb_table_bytes(int64_t n, int g) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * g * CBB_ROWS * 64 * sizeof(uint32_t); }
+size_t cbb_valid_bytes(int64_t n) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * 64 * sizeof(uint32_t); }
+
+// b(v) = number of edges <= v, edges ascending [CBB_B - 1]
+__device__ __forceinline__ int cbb_bucket(const double *__restrict__ edges, double v)
+{
+    int lo = 0, hi = CBB_B - 1;           // answer in [0, CBB_B - 1]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (edges[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// grid (blocks, g), 64 threads: lane w builds the 33 cumulative rows of its word for dimension blockIdx.y
+__global__ __launch_bounds__(64) void cbb_pack_table_kernel(const double *__restrict__ Y, int64_t n, int g,
+                                                            const double *__restrict__ edges, uint32_t *__restrict__ tab)
+{
+    __shared__ uint32_t eq[CBB_ROWS][64];
+    const int w = threadIdx.x, d = blockIdx.y;
+    const int64_t blk = blockIdx.x;
+#pragma unroll
+    for (int r = 0; r < CBB_ROWS; ++r) eq[r][w] = 0u;
+    const double *ed = edges + (size_t)d * (CBB_B - 1);
+    for (int r = 0; r < 32; ++r) {
+        const int64_t j = blk * CBB_BLK + (int64_t)w * 32 + r;
+        if (j < n) eq[cbb_bucket(ed, Y[j * g + d]) + 1][w] |= 1u << r;         // (column w is this lane's own: no races)
+    }
+    uint32_t acc = 0u;
+    uint32_t *o = tab + ((size_t)(blk * g + d) * CBB_ROWS) * 64 + w;
+    for (int r = 0; r < CBB_ROWS; ++r) {
+        acc |= eq[r][w];
+        o[(size_t)r * 64] = acc;
+    }
+}
+
+// vbits[block][w]: bit r = reference block*2048 + 32 w + r exists and is not ignored
+__global__ void cbb_valid_kernel(const uint8_t *__restrict__ mask, int64_t n, int64_t n_words, uint32_t *__restrict__ vbits)
+{
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    uint32_t v = 0u;
+    for (int r = 0; r < 32; ++r) {
+        const int64_t j = w * 32 + r;
+        if (j < n && !(mask && mask[j])) v |= 1u << r;
+    }
+    vbits[w] = v;
+}
+
+// rowoff[row][k] = (d 33 + b(lo)) | (d 33 + b(hi) + 1) << 16 for the window (lo, hi) of the reference's test widened by
+// its own float64 roundings (T+ as in canberra_f32.hip: cbf_pack_targets8_kernel); padding dimensions: 0 (empty set)
+__global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
+                                        const double *__restrict__ edges, uint32_t *__restrict__ rowoff)
+{
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m * gp) return;
+    const int64_t row = e / gp;
+    const int k = (int)(e - row * gp);
+    if (k >= g) { rowoff[e] = 0u; return; }
+    const double x = X[row * g + k];
+    const double tp = (f * fabs(x)) * (1.0 + 2.3e-16) * (1.0 + 1e-12);             // T+ >= the reference's fl64(f |x|), padded
+    int blo = 0, bhi = CBB_B - 1;                                                   // "cannot tell": every bucket
+    if (tp == tp && tp < 1e300 && x == x) {
+        const double *ed = edges + (size_t)k * (CBB_B - 1);
+        // in-window  =>  |x - y| < T+  =>  y in (x - T+, x + T+); the two ends computed in float64 and moved one ulp outwards
+        blo = cbb_bucket(ed, nextafter(x - tp, -__builtin_inf()));
+        bhi = cbb_bucket(ed, nextafter(x + tp, __builtin_inf()));
+    }
+    rowoff[e] = (uint32_t)(k * CBB_ROWS + blo) | ((uint32_t)(k * CBB_ROWS + bhi + 1) << 16);
+}
+
+template <int EPL>
+__device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count, float (&key)[EPL], uint32_t (&val)[EPL])
+{
+    constexpr int L = 32 * EPL;
+    const int lane = lane_id();
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const int e = r * 64 + lane;
+        key[r] = __builtin_inff();
+        val[r] = 0xFFFFFFFFu;
+        if (e < count) { key[r] = kb[e]; val[r] = ib[e]; }
+    }
+    wave_sort_f32<EPL>(key, val);
+#pragma unroll
+    for (int r = 0; r < EPL; ++r) {
+        const int e = r * 64 + lane;
+        if (e < L) { kb[e] = key[r]; ib[e] = val[r]; }
+    }
+    return __shfl(key[(L - 1) >> 6], (L - 1) & 63, 64);
+}
+
+// 3:2 compressor on bit planes: (h, l) = a + b + c
+#define CBB_CSA(h, l, a, b, c)                                                        \
+    do {                                                                              \
+        const uint32_t a__ = (a), b__ = (b), c__ = (c);                               \
+        (h) = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0xE8);                       \
+        (l) = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0x96);                       \
+    } while (0)
+
+// grid.x = ceil(m / T) one-wave workgroups, grid.y = S splits of `blocks_per_split` reference blocks.
+template <int GP, int EPL>
+__global__ __launch_bounds__(64, 2)
+void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict__ rowoff, int64_t m,
+                       const float *__restrict__ yrow, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ vbits,
+                       int64_t n, int g, int64_t n_blocks, int64_t blocks_per_split, float slack, float plateau,
+                       uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau)
+{
+    constexpr int T = CBB_T;
+    constexpr int L = 32 * EPL, CAP = L + 16 * EPL;      // kept + pending entries per list
+    constexpr int NG = GP / 8;                           // groups of eight dimensions
+    constexpr int WLN = 512;                             // work-list ring (entries)
+    static_assert(GP % 8 == 0 && GP <= 128, "padded dimensionality");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = lane_id();
+    // ro [T][GP] u32 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | cnt [T] i32 | thr [T] u32 | wl [WLN] u32 | wl_t [WLN] u8
+    uint32_t *ro = reinterpret_cast<uint32_t *>(smem_raw);
+    float *keys = reinterpret_cast<float *>(ro + T * GP);
+    uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
+    float *tau = reinterpret_cast<float *>(idxs + T * CAP);
+    int *cnt = reinterpret_cast<int *>(tau + T);
+    uint32_t *thr_l = reinterpret_cast<uint32_t *>(cnt + T);
+    uint32_t *wl = thr_l + T;
+    unsigned char *wl_t = reinterpret_cast<unsigned char *>(wl + WLN);
+
+    const int S = gridDim.y;
+    const int split = blockIdx.y;
+    const int64_t row0 = (int64_t)blockIdx.x * T;
+    if (row0 >= m) return;                                   // (no barriers in this kernel)
+    // Survivor test: n_out = g - inw dimensions are PROVEN out of window, distance >= n_out; a pair is dropped when
+    // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. survivors have inw > g - t1 (canberra_f32.hip: count_threshold).
+    auto count_threshold = [&](float tau_t) -> uint32_t {
+        float t1 = tau_t + (2e-5f + slack);
+        t1 = __uint_as_float(__float_as_uint(t1) + (t1 < __builtin_inff() ? 1u : 0u));
+        const float need = (float)g - t1;
+        return need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;
+    };
+    for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); cnt[e] = 0; thr_l[e] = 0u; }
+    for (int e = lane; e < T * GP; e += 64) {
+        const int64_t row = row0 + e / GP;
+        ro[e] = row < m ? rowoff[row * GP + e % GP] : 0u;
+    }
+    const float below_plateau = __uint_as_float(__float_as_uint(plateau) - 1u);
+    int t_cnt = T;
+    if (row0 + T > m) t_cnt = (int)(m - row0);
+    int wl_head = 0, wl_n = 0;                               // wave-uniform ring state
+
+    // fp32 lower bound of `nb` (<= 64) work-list pairs, one per lane, then list insertion (canberra_f32.hip: drain);
+    // the target's packed (x, thr) row comes from global memory here (rare: 7e-3 of the pairs)
+    auto drain = [&](int nb) {
+        const bool act = lane < nb;
+        const int slot = (wl_head + lane) & (WLN - 1);
+        const uint32_t j = act ? wl[slot] : 0u;
+        const int t_p = act ? (int)wl_t[slot] : 0;
+        wl_head = (wl_head + nb) & (WLN - 1);
+        wl_n -= nb;
+        const float4 *xp = reinterpret_cast<const float4 *>(xq + (row0 + t_p) * GP);     // (x, thr) of two dimensions
+        const float4 *yp = reinterpret_cast<const float4 *>(yrow + (int64_t)j * GP);     // four dimensions
+        float lb = 0.0f;
+        int no_p = 0;
+#pragma unroll 1
+        for (int q8 = 0; q8 < GP / 8; ++q8) {
+            const float4 y0 = yp[2 * q8], y1 = yp[2 * q8 + 1];
+            const float4 x0 = xp[4 * q8], x1 = xp[4 * q8 + 1], x2 = xp[4 * q8 + 2], x3 = xp[4 * q8 + 3];
+            const float xs_[8] = {x0.x, x0.z, x1.x, x1.z, x2.x, x2.z, x3.x, x3.z};
+            const float th_[8] = {x0.y, x0.w, x1.y, x1.w, x2.y, x2.w, x3.y, x3.w};
+            const float ys_[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float s = fabsf(xs_[k]) + fabsf(ys_[k]);
+                const float ad = fabsf(xs_[k] - ys_[k]);
+                const float nlb = fmaxf(__builtin_fmaf(s, -2.5e-07f, ad), 0.0f);
+                const float den = __builtin_fmaf(s, 1.00000072f, 0.01000002f);
+                const float q = nlb * __builtin_amdgcn_rcpf(den);
+                const bool out = ad >= th_[k];
+                no_p += out ? 1 : 0;
+                lb += out ? 1.0f : q;
+            }
+        }
+        const float key = (no_p == g) ? plateau : fminf(lb - slack, below_plateau);
+        const bool hit = act && (key < tau[t_p]);
+        if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
+        for (int t2 = 0; t2 < t_cnt; ++t2) {
+            bool pend = hit && (t_p == t2);
+            uint64_t pm = __builtin_amdgcn_ballot_w64(pend);
+            while (pm != 0) {
+                const int c = cnt[t2];
+                const int room = CAP - c;
+                if (room == 0) {
+                    float kr[EPL];
+                    uint32_t vr[EPL];
+                    const float nt = cbb_compact<EPL>(keys + t2 * CAP, idxs + t2 * CAP, c, kr, vr);
+                    if (lane == 0) { tau[t2] = nt; cnt[t2] = L; thr_l[t2] = count_threshold(nt); }
+                    pend = pend && (key < nt);
+                } else {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    const bool take = pend && rank < room;
+                    if (take) {
+                        keys[t2 * CAP + c + rank] = key;
+                        idxs[t2 * CAP + c + rank] = j;
+                    }
+                    const int np = __popcll(pm);
+                    if (lane == 0) cnt[t2] = c + (np < room ? np : room);
+                    pend = pend && !take;
+                }
+                pm = __builtin_amdgcn_ballot_w64(pend);
+            }
+        }
+    };
+
+    const int64_t b_begin = split * blocks_per_split;
+    int64_t b_end = b_begin + blocks_per_split;
+    if (b_end > n_blocks) b_end = n_blocks;
+    for (int64_t blk = b_begin; blk < b_end; ++blk) {
+        const uint32_t *tb = tab + (size_t)blk * g * CBB_ROWS * 64 + lane;          // this lane's word of every row
+        const uint32_t vmask = vbits[blk * 64 + lane];
+        // window masks of eight dimensions of target t: two loads per dimension, row numbers wave-uniform
+        uint32_t hv[2][8], lv[2][8];
+        auto load_group = [&](int t, int grp, uint32_t (&h)[8], uint32_t (&l)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ro[t * GP + grp * 8 + i]);
+                h[i] = tb[(size_t)(r >> 16) * 64];
+                l[i] = tb[(size_t)(r & 0xFFFFu) * 64];
+            }
+        };
+        // One target against the block.  P = which of the two register sets holds its first group (the sets alternate
+        // group by group; with an odd number of groups the parity flips from target to target).
+        auto target = [&](auto par, int t) {
+            constexpr int P = decltype(par)::value;
+            uint32_t ones = 0u, twos = 0u, fours = 0u, eights = 0u, sixteens = 0u, thirtytwos = 0u;
+#pragma unroll
+            for (int grp = 0; grp < NG; ++grp) {
+                // the next group's loads (the next target's first group behind the last one) fly while this one is counted
+                constexpr int PN = (P + NG) & 1;
+                const int cur = (P + grp) & 1;
+                if (grp + 1 < NG) load_group(t, grp + 1, hv[cur ^ 1], lv[cur ^ 1]);
+                else if (t + 1 < t_cnt) load_group(t + 1, 0, hv[PN], lv[PN]);
+                uint32_t mk[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) mk[i] = hv[cur][i] & ~lv[cur][i];
+                uint32_t tA, tB, fA, fB, e8;
+                CBB_CSA(tA, ones, ones, mk[0], mk[1]);
+                CBB_CSA(tB, ones, ones, mk[2], mk[3]);
+                CBB_CSA(fA, twos, twos, tA, tB);
+                CBB_CSA(tA, ones, ones, mk[4], mk[5]);
+                CBB_CSA(tB, ones, ones, mk[6], mk[7]);
+                CBB_CSA(fB, twos, twos, tA, tB);
+                CBB_CSA(e8, fours, fours, fA, fB);
+                const uint32_t c16 = eights & e8;
+                eights ^= e8;
+                const uint32_t c32 = sixteens & c16;
+                sixteens ^= c16;
+                thirtytwos ^= c32;
+            }
+            // inw >= thr ?  bit-sliced, the threshold is wave-uniform (padding dimensions count nothing)
+            const uint32_t thr_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_l[t]);
+            uint32_t ge = 0u;
+            if (thr_in < 64u) {
+                const uint32_t pl[6] = {ones, twos, fours, eights, sixteens, thirtytwos};
+                uint32_t gt = 0u, eq = 0xFFFFFFFFu;
+#pragma unroll
+                for (int b = 5; b >= 0; --b) {
+                    if ((thr_in >> b) & 1u) eq &= pl[b];
+                    else { gt |= eq & pl[b]; eq &= ~pl[b]; }
+                }
+                ge = (gt | eq) & vmask;
+            }
+            uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
+            while (anyb != 0) {                                  // every lane with survivors hands over its lowest one
+                const bool has = ge != 0u;
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
+                if (has) {
+                    const int r = __builtin_ctz(ge);
+                    const int slot = (wl_head + wl_n + rank) & (WLN - 1);
+                    wl[slot] = (uint32_t)(blk * CBB_BLK + lane * 32 + r);
+                    wl_t[slot] = (unsigned char)t;
+                    ge &= ge - 1u;
+                }
+                wl_n += __popcll(anyb);
+                while (wl_n >= 64) drain(64);
+                anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
+            }
+        };
+        load_group(0, 0, hv[0], lv[0]);
+        if (NG & 1) {
+            for (int t = 0; t < t_cnt; t += 2) {
+                target(std::integral_constant<int, 0>{}, t);
+                if (t + 1 < t_cnt) target(std::integral_constant<int, 1>{}, t + 1);
+            }
+        } else {
+            for (int t = 0; t < t_cnt; ++t) target(std::integral_constant<int, 0>{}, t);
+        }
+    }
+    while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);
+    // flush: the L smallest (key, index) per target; tau = L-th key if anything was ever dropped
+    for (int t = 0; t < t_cnt; ++t) {
+        const int64_t row = row0 + t;
+        float kr[EPL];
+        uint32_t vr[EPL];
+        const int c = cnt[t];
+        const float nt = cbb_compact<EPL>(keys + t * CAP, idxs + t * CAP, c, kr, vr);
+        float t_row = tau[t];
+        if (c > L) t_row = nt;
+        const int64_t o = (row * S + split) * (int64_t)L;
+#pragma unroll
+        for (int r = 0; r < EPL; ++r) {
+            const int e = r * 64 + lane;
+            if (e < L) cand_idx[o + e] = vr[r];
+        }
+        if (lane == 0) cand_tau[row * S + split] = t_row;
+    }
+}
+
+hipError_t cbb_pack_table_launch(const double *Y, int64_t n, int g, const double *edges, uint32_t *tab, hipStream_t st)
+{
+    const int64_t blocks = (n + CBB_BLK - 1) / CBB_BLK;
+    hipLaunchKernelGGL(cbb_pack_table_kernel, dim3((unsigned)blocks, (unsigned)g), dim3(64), 0, st, Y, n, g, edges, tab);
+    return hipGetLastError();
+}
+
+hipError_t cbb_valid_launch(const uint8_t *mask, int64_t n, uint32_t *vbits, hipStream_t st)
+{
+    const int64_t words = ((n + CBB_BLK - 1) / CBB_BLK) * 64;
+    hipLaunchKernelGGL(cbb_valid_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, mask, n, words, vbits);
+    return hipGetLastError();
+}
+
+hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, const double *edges, uint32_t *rowoff,
+                                   hipStream_t st)
+{
+    const int64_t tot = m * gp;
+    hipLaunchKernelGGL(cbb_pack_targets_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, X, m, g, gp, f, edges,
+                       rowoff);
+    return hipGetLastError();
+}
+
+void cbf_constants(int g, float *slack, float *plateau);
+
+template <int GP, int EPL>
+static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
+                                 const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau,
+                                 hipStream_t st)
+{
+    constexpr int L = 32 * EPL, CAP = L + 16 * EPL;
+    const int64_t n_blocks = (n + CBB_BLK - 1) / CBB_BLK;
+    const int64_t bps = (n_blocks + S - 1) / S;
+    float slack, plateau;
+    cbf_constants(g, &slack, &plateau);
+    const size_t lds = (size_t)CBB_T * GP * 4 + (size_t)CBB_T * CAP * 8 + (size_t)CBB_T * 12 + 512 * 5 + 16;
+    auto kern = &cbb_filter_kernel<GP, EPL>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)((m + CBB_T - 1) / CBB_T), S), block(64);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const float2 *>(xq), rowoff, m, yrow, tab, vbits, n, g,
+                       n_blocks, bps, slack, plateau, cand_idx, cand_tau);
+    return hipGetLastError();
+}
+
+// instantiated for g <= 64 (six count planes hold 63) and 32-entry lists (k + drop_first <= 24)
+bool cbb_available(int g, int gp, int epl) { return g <= 63 && gp <= 64 && epl == 1; }
+
+hipError_t cbb_filter_launch(int gp, const float *xq, const uint32_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
+                             const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st)
+{
+#define NABO_CBB(GPV) case GPV: return cbb_launch_one<GPV, 1>(xq, rowoff, m, yrow, tab, vbits, n, g, S, cand_idx, cand_tau, st);
+    switch (gp) {
+        NABO_CBB(8) NABO_CBB(16) NABO_CBB(24) NABO_CBB(32) NABO_CBB(40) NABO_CBB(48) NABO_CBB(56) NABO_CBB(64)
+    default: return hipErrorInvalidValue;
+    }
+#undef NABO_CBB
+}
+
+}  // namespace nabo

@@ -77,6 +77,44 @@ def test_canberra_knn_vs_oracle(gpu_lib, m, n, g, k, drop):
         _check(gi, gd, oi, od)
 
 
+@pytest.mark.parametrize("m,n,g,k,drop,f,masked", [
+    (50, 300, 10, 5, False, 0.25, False),            # one block, mostly padding bits
+    (500, 3000, 30, 11, False, 0.25, True),          # two blocks, ignored references
+    (333, 5000, 50, 15, True, 0.25, False),          # positional drop; 56 padded dimensions = 7 groups (odd: buffer parity flips)
+    (2100, 9000, 50, 20, False, 1.0, False),         # f = 1: wide windows, many survivors; 66 waves of 32 rows
+    (70, 40000, 63, 24, False, 0.1, True),           # the largest g / k' the bit-sliced pass is instantiated for, reference splits
+    (40, 2600, 7, 3, False, 0.25, False),
+    (1500, 70000, 16, 9, False, 0.25, False),        # g = 16: two groups (even)
+])
+def test_canberra_bit_sliced_count_gives_the_same_bits(gpu_lib, m, n, g, k, drop, f, masked):
+    """canberra_bits.hip (the default counting pass from 32k references on; NABO_CANBERRA_MODE=bits forces it at any
+    size): cumulative per-bucket bitmaps, carry-save count, bit-sliced comparator.  Same candidates' certificate, same
+    float64 refine: the oracle's bits -- and the SWAR pass (NABO_CANBERRA_MODE=swar) on the same inputs too."""
+    Y = pca_like(n, g, seed=4100 + n + g)
+    Y[11] = Y[5]                                             # an exact tie
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=4200 + m + g)
+    X[0] = 1e-3 * X[0]                                       # tiny windows: everything far away sits on the plateau (distance g)
+    mask = (np.random.default_rng(n).random(n) < 0.25).astype(np.uint8) if masked else None
+    oi, od = oracle.knn(X, Y, k, 1, f, ref_mask=mask, drop_first=drop, nthreads=8)
+    for mode in ("bits", "swar"):
+        os.environ["NABO_CANBERRA_MODE"] = mode
+        try:
+            ix = gpu_lib.KnnIndex(n, g, metric=1, dist_factor=f).set_ref(Y, ref_mask=mask)
+        finally:
+            os.environ.pop("NABO_CANBERRA_MODE", None)
+        gi, gd = ix.query(X, k, drop_first=drop)
+        kern = ix.last_kernel()
+        if mask is not None and mode == "bits":              # a new ignore list on the resident index: the valid bits follow
+            mask2 = np.roll(mask, 17)
+            ix.set_mask(mask2)
+            g2i, g2d = ix.query(X[:64], k, drop_first=drop)
+            o2i, o2d = oracle.knn(X[:64], Y, k, 1, f, ref_mask=mask2, drop_first=drop, nthreads=8)
+            _check(g2i, g2d, o2i, o2d)
+        ix.close()
+        assert ("cbb_filter" if mode == "bits" else "cbf_filter") in kern, kern
+        _check(gi, gd, oi, od)
+
+
 def test_canberra_exact_ties_follow_canonical_order(gpu_lib):
     """Far-apart pairs all score exactly g: the top-k is tie-filled and must come out in
     ascending index order (the canonical (dist, idx) rule)."""
