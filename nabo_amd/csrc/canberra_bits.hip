@@ -14,19 +14,25 @@
 //   * Index side (once per set_ref): for every block of 2048 references, dimension d and bucket row r the word
 //     tab[block][d][r][w] holds, for the 32 references of word w, the bits "b(y_d) <= r - 1" (row 0 is the empty set):
 //     cumulative bitmaps, 50 x 33 x 64 words per block = 206 bytes per reference.
-//   * Query side: a target's window in dimension d is two row numbers (lo_row = b(lo), hi_row = b(hi) + 1, 16 bits each,
-//     one word per (target, dimension)), and the 32 references of a word that MAY be in the window are
-//         tab[hi_row] & ~tab[lo_row]                      two coalesced 256-byte loads + one vector instruction per 2048 pairs.
-//     The per-reference count over the dimensions is a carry-save adder tree on the bit planes (Harley-Seal: seven 3:2
-//     compressors -- v_bitop3 0x96 / 0xE8 -- per eight dimensions, then a ripple into the 8 / 16 / 32 planes), the
-//     comparison with the row's integer threshold a bit-sliced comparator: ~3.5 vector instructions per dimension and
-//     32 pairs -- 0.11 per pair and dimension against 1.22.
+//   * Query side: a target's window in dimension d is two row numbers (lo_row = b(lo), hi_row = b(hi) + 1), and the 32
+//     references of a word that MAY be in the window are  tab[hi_row] & ~tab[lo_row]  -- two reads and one vector
+//     instruction per 32 pairs; the per-reference count over the dimensions lives in SIX BIT PLANES per target (a
+//     bit-sliced counter: adding a 0/1 plane is a ripple of and / xor pairs), the comparison with the row's integer
+//     threshold is a bit-sliced comparator.  ~14 vector instructions per dimension and 32 pairs: 0.44 per pair and
+//     dimension against 1.22.
+//   * Who shares what.  The table is 206 bytes per reference and every target needs all of it: a wave that streamed it
+//     for its own 16-32 targets (the first version of this file) moved 14 TB per 1M x 1M step through L2 and was no
+//     faster than the SWAR pass (1.88 s vs 1.75 s).  So a WORKGROUP of 8 waves (128 targets) walks the table together:
+//     the 33 rows of ONE dimension of the current block (8.4 KB) are staged in LDS (double-buffered, one barrier per
+//     dimension), every wave reads the two rows each of its 16 targets needs from there (row number wave-uniform, lane =
+//     word: conflict-free) and ripples the mask into that target's counter, which stays in registers for the whole
+//     block (16 targets x 6 planes = 96 VGPRs).  Table traffic: 206 MB per 128 targets = 1.6 TB per step.
 //   * Survivors (7e-3 of the pairs with 32 quantile buckets, simulated on the bench's data; 2.2e-3 for the 128 uniform
 //     buckets of the SWAR pass) leave through the same wave-private work ring, fp32 lower bound, candidate lists and
-//     certificate as before -- results are the reference's bits either way (tests/test_knn_gpu.py: canberra cases run
-//     both kernels).
-// The wave owns T = 32 target rows (lists, row numbers and thresholds in LDS: 8 waves per CU) and streams the blocks of
-// its reference split; what bounds the pass is the vector L1 (two 256-byte loads per 3.5 vector instructions).
+//     certificate as before.  The ring is filled one survivor per lane and round, i.e. NOT in ascending reference
+//     order, so a list accepts a candidate by (key, index) < (tau, index of the last kept entry): the kept set is the
+//     L smallest pairs in that order whatever the arrival order (refine.hip's plateau certificate relies on it).
+//     Results are the reference's bits either way (tests/test_knn_gpu.py: canberra cases run both kernels).
 #include <cstdlib>
 #include <type_traits>
 #include "knn_common.h"
@@ -36,10 +42,11 @@ namespace nabo {
 constexpr int CBB_B = 32;                 // quantile buckets per dimension
 constexpr int CBB_ROWS = CBB_B + 1;       // cumulative rows per dimension (row 0: empty set)
 constexpr int CBB_BLK = 2048;             // references per block: 64 lanes x 32 bits
-constexpr int CBB_T = 32;                 // target rows per wave
+constexpr int CBB_T = 16;                 // target rows per wave (six count planes each, in registers)
+constexpr int CBB_NW = 8;                 // waves per workgroup: they share the LDS copy of the table rows
 
 int cbb_buckets() { return CBB_B; }
-int cbb_rows_per_wg() { return CBB_T; }
+int cbb_rows_per_wg() { return CBB_T * CBB_NW; }
 size_t cbb_table_bytes(int64_t n, int g) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * g * CBB_ROWS * 64 * sizeof(uint32_t); }
 size_t cbb_valid_bytes(int64_t n) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * 64 * sizeof(uint32_t); }
 
@@ -90,7 +97,7 @@ __global__ void cbb_valid_kernel(const uint8_t *__restrict__ mask, int64_t n, in
     vbits[w] = v;
 }
 
-// rowoff[row][k] = (d 33 + b(lo)) | (d 33 + b(hi) + 1) << 16 for the window (lo, hi) of the reference's test widened by
+// rowoff[row][k] = b(lo) | (b(hi) + 1) << 16 (rows of dimension k's cumulative table) for the window (lo, hi) of the reference's test widened by
 // its own float64 roundings (T+ as in canberra_f32.hip: cbf_pack_targets8_kernel); padding dimensions: 0 (empty set)
 __global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
                                         const double *__restrict__ edges, uint32_t *__restrict__ rowoff)
@@ -109,11 +116,12 @@ __global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m,
         blo = cbb_bucket(ed, nextafter(x - tp, -__builtin_inf()));
         bhi = cbb_bucket(ed, nextafter(x + tp, __builtin_inf()));
     }
-    rowoff[e] = (uint32_t)(k * CBB_ROWS + blo) | ((uint32_t)(k * CBB_ROWS + bhi + 1) << 16);
+    rowoff[e] = (uint32_t)blo | ((uint32_t)(bhi + 1) << 16);
 }
 
 template <int EPL>
-__device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count, float (&key)[EPL], uint32_t (&val)[EPL])
+__device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count, float (&key)[EPL], uint32_t (&val)[EPL],
+                                             uint32_t *last_idx = nullptr)
 {
     constexpr int L = 32 * EPL;
     const int lane = lane_id();
@@ -130,46 +138,47 @@ __device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count,
         const int e = r * 64 + lane;
         if (e < L) { kb[e] = key[r]; ib[e] = val[r]; }
     }
+    if (last_idx) *last_idx = (uint32_t)__shfl((int)val[(L - 1) >> 6], (L - 1) & 63, 64);
     return __shfl(key[(L - 1) >> 6], (L - 1) & 63, 64);
 }
 
-// 3:2 compressor on bit planes: (h, l) = a + b + c
-#define CBB_CSA(h, l, a, b, c)                                                        \
-    do {                                                                              \
-        const uint32_t a__ = (a), b__ = (b), c__ = (c);                               \
-        (h) = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0xE8);                       \
-        (l) = __builtin_amdgcn_bitop3_b32(a__, b__, c__, 0x96);                       \
-    } while (0)
-
-// grid.x = ceil(m / T) one-wave workgroups, grid.y = S splits of `blocks_per_split` reference blocks.
+// grid.x = ceil(m / (NW T)) workgroups of NW waves, grid.y = S splits of `blocks_per_split` reference blocks.
 template <int GP, int EPL>
-__global__ __launch_bounds__(64, 2)
+__global__ __launch_bounds__(64 * CBB_NW, 1)
 void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict__ rowoff, int64_t m,
                        const float *__restrict__ yrow, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ vbits,
                        int64_t n, int g, int64_t n_blocks, int64_t blocks_per_split, float slack, float plateau,
                        uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau)
 {
-    constexpr int T = CBB_T;
+    constexpr int T = CBB_T, NW = CBB_NW;
     constexpr int L = 32 * EPL, CAP = L + 16 * EPL;      // kept + pending entries per list
-    constexpr int NG = GP / 8;                           // groups of eight dimensions
     constexpr int WLN = 512;                             // work-list ring (entries)
-    static_assert(GP % 8 == 0 && GP <= 128, "padded dimensionality");
+    constexpr int ROWW = CBB_ROWS * 64;                  // words of one dimension's rows
+    constexpr int WAVE_BYTES = T * GP * 4 + T * CAP * 8 + T * 16 + WLN * 5;
+    static_assert(WAVE_BYTES % 16 == 0, "wave block alignment");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
-    // ro [T][GP] u32 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | cnt [T] i32 | thr [T] u32 | wl [WLN] u32 | wl_t [WLN] u8
-    uint32_t *ro = reinterpret_cast<uint32_t *>(smem_raw);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // shared: rows [2][33][64] u32 (one dimension of the current block, double-buffered)
+    // per wave: ro [T][GP] u32 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
+    //           wl [WLN] u32 | wl_t [WLN] u8
+    uint32_t *rows = reinterpret_cast<uint32_t *>(smem_raw);
+    unsigned char *wb = smem_raw + 2 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
+    uint32_t *ro = reinterpret_cast<uint32_t *>(wb);
     float *keys = reinterpret_cast<float *>(ro + T * GP);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
     float *tau = reinterpret_cast<float *>(idxs + T * CAP);
-    int *cnt = reinterpret_cast<int *>(tau + T);
+    uint32_t *tidx = reinterpret_cast<uint32_t *>(tau + T);
+    int *cnt = reinterpret_cast<int *>(tidx + T);
     uint32_t *thr_l = reinterpret_cast<uint32_t *>(cnt + T);
     uint32_t *wl = thr_l + T;
     unsigned char *wl_t = reinterpret_cast<unsigned char *>(wl + WLN);
 
     const int S = gridDim.y;
     const int split = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * T;
-    if (row0 >= m) return;                                   // (no barriers in this kernel)
+    const int64_t row0 = ((int64_t)blockIdx.x * NW + wave) * T;
+    // (a wave without rows still loads and waits at the barriers with the others)
+    int t_cnt = row0 >= m ? 0 : (row0 + T > m ? (int)(m - row0) : T);
     // Survivor test: n_out = g - inw dimensions are PROVEN out of window, distance >= n_out; a pair is dropped when
     // n_out >= t1 = tau + slack (+2e-5, rounded up), i.e. survivors have inw > g - t1 (canberra_f32.hip: count_threshold).
     auto count_threshold = [&](float tau_t) -> uint32_t {
@@ -178,18 +187,17 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
         const float need = (float)g - t1;
         return need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;
     };
-    for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); cnt[e] = 0; thr_l[e] = 0u; }
+    for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); tidx[e] = 0xFFFFFFFFu; cnt[e] = 0; thr_l[e] = 0u; }
     for (int e = lane; e < T * GP; e += 64) {
         const int64_t row = row0 + e / GP;
         ro[e] = row < m ? rowoff[row * GP + e % GP] : 0u;
     }
     const float below_plateau = __uint_as_float(__float_as_uint(plateau) - 1u);
-    int t_cnt = T;
-    if (row0 + T > m) t_cnt = (int)(m - row0);
     int wl_head = 0, wl_n = 0;                               // wave-uniform ring state
 
     // fp32 lower bound of `nb` (<= 64) work-list pairs, one per lane, then list insertion (canberra_f32.hip: drain);
-    // the target's packed (x, thr) row comes from global memory here (rare: 7e-3 of the pairs)
+    // the target's packed (x, thr) row comes from global memory here (rare: 7e-3 of the pairs).  A list accepts
+    // (key, j) < (tau, tidx) lexicographically: arrival order does not matter (header).
     auto drain = [&](int nb) {
         const bool act = lane < nb;
         const int slot = (wl_head + lane) & (WLN - 1);
@@ -221,7 +229,8 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
             }
         }
         const float key = (no_p == g) ? plateau : fminf(lb - slack, below_plateau);
-        const bool hit = act && (key < tau[t_p]);
+        auto below = [&](float tk, uint32_t ti) { return key < tk || (key == tk && j < ti); };
+        const bool hit = act && below(tau[t_p], tidx[t_p]);
         if (__builtin_amdgcn_ballot_w64(hit) == 0) return;
         for (int t2 = 0; t2 < t_cnt; ++t2) {
             bool pend = hit && (t_p == t2);
@@ -232,9 +241,10 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
                 if (room == 0) {
                     float kr[EPL];
                     uint32_t vr[EPL];
-                    const float nt = cbb_compact<EPL>(keys + t2 * CAP, idxs + t2 * CAP, c, kr, vr);
-                    if (lane == 0) { tau[t2] = nt; cnt[t2] = L; thr_l[t2] = count_threshold(nt); }
-                    pend = pend && (key < nt);
+                    uint32_t li = 0xFFFFFFFFu;
+                    const float nt = cbb_compact<EPL>(keys + t2 * CAP, idxs + t2 * CAP, c, kr, vr, &li);
+                    if (lane == 0) { tau[t2] = nt; tidx[t2] = li; cnt[t2] = L; thr_l[t2] = count_threshold(nt); }
+                    pend = pend && below(nt, li);
                 } else {
                     const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
@@ -255,58 +265,73 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     const int64_t b_begin = split * blocks_per_split;
     int64_t b_end = b_begin + blocks_per_split;
     if (b_end > n_blocks) b_end = n_blocks;
+    // the rows of dimension d of block blk, staged by the whole workgroup: ROWW / 4 sixteen-byte pieces
+    constexpr int PIECES = ROWW / 4;                         // 528: one piece per thread and 16 left over
+    static_assert(PIECES > 64 * NW && PIECES <= 2 * 64 * NW, "two pieces per thread at most");
+    uint4 stage0 = make_uint4(0u, 0u, 0u, 0u), stage1 = stage0;
+    const int tid = (int)threadIdx.x;
+    auto fetch = [&](int64_t blk, int d) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab + ((size_t)blk * g + d) * ROWW);
+        stage0 = src[tid];
+        if (tid < PIECES - 64 * NW) stage1 = src[tid + 64 * NW];
+    };
+    auto commit = [&](int buf) {
+        uint4 *dst = reinterpret_cast<uint4 *>(rows + buf * ROWW);
+        dst[tid] = stage0;
+        if (tid < PIECES - 64 * NW) dst[tid + 64 * NW] = stage1;
+    };
+    if (b_begin < b_end) {
+        fetch(b_begin, 0);
+        commit(0);
+    }
+    __syncthreads();
+    int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
-        const uint32_t *tb = tab + (size_t)blk * g * CBB_ROWS * 64 + lane;          // this lane's word of every row
         const uint32_t vmask = vbits[blk * 64 + lane];
-        // window masks of eight dimensions of target t: two loads per dimension, row numbers wave-uniform
-        uint32_t hv[2][8], lv[2][8];
-        auto load_group = [&](int t, int grp, uint32_t (&h)[8], uint32_t (&l)[8]) {
+        uint32_t pl[T][6];                                   // bit-sliced counters: pl[t][b] = bit b of the 32 counts
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ro[t * GP + grp * 8 + i]);
-                h[i] = tb[(size_t)(r >> 16) * 64];
-                l[i] = tb[(size_t)(r & 0xFFFFu) * 64];
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) pl[t][b] = 0u;
+        for (int d = 0; d < g; ++d) {
+            // the next dimension's rows (the next block's first behind the last) travel while this one is counted
+            const bool more = d + 1 < g || blk + 1 < b_end;
+            if (more) fetch(d + 1 < g ? blk : blk + 1, d + 1 < g ? d + 1 : 0);
+            const uint32_t *rb = rows + buf * ROWW + lane;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ro[t * GP + d]);
+                uint32_t c = rb[(r >> 16) * 64] & ~rb[(r & 0xFFFFu) * 64];
+#pragma unroll
+                for (int b = 0; b < 6; ++b) {                // ripple the 0/1 plane into the counter
+                    const uint32_t carry = pl[t][b] & c;
+                    pl[t][b] ^= c;
+                    c = carry;
+                }
             }
-        };
-        // One target against the block.  P = which of the two register sets holds its first group (the sets alternate
-        // group by group; with an odd number of groups the parity flips from target to target).
-        auto target = [&](auto par, int t) {
-            constexpr int P = decltype(par)::value;
-            uint32_t ones = 0u, twos = 0u, fours = 0u, eights = 0u, sixteens = 0u, thirtytwos = 0u;
-#pragma unroll
-            for (int grp = 0; grp < NG; ++grp) {
-                // the next group's loads (the next target's first group behind the last one) fly while this one is counted
-                constexpr int PN = (P + NG) & 1;
-                const int cur = (P + grp) & 1;
-                if (grp + 1 < NG) load_group(t, grp + 1, hv[cur ^ 1], lv[cur ^ 1]);
-                else if (t + 1 < t_cnt) load_group(t + 1, 0, hv[PN], lv[PN]);
-                uint32_t mk[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) mk[i] = hv[cur][i] & ~lv[cur][i];
-                uint32_t tA, tB, fA, fB, e8;
-                CBB_CSA(tA, ones, ones, mk[0], mk[1]);
-                CBB_CSA(tB, ones, ones, mk[2], mk[3]);
-                CBB_CSA(fA, twos, twos, tA, tB);
-                CBB_CSA(tA, ones, ones, mk[4], mk[5]);
-                CBB_CSA(tB, ones, ones, mk[6], mk[7]);
-                CBB_CSA(fB, twos, twos, tA, tB);
-                CBB_CSA(e8, fours, fours, fA, fB);
-                const uint32_t c16 = eights & e8;
-                eights ^= e8;
-                const uint32_t c32 = sixteens & c16;
-                sixteens ^= c16;
-                thirtytwos ^= c32;
-            }
-            // inw >= thr ?  bit-sliced, the threshold is wave-uniform (padding dimensions count nothing)
+            if (more) commit(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // inw >= thr ?  bit-sliced comparator per target, then the survivors into the ring
+#pragma unroll 1
+        for (int t = 0; t < t_cnt; ++t) {
             const uint32_t thr_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_l[t]);
+            uint32_t p[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {                    // (t is a run-time index here: select the target's planes)
+                uint32_t v = pl[0][b];
+#pragma unroll
+                for (int tt = 1; tt < T; ++tt) v = (t == tt) ? pl[tt][b] : v;
+                p[b] = v;
+            }
             uint32_t ge = 0u;
             if (thr_in < 64u) {
-                const uint32_t pl[6] = {ones, twos, fours, eights, sixteens, thirtytwos};
                 uint32_t gt = 0u, eq = 0xFFFFFFFFu;
 #pragma unroll
                 for (int b = 5; b >= 0; --b) {
-                    if ((thr_in >> b) & 1u) eq &= pl[b];
-                    else { gt |= eq & pl[b]; eq &= ~pl[b]; }
+                    if ((thr_in >> b) & 1u) eq &= p[b];
+                    else { gt |= eq & p[b]; eq &= ~p[b]; }
                 }
                 ge = (gt | eq) & vmask;
             }
@@ -325,15 +350,6 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
                 while (wl_n >= 64) drain(64);
                 anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
             }
-        };
-        load_group(0, 0, hv[0], lv[0]);
-        if (NG & 1) {
-            for (int t = 0; t < t_cnt; t += 2) {
-                target(std::integral_constant<int, 0>{}, t);
-                if (t + 1 < t_cnt) target(std::integral_constant<int, 1>{}, t + 1);
-            }
-        } else {
-            for (int t = 0; t < t_cnt; ++t) target(std::integral_constant<int, 0>{}, t);
         }
     }
     while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);
@@ -391,11 +407,12 @@ static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_
     const int64_t bps = (n_blocks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)CBB_T * GP * 4 + (size_t)CBB_T * CAP * 8 + (size_t)CBB_T * 12 + 512 * 5 + 16;
+    const size_t lds = (size_t)2 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 4 + CBB_T * CAP * 8 + CBB_T * 16 + 512 * 5);
     auto kern = &cbb_filter_kernel<GP, EPL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid((unsigned)((m + CBB_T - 1) / CBB_T), S), block(64);
+    const int rpw = CBB_T * CBB_NW;
+    dim3 grid((unsigned)((m + rpw - 1) / rpw), S), block(64 * CBB_NW);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const float2 *>(xq), rowoff, m, yrow, tab, vbits, n, g,
                        n_blocks, bps, slack, plateau, cand_idx, cand_tau);
     return hipGetLastError();
