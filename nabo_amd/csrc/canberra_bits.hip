@@ -25,8 +25,9 @@
 //     faster than the SWAR pass (1.88 s vs 1.75 s).  So a WORKGROUP of 8 waves (128 targets) walks the table together:
 //     the 33 rows of ONE dimension of the current block (8.4 KB) are staged in LDS (double-buffered, one barrier per
 //     dimension), every wave reads the two rows each of its 16 targets needs from there (row number wave-uniform, lane =
-//     word: conflict-free) and ripples the mask into that target's counter, which stays in registers for the whole
-//     block (16 targets x 6 planes = 96 VGPRs).  Table traffic: 206 MB per 128 targets = 1.6 TB per step.
+//     word: conflict-free) and adds the masks to that target's counter, which stays in registers for the whole block
+//     (16 targets x 6 planes = 96 VGPRs); two dimensions per step: one 3:2 compressor (v_bitop3 0x96 / 0xE8) takes both
+//     masks into the lowest plane, one carry ripples upwards.  Table traffic: 206 MB per 128 targets = 1.6 TB per step.
 //   * Survivors (7e-3 of the pairs with 32 quantile buckets, simulated on the bench's data; 2.2e-3 for the 128 uniform
 //     buckets of the SWAR pass) leave through the same wave-private work ring, fp32 lower bound, candidate lists and
 //     certificate as before.  The ring is filled one survivor per lane and round, i.e. NOT in ascending reference
@@ -47,7 +48,11 @@ constexpr int CBB_NW = 8;                 // waves per workgroup: they share the
 
 int cbb_buckets() { return CBB_B; }
 int cbb_rows_per_wg() { return CBB_T * CBB_NW; }
-size_t cbb_table_bytes(int64_t n, int g) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * g * CBB_ROWS * 64 * sizeof(uint32_t); }
+size_t cbb_table_bytes(int64_t n, int g)
+{
+    // (+ one dimension of slack: with an odd g the kernel stages dimension g of the last block -- never used)
+    return ((size_t)((n + CBB_BLK - 1) / CBB_BLK) * g + 1) * CBB_ROWS * 64 * sizeof(uint32_t);
+}
 size_t cbb_valid_bytes(int64_t n) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * 64 * sizeof(uint32_t); }
 
 // b(v) = number of edges <= v, edges ascending [CBB_B - 1]
@@ -97,7 +102,7 @@ __global__ void cbb_valid_kernel(const uint8_t *__restrict__ mask, int64_t n, in
     vbits[w] = v;
 }
 
-// rowoff[row][k] = b(lo) | (b(hi) + 1) << 16 (rows of dimension k's cumulative table) for the window (lo, hi) of the reference's test widened by
+// rowoff[row][k] = 256 b(lo) | 256 (b(hi) + 1) << 16 (BYTE offsets of the two rows in dimension k's cumulative table) for the window (lo, hi) of the reference's test widened by
 // its own float64 roundings (T+ as in canberra_f32.hip: cbf_pack_targets8_kernel); padding dimensions: 0 (empty set)
 __global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
                                         const double *__restrict__ edges, uint32_t *__restrict__ rowoff)
@@ -116,7 +121,7 @@ __global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m,
         blo = cbb_bucket(ed, nextafter(x - tp, -__builtin_inf()));
         bhi = cbb_bucket(ed, nextafter(x + tp, __builtin_inf()));
     }
-    rowoff[e] = (uint32_t)blo | ((uint32_t)(bhi + 1) << 16);
+    rowoff[e] = ((uint32_t)blo * 256u) | (((uint32_t)(bhi + 1) * 256u) << 16);
 }
 
 template <int EPL>
@@ -159,11 +164,11 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // shared: rows [2][33][64] u32 (one dimension of the current block, double-buffered)
+    // shared: rows [2][2][33][64] u32 (a pair of dimensions of the current block, double-buffered)
     // per wave: ro [T][GP] u32 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
     //           wl [WLN] u32 | wl_t [WLN] u8
     uint32_t *rows = reinterpret_cast<uint32_t *>(smem_raw);
-    unsigned char *wb = smem_raw + 2 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
+    unsigned char *wb = smem_raw + 4 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
     uint32_t *ro = reinterpret_cast<uint32_t *>(wb);
     float *keys = reinterpret_cast<float *>(ro + T * GP);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
@@ -265,20 +270,27 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     const int64_t b_begin = split * blocks_per_split;
     int64_t b_end = b_begin + blocks_per_split;
     if (b_end > n_blocks) b_end = n_blocks;
-    // the rows of dimension d of block blk, staged by the whole workgroup: ROWW / 4 sixteen-byte pieces
-    constexpr int PIECES = ROWW / 4;                         // 528: one piece per thread and 16 left over
-    static_assert(PIECES > 64 * NW && PIECES <= 2 * 64 * NW, "two pieces per thread at most");
-    uint4 stage0 = make_uint4(0u, 0u, 0u, 0u), stage1 = stage0;
+    // The rows of dimensions 2 dp, 2 dp + 1 of block blk (a PAIR of dimensions per step: one barrier and one carry-save
+    // step serve both), staged by the whole workgroup: 2 x 528 sixteen-byte pieces.  g odd: the last pair's second half
+    // is the first dimension again with every target's rows (0, 0) -- see below.
+    constexpr int PIECES = ROWW / 4;                         // 528 per dimension
+    static_assert(2 * PIECES > 2 * 64 * NW && 2 * PIECES <= 3 * 64 * NW, "three pieces per thread at most");
+    uint4 stage0 = make_uint4(0u, 0u, 0u, 0u), stage1 = stage0, stage2 = stage0;
     const int tid = (int)threadIdx.x;
-    auto fetch = [&](int64_t blk, int d) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(tab + ((size_t)blk * g + d) * ROWW);
+    const int npair = (g + 1) / 2;
+    auto fetch = [&](int64_t blk, int dp) {
+        // (both dimensions of a pair are contiguous in the table; an odd g reads one dimension past the block's last --
+        // the next block's first, or the table's padding dimension behind the very last block)
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab + ((size_t)blk * g + 2 * dp) * ROWW);
         stage0 = src[tid];
-        if (tid < PIECES - 64 * NW) stage1 = src[tid + 64 * NW];
+        stage1 = src[tid + 64 * NW];
+        if (tid < 2 * PIECES - 2 * 64 * NW) stage2 = src[tid + 2 * 64 * NW];
     };
     auto commit = [&](int buf) {
-        uint4 *dst = reinterpret_cast<uint4 *>(rows + buf * ROWW);
+        uint4 *dst = reinterpret_cast<uint4 *>(rows + buf * 2 * ROWW);
         dst[tid] = stage0;
-        if (tid < PIECES - 64 * NW) dst[tid + 64 * NW] = stage1;
+        dst[tid + 64 * NW] = stage1;
+        if (tid < 2 * PIECES - 2 * 64 * NW) dst[tid + 2 * 64 * NW] = stage2;
     };
     if (b_begin < b_end) {
         fetch(b_begin, 0);
@@ -293,17 +305,26 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int b = 0; b < 6; ++b) pl[t][b] = 0u;
-        for (int d = 0; d < g; ++d) {
-            // the next dimension's rows (the next block's first behind the last) travel while this one is counted
-            const bool more = d + 1 < g || blk + 1 < b_end;
-            if (more) fetch(d + 1 < g ? blk : blk + 1, d + 1 < g ? d + 1 : 0);
-            const uint32_t *rb = rows + buf * ROWW + lane;
+        for (int dp = 0; dp < npair; ++dp) {
+            // the next pair's rows (the next block's first behind the last) travel while this one is counted
+            const bool more = dp + 1 < npair || blk + 1 < b_end;
+            if (more) fetch(dp + 1 < npair ? blk : blk + 1, dp + 1 < npair ? dp + 1 : 0);
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + buf * 2 * ROWW + lane);
+            const bool second = 2 * dp + 1 < g;              // (wave-uniform)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ro[t * GP + d]);
-                uint32_t c = rb[(r >> 16) * 64] & ~rb[(r & 0xFFFFu) * 64];
+                const uint2 r2 = *reinterpret_cast<const uint2 *>(ro + t * GP + 2 * dp);       // two dimensions' row offsets
+                const uint32_t ra = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.x);
+                const uint32_t rc = second ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.y) : 0u;
+                const uint32_t m0 = *reinterpret_cast<const uint32_t *>(rb + (ra >> 16)) &
+                                    ~*reinterpret_cast<const uint32_t *>(rb + (ra & 0xFFFFu));
+                const uint32_t m1 = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc >> 16)) &
+                                    ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc & 0xFFFFu));
+                // carry-save: (carry, ones) = ones + m0 + m1, then the carry ripples through the planes above
+                uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0, m1, 0xE8);
+                pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0, m1, 0x96);
 #pragma unroll
-                for (int b = 0; b < 6; ++b) {                // ripple the 0/1 plane into the counter
+                for (int b = 1; b < 6; ++b) {
                     const uint32_t carry = pl[t][b] & c;
                     pl[t][b] ^= c;
                     c = carry;
@@ -407,7 +428,7 @@ static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_
     const int64_t bps = (n_blocks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)2 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 4 + CBB_T * CAP * 8 + CBB_T * 16 + 512 * 5);
+    const size_t lds = (size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 4 + CBB_T * CAP * 8 + CBB_T * 16 + 512 * 5);
     auto kern = &cbb_filter_kernel<GP, EPL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
