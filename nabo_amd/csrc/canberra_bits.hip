@@ -40,7 +40,10 @@
 
 namespace nabo {
 
-constexpr int CBB_B = 32;                 // quantile buckets per dimension
+#ifndef NABO_CBB_B
+#define NABO_CBB_B 64
+#endif
+constexpr int CBB_B = NABO_CBB_B;         // quantile buckets per dimension (survivors of the count: 7e-3 of the pairs at 32, 2.6e-3 at 64)
 constexpr int CBB_ROWS = CBB_B + 1;       // cumulative rows per dimension (row 0: empty set)
 constexpr int CBB_BLK = 2048;             // references per block: 64 lanes x 32 bits
 constexpr int CBB_T = 16;                 // target rows per wave (six count planes each, in registers)
@@ -164,11 +167,11 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // shared: rows [2][2][33][64] u32 (a pair of dimensions of the current block, double-buffered)
+    // shared: rows [2][CBB_ROWS][64] u32 (a pair of dimensions of the current block)
     // per wave: ro [T][GP] u32 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
     //           wl [WLN] u32 | wl_t [WLN] u8
     uint32_t *rows = reinterpret_cast<uint32_t *>(smem_raw);
-    unsigned char *wb = smem_raw + 4 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
+    unsigned char *wb = smem_raw + 2 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
     uint32_t *ro = reinterpret_cast<uint32_t *>(wb);
     float *keys = reinterpret_cast<float *>(ro + T * GP);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
@@ -270,34 +273,44 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     const int64_t b_begin = split * blocks_per_split;
     int64_t b_end = b_begin + blocks_per_split;
     if (b_end > n_blocks) b_end = n_blocks;
-    // The rows of dimensions 2 dp, 2 dp + 1 of block blk (a PAIR of dimensions per step: one barrier and one carry-save
-    // step serve both), staged by the whole workgroup: 2 x 528 sixteen-byte pieces.  g odd: the last pair's second half
-    // is the first dimension again with every target's rows (0, 0) -- see below.
-    constexpr int PIECES = ROWW / 4;                         // 528 per dimension
-    static_assert(2 * PIECES > 2 * 64 * NW && 2 * PIECES <= 3 * 64 * NW, "three pieces per thread at most");
-    uint4 stage0 = make_uint4(0u, 0u, 0u, 0u), stage1 = stage0, stage2 = stage0;
+    // The rows of dimensions 2 dp, 2 dp + 1 of block blk (a PAIR of dimensions per step: one carry-save step serves
+    // both), staged by the whole workgroup through registers into ONE LDS buffer: the next pair is fetched before this
+    // one is counted, written behind a barrier when everybody has finished reading, and a second barrier publishes it.
+    // g odd: the last pair's second half is whatever follows in the table, with every target's rows (0, 0).
+    constexpr int PIECES = 2 * ROWW / 4;                     // sixteen-byte pieces of a pair
+    constexpr int NST = (PIECES + 64 * NW - 1) / (64 * NW);  // per thread
+    static_assert(NST <= 6, "staging registers");
+    uint4 st0, st1, st2, st3, st4, st5;                      // (scalars, not an array: an array captured by the lambdas went to scratch)
+    st0 = st1 = st2 = st3 = st4 = st5 = make_uint4(0u, 0u, 0u, 0u);
     const int tid = (int)threadIdx.x;
     const int npair = (g + 1) / 2;
     auto fetch = [&](int64_t blk, int dp) {
         // (both dimensions of a pair are contiguous in the table; an odd g reads one dimension past the block's last --
-        // the next block's first, or the table's padding dimension behind the very last block)
+        // the next block's first, or the table's slack dimension behind the very last block)
         const uint4 *src = reinterpret_cast<const uint4 *>(tab + ((size_t)blk * g + 2 * dp) * ROWW);
-        stage0 = src[tid];
-        stage1 = src[tid + 64 * NW];
-        if (tid < 2 * PIECES - 2 * 64 * NW) stage2 = src[tid + 2 * 64 * NW];
+        auto ld = [&](int i) { const int pc = tid + i * 64 * NW; return src[pc < PIECES ? pc : PIECES - 1]; };
+        st0 = ld(0);
+        if constexpr (NST > 1) st1 = ld(1);
+        if constexpr (NST > 2) st2 = ld(2);
+        if constexpr (NST > 3) st3 = ld(3);
+        if constexpr (NST > 4) st4 = ld(4);
+        if constexpr (NST > 5) st5 = ld(5);
     };
-    auto commit = [&](int buf) {
-        uint4 *dst = reinterpret_cast<uint4 *>(rows + buf * 2 * ROWW);
-        dst[tid] = stage0;
-        dst[tid + 64 * NW] = stage1;
-        if (tid < 2 * PIECES - 2 * 64 * NW) dst[tid + 2 * 64 * NW] = stage2;
+    auto commit = [&]() {
+        uint4 *dst = reinterpret_cast<uint4 *>(rows);
+        auto wr = [&](int i, const uint4 &v) { const int pc = tid + i * 64 * NW; if (pc < PIECES) dst[pc] = v; };
+        wr(0, st0);
+        if constexpr (NST > 1) wr(1, st1);
+        if constexpr (NST > 2) wr(2, st2);
+        if constexpr (NST > 3) wr(3, st3);
+        if constexpr (NST > 4) wr(4, st4);
+        if constexpr (NST > 5) wr(5, st5);
     };
     if (b_begin < b_end) {
         fetch(b_begin, 0);
-        commit(0);
+        commit();
     }
     __syncthreads();
-    int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
         const uint32_t vmask = vbits[blk * 64 + lane];
         uint32_t pl[T][6];                                   // bit-sliced counters: pl[t][b] = bit b of the 32 counts
@@ -309,7 +322,7 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
             // the next pair's rows (the next block's first behind the last) travel while this one is counted
             const bool more = dp + 1 < npair || blk + 1 < b_end;
             if (more) fetch(dp + 1 < npair ? blk : blk + 1, dp + 1 < npair ? dp + 1 : 0);
-            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + buf * 2 * ROWW + lane);
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + lane);
             const bool second = 2 * dp + 1 < g;              // (wave-uniform)
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -330,9 +343,9 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
                     c = carry;
                 }
             }
-            if (more) commit(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+            __syncthreads();                                 // everybody has read this pair
+            if (more) commit();
+            __syncthreads();                                 // the next pair is in place
         }
         // inw >= thr ?  bit-sliced comparator per target, then the survivors into the ring
 #pragma unroll 1
@@ -428,7 +441,7 @@ static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_
     const int64_t bps = (n_blocks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 4 + CBB_T * CAP * 8 + CBB_T * 16 + 512 * 5);
+    const size_t lds = (size_t)2 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 4 + CBB_T * CAP * 8 + CBB_T * 16 + 512 * 5);
     auto kern = &cbb_filter_kernel<GP, EPL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
