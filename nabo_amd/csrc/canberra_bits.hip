@@ -323,24 +323,35 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
             const bool more = dp + 1 < npair || blk + 1 < b_end;
             if (more) fetch(dp + 1 < npair ? blk : blk + 1, dp + 1 < npair ? dp + 1 : 0);
             const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + lane);
-            const bool second = 2 * dp + 1 < g;              // (wave-uniform)
+            // ONE LDS read hands the pair's row offsets of all T targets to the wave (lane t holds target t's two words;
+            // v_readlane then makes them scalars) -- a read + wait per target made the step a chain of LDS latencies
+            const uint2 myro = *reinterpret_cast<const uint2 *>(ro + (lane & (T - 1)) * GP + 2 * dp);
+            // (an odd g: the second word of the last pair is a padding dimension's (0, 0): the mask is x & ~x = 0)
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const uint2 r2 = *reinterpret_cast<const uint2 *>(ro + t * GP + 2 * dp);       // two dimensions' row offsets
-                const uint32_t ra = (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.x);
-                const uint32_t rc = second ? (uint32_t)__builtin_amdgcn_readfirstlane((int)r2.y) : 0u;
-                const uint32_t m0 = *reinterpret_cast<const uint32_t *>(rb + (ra >> 16)) &
-                                    ~*reinterpret_cast<const uint32_t *>(rb + (ra & 0xFFFFu));
-                const uint32_t m1 = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc >> 16)) &
-                                    ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc & 0xFFFFu));
-                // carry-save: (carry, ones) = ones + m0 + m1, then the carry ripples through the planes above
-                uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0, m1, 0xE8);
-                pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0, m1, 0x96);
+            for (int half = 0; half < 2; ++half) {
+                uint32_t m0[T / 2], m1[T / 2];
 #pragma unroll
-                for (int b = 1; b < 6; ++b) {
-                    const uint32_t carry = pl[t][b] & c;
-                    pl[t][b] ^= c;
-                    c = carry;
+                for (int i = 0; i < T / 2; ++i) {                // all the row reads of eight targets fly together
+                    const int t = half * (T / 2) + i;
+                    const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)myro.x, t);
+                    const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)myro.y, t);
+                    m0[i] = *reinterpret_cast<const uint32_t *>(rb + (ra >> 16)) &
+                            ~*reinterpret_cast<const uint32_t *>(rb + (ra & 0xFFFFu));
+                    m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc >> 16)) &
+                            ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc & 0xFFFFu));
+                }
+#pragma unroll
+                for (int i = 0; i < T / 2; ++i) {
+                    const int t = half * (T / 2) + i;
+                    // carry-save: (carry, ones) = ones + m0 + m1, then the carry ripples through the planes above
+                    uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0xE8);
+                    pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0x96);
+#pragma unroll
+                    for (int b = 1; b < 6; ++b) {
+                        const uint32_t carry = pl[t][b] & c;
+                        pl[t][b] ^= c;
+                        c = carry;
+                    }
                 }
             }
             __syncthreads();                                 // everybody has read this pair
