@@ -108,9 +108,9 @@ size_t cbb_table_bytes(int64_t n, int g);
 size_t cbb_valid_bytes(int64_t n);
 hipError_t cbb_pack_table_launch(const double *Y, int64_t n, int g, const double *edges, uint32_t *tab, hipStream_t st);
 hipError_t cbb_valid_launch(const uint8_t *mask, int64_t n, uint32_t *vbits, hipStream_t st);
-hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, const double *edges, uint32_t *rowoff,
+hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, const double *edges, uint16_t *rowoff,
                                    hipStream_t st);
-hipError_t cbb_filter_launch(int gp, const float *xq, const uint32_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
+hipError_t cbb_filter_launch(int gp, const float *xq, const uint16_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
                              const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st);
 hipError_t gather_rows_launch(const double *X, const uint32_t *rows, int64_t nrows, int g, double *out, hipStream_t st);
 hipError_t iota_launch(uint32_t *out, int64_t n, hipStream_t st);
@@ -998,7 +998,9 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const int lists = nabo::cbf_lists_per_split();
             const int rpw = bits ? nabo::cbb_rows_per_wg() : nabo::cbf_rows_per_wg(epl);
             const int64_t gxf = (m + rpw - 1) / rpw;
-            const int64_t slots = (int64_t)ix->n_cu * 8;                 // one-wave workgroups, 2 per SIMD
+            // resident workgroups: SWAR pass -- one-wave workgroups, 2 per SIMD; bitmap pass -- ONE 8-wave workgroup per CU
+            // (its LDS copy of the table rows + eight waves' lists fill the CU's LDS)
+            const int64_t slots = bits ? (int64_t)ix->n_cu : (int64_t)ix->n_cu * 8;
             int Sf = env_int("NABO_SPLITS", 0);
             int s_max = 1024 / (lists * L);                   // refine handles <= 1024 candidates per row
             if (bits) {                                       // splits are ranges of 2048-reference blocks, >= 2 each
@@ -1055,15 +1057,15 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             unsigned int *d_failcnt = ix->cbflag.as<unsigned int>() + 1, *d_flag = ix->cbflag.as<unsigned int>();
             HIP_TRY(nabo::cbf_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->xpk.as<float>(), d_flag, st));
             if (bits) {
-                if ((rc = ix->cbrow.reserve((size_t)m * ix->cb_gp * sizeof(uint32_t)))) return rc;
-                HIP_TRY(nabo::cbb_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbedges.as<double>(), ix->cbrow.as<uint32_t>(), st));
+                if ((rc = ix->cbrow.reserve((size_t)m * ix->cb_gp * sizeof(uint16_t)))) return rc;
+                HIP_TRY(nabo::cbb_pack_targets_launch(dX, m, g, ix->cb_gp, ix->f, ix->cbedges.as<double>(), ix->cbrow.as<uint16_t>(), st));
                 HIP_TRY(hipEventRecord(ix->ev[1], st));
-                HIP_TRY(nabo::cbb_filter_launch(ix->cb_gp, ix->xpk.as<float>(), ix->cbrow.as<uint32_t>(), rows_main,
+                HIP_TRY(nabo::cbb_filter_launch(ix->cb_gp, ix->xpk.as<float>(), ix->cbrow.as<uint16_t>(), rows_main,
                                                 ix->yrow.as<float>(), ix->cbtab.as<uint32_t>(), ix->cbvalid.as<uint32_t>(), ix->n, g,
                                                 Sf, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), st));
                 if (rows_tail > 0)
                     HIP_TRY(nabo::cbb_filter_launch(ix->cb_gp, ix->xpk.as<float>() + (size_t)rows_main * ix->cb_gp * 2,
-                                                    ix->cbrow.as<uint32_t>() + (size_t)rows_main * ix->cb_gp, rows_tail,
+                                                    ix->cbrow.as<uint16_t>() + (size_t)rows_main * ix->cb_gp, rows_tail,
                                                     ix->yrow.as<float>(), ix->cbtab.as<uint32_t>(), ix->cbvalid.as<uint32_t>(),
                                                     ix->n, g, S2, ix->cand_idx2.as<uint32_t>(), ix->cand_tau2.as<float>(), st));
             } else {

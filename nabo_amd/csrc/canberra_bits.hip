@@ -105,16 +105,16 @@ __global__ void cbb_valid_kernel(const uint8_t *__restrict__ mask, int64_t n, in
     vbits[w] = v;
 }
 
-// rowoff[row][k] = 256 b(lo) | 256 (b(hi) + 1) << 16 (BYTE offsets of the two rows in dimension k's cumulative table) for the window (lo, hi) of the reference's test widened by
+// rowoff[row][k] = b(lo) | (b(hi) + 1) << 8 (the two rows of dimension k's cumulative table, a byte each) for the window (lo, hi) of the reference's test widened by
 // its own float64 roundings (T+ as in canberra_f32.hip: cbf_pack_targets8_kernel); padding dimensions: 0 (empty set)
 __global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m, int g, int gp, double f,
-                                        const double *__restrict__ edges, uint32_t *__restrict__ rowoff)
+                                        const double *__restrict__ edges, uint16_t *__restrict__ rowoff)
 {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= m * gp) return;
     const int64_t row = e / gp;
     const int k = (int)(e - row * gp);
-    if (k >= g) { rowoff[e] = 0u; return; }
+    if (k >= g) { rowoff[e] = 0; return; }
     const double x = X[row * g + k];
     const double tp = (f * fabs(x)) * (1.0 + 2.3e-16) * (1.0 + 1e-12);             // T+ >= the reference's fl64(f |x|), padded
     int blo = 0, bhi = CBB_B - 1;                                                   // "cannot tell": every bucket
@@ -124,7 +124,7 @@ __global__ void cbb_pack_targets_kernel(const double *__restrict__ X, int64_t m,
         blo = cbb_bucket(ed, nextafter(x - tp, -__builtin_inf()));
         bhi = cbb_bucket(ed, nextafter(x + tp, __builtin_inf()));
     }
-    rowoff[e] = ((uint32_t)blo * 256u) | (((uint32_t)(bhi + 1) * 256u) << 16);
+    rowoff[e] = (uint16_t)((uint32_t)blo | ((uint32_t)(bhi + 1) << 8));
 }
 
 template <int EPL>
@@ -153,26 +153,26 @@ __device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count,
 // grid.x = ceil(m / (NW T)) workgroups of NW waves, grid.y = S splits of `blocks_per_split` reference blocks.
 template <int GP, int EPL>
 __global__ __launch_bounds__(64 * CBB_NW, 1)
-void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict__ rowoff, int64_t m,
+void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict__ rowoff, int64_t m,
                        const float *__restrict__ yrow, const uint32_t *__restrict__ tab, const uint32_t *__restrict__ vbits,
                        int64_t n, int g, int64_t n_blocks, int64_t blocks_per_split, float slack, float plateau,
                        uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau)
 {
     constexpr int T = CBB_T, NW = CBB_NW;
     constexpr int L = 32 * EPL, CAP = L + 16 * EPL;      // kept + pending entries per list
-    constexpr int WLN = 512;                             // work-list ring (entries)
+    constexpr int WLN = 256;                             // work-list ring (entries; <= 63 pending + 64 new)
     constexpr int ROWW = CBB_ROWS * 64;                  // words of one dimension's rows
-    constexpr int WAVE_BYTES = T * GP * 4 + T * CAP * 8 + T * 16 + WLN * 5;
+    constexpr int WAVE_BYTES = T * GP * 2 + T * CAP * 8 + T * 16 + WLN * 5;
     static_assert(WAVE_BYTES % 16 == 0, "wave block alignment");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // shared: rows [2][CBB_ROWS][64] u32 (a pair of dimensions of the current block)
-    // per wave: ro [T][GP] u32 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
+    // shared: rows [2][2][CBB_ROWS][64] u32 (a pair of dimensions of the current block, double-buffered)
+    // per wave: ro [T][GP] u16 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
     //           wl [WLN] u32 | wl_t [WLN] u8
     uint32_t *rows = reinterpret_cast<uint32_t *>(smem_raw);
-    unsigned char *wb = smem_raw + 2 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
-    uint32_t *ro = reinterpret_cast<uint32_t *>(wb);
+    unsigned char *wb = smem_raw + 4 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
+    uint16_t *ro = reinterpret_cast<uint16_t *>(wb);
     float *keys = reinterpret_cast<float *>(ro + T * GP);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
     float *tau = reinterpret_cast<float *>(idxs + T * CAP);
@@ -198,7 +198,7 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); tidx[e] = 0xFFFFFFFFu; cnt[e] = 0; thr_l[e] = 0u; }
     for (int e = lane; e < T * GP; e += 64) {
         const int64_t row = row0 + e / GP;
-        ro[e] = row < m ? rowoff[row * GP + e % GP] : 0u;
+        ro[e] = row < m ? rowoff[row * GP + e % GP] : (uint16_t)0;
     }
     const float below_plateau = __uint_as_float(__float_as_uint(plateau) - 1u);
     int wl_head = 0, wl_n = 0;                               // wave-uniform ring state
@@ -274,8 +274,8 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     int64_t b_end = b_begin + blocks_per_split;
     if (b_end > n_blocks) b_end = n_blocks;
     // The rows of dimensions 2 dp, 2 dp + 1 of block blk (a PAIR of dimensions per step: one carry-save step serves
-    // both), staged by the whole workgroup through registers into ONE LDS buffer: the next pair is fetched before this
-    // one is counted, written behind a barrier when everybody has finished reading, and a second barrier publishes it.
+    // both), staged by the whole workgroup through registers into the LDS buffer the previous step has finished with:
+    // the next pair is fetched before this one is counted and written behind the count; ONE barrier per step.
     // g odd: the last pair's second half is whatever follows in the table, with every target's rows (0, 0).
     constexpr int PIECES = 2 * ROWW / 4;                     // sixteen-byte pieces of a pair
     constexpr int NST = (PIECES + 64 * NW - 1) / (64 * NW);  // per thread
@@ -296,8 +296,8 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
         if constexpr (NST > 4) st4 = ld(4);
         if constexpr (NST > 5) st5 = ld(5);
     };
-    auto commit = [&]() {
-        uint4 *dst = reinterpret_cast<uint4 *>(rows);
+    auto commit = [&](int buf) {
+        uint4 *dst = reinterpret_cast<uint4 *>(rows + buf * 2 * ROWW);
         auto wr = [&](int i, const uint4 &v) { const int pc = tid + i * 64 * NW; if (pc < PIECES) dst[pc] = v; };
         wr(0, st0);
         if constexpr (NST > 1) wr(1, st1);
@@ -308,9 +308,10 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
     };
     if (b_begin < b_end) {
         fetch(b_begin, 0);
-        commit();
+        commit(0);
     }
     __syncthreads();
+    int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
         const uint32_t vmask = vbits[blk * 64 + lane];
         uint32_t pl[T][6];                                   // bit-sliced counters: pl[t][b] = bit b of the 32 counts
@@ -322,23 +323,22 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
             // the next pair's rows (the next block's first behind the last) travel while this one is counted
             const bool more = dp + 1 < npair || blk + 1 < b_end;
             if (more) fetch(dp + 1 < npair ? blk : blk + 1, dp + 1 < npair ? dp + 1 : 0);
-            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + lane);
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + buf * 2 * ROWW + lane);
             // ONE LDS read hands the pair's row offsets of all T targets to the wave (lane t holds target t's two words;
             // v_readlane then makes them scalars) -- a read + wait per target made the step a chain of LDS latencies
-            const uint2 myro = *reinterpret_cast<const uint2 *>(ro + (lane & (T - 1)) * GP + 2 * dp);
-            // (an odd g: the second word of the last pair is a padding dimension's (0, 0): the mask is x & ~x = 0)
+            const uint32_t myro = *reinterpret_cast<const uint32_t *>(ro + (lane & (T - 1)) * GP + 2 * dp);     // (lo0, hi0, lo1, hi1)
+            // (an odd g: the second half of the last pair is a padding dimension's (0, 0): the mask is x & ~x = 0)
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 uint32_t m0[T / 2], m1[T / 2];
 #pragma unroll
                 for (int i = 0; i < T / 2; ++i) {                // all the row reads of eight targets fly together
                     const int t = half * (T / 2) + i;
-                    const uint32_t ra = (uint32_t)__builtin_amdgcn_readlane((int)myro.x, t);
-                    const uint32_t rc = (uint32_t)__builtin_amdgcn_readlane((int)myro.y, t);
-                    m0[i] = *reinterpret_cast<const uint32_t *>(rb + (ra >> 16)) &
-                            ~*reinterpret_cast<const uint32_t *>(rb + (ra & 0xFFFFu));
-                    m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc >> 16)) &
-                            ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + (rc & 0xFFFFu));
+                    const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane((int)myro, t);      // row numbers -> byte offsets (x 256)
+                    m0[i] = *reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFF00u))) &
+                            ~*reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFFu) << 8));
+                    m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 16) & 0xFF00u)) &
+                            ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 8) & 0xFF00u));
                 }
 #pragma unroll
                 for (int i = 0; i < T / 2; ++i) {
@@ -354,9 +354,9 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint32_t *__restrict
                     }
                 }
             }
-            __syncthreads();                                 // everybody has read this pair
-            if (more) commit();
-            __syncthreads();                                 // the next pair is in place
+            if (more) commit(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
         }
         // inw >= thr ?  bit-sliced comparator per target, then the survivors into the ring
 #pragma unroll 1
@@ -431,7 +431,7 @@ hipError_t cbb_valid_launch(const uint8_t *mask, int64_t n, uint32_t *vbits, hip
     return hipGetLastError();
 }
 
-hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, const double *edges, uint32_t *rowoff,
+hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, double f, const double *edges, uint16_t *rowoff,
                                    hipStream_t st)
 {
     const int64_t tot = m * gp;
@@ -443,7 +443,7 @@ hipError_t cbb_pack_targets_launch(const double *X, int64_t m, int g, int gp, do
 void cbf_constants(int g, float *slack, float *plateau);
 
 template <int GP, int EPL>
-static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
+static hipError_t cbb_launch_one(const float *xq, const uint16_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
                                  const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau,
                                  hipStream_t st)
 {
@@ -452,7 +452,8 @@ static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_
     const int64_t bps = (n_blocks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)2 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 4 + CBB_T * CAP * 8 + CBB_T * 16 + 512 * 5);
+    const size_t lds = (size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 2 + CBB_T * CAP * 8 + CBB_T * 16 + 256 * 5);
+    static_assert((size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 2 + CBB_T * CAP * 8 + CBB_T * 16 + 256 * 5) <= 163840, "LDS budget");
     auto kern = &cbb_filter_kernel<GP, EPL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -466,7 +467,7 @@ static hipError_t cbb_launch_one(const float *xq, const uint32_t *rowoff, int64_
 // instantiated for g <= 64 (six count planes hold 63) and 32-entry lists (k + drop_first <= 24)
 bool cbb_available(int g, int gp, int epl) { return g <= 63 && gp <= 64 && epl == 1; }
 
-hipError_t cbb_filter_launch(int gp, const float *xq, const uint32_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
+hipError_t cbb_filter_launch(int gp, const float *xq, const uint16_t *rowoff, int64_t m, const float *yrow, const uint32_t *tab,
                              const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau, hipStream_t st)
 {
 #define NABO_CBB(GPV) case GPV: return cbb_launch_one<GPV, 1>(xq, rowoff, m, yrow, tab, vbits, n, g, S, cand_idx, cand_tau, st);
