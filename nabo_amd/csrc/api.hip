@@ -565,7 +565,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                 const bool want_bits = cmode ? strcmp(cmode, "bits") == 0 : ix->n >= 16 * 2048;
                 if (want_bits && nabo::cbb_available(G, ix->cb_gp, 1)) {
                     const int B = nabo::cbb_buckets();
-                    int64_t ns = ix->n < 8192 ? ix->n : 8192;
+                    int64_t ns = ix->n < 2048 ? ix->n : 2048;          // (32 sample values per bucket; the sort is host time inside set_ref)
                     const int64_t stride = ix->n / ns;
                     std::vector<double> smp((size_t)ns * G), col((size_t)ns), edges((size_t)G * (B - 1));
                     HIP_TRY(hipMemcpy2DAsync(smp.data(), (size_t)G * sizeof(double), ix->dY, (size_t)stride * G * sizeof(double),

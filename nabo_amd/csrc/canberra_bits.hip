@@ -23,11 +23,11 @@
 //   * Who shares what.  The table is 206 bytes per reference and every target needs all of it: a wave that streamed it
 //     for its own 16-32 targets (the first version of this file) moved 14 TB per 1M x 1M step through L2 and was no
 //     faster than the SWAR pass (1.88 s vs 1.75 s).  So a WORKGROUP of 8 waves (128 targets) walks the table together:
-//     the 33 rows of ONE dimension of the current block (8.4 KB) are staged in LDS (double-buffered, one barrier per
-//     dimension), every wave reads the two rows each of its 16 targets needs from there (row number wave-uniform, lane =
-//     word: conflict-free) and adds the masks to that target's counter, which stays in registers for the whole block
-//     (16 targets x 6 planes = 96 VGPRs); two dimensions per step: one 3:2 compressor (v_bitop3 0x96 / 0xE8) takes both
-//     masks into the lowest plane, one carry ripples upwards.  Table traffic: 206 MB per 128 targets = 1.6 TB per step.
+//     the rows of a PAIR of dimensions of the current block (2 x 65 x 256 B) are staged in LDS (double-buffered, one
+//     barrier per pair), every wave reads the rows each of its 8 targets needs from there (row number wave-uniform, lane =
+//     word: conflict-free) and adds the two masks to that target's counter, which stays in registers for the whole block
+//     (8 targets x 6 planes = 48 VGPRs; sixteen waves per workgroup, four per SIMD): one 3:2 compressor (v_bitop3 0x96 /
+//     0xE8) takes both masks into the lowest plane, one carry ripples upwards.  Table traffic: 412 MB per 128 targets.
 //   * Survivors (7e-3 of the pairs with 32 quantile buckets, simulated on the bench's data; 2.2e-3 for the 128 uniform
 //     buckets of the SWAR pass) leave through the same wave-private work ring, fp32 lower bound, candidate lists and
 //     certificate as before.  The ring is filled one survivor per lane and round, i.e. NOT in ascending reference
@@ -46,8 +46,8 @@ namespace nabo {
 constexpr int CBB_B = NABO_CBB_B;         // quantile buckets per dimension (survivors of the count: 7e-3 of the pairs at 32, 2.6e-3 at 64)
 constexpr int CBB_ROWS = CBB_B + 1;       // cumulative rows per dimension (row 0: empty set)
 constexpr int CBB_BLK = 2048;             // references per block: 64 lanes x 32 bits
-constexpr int CBB_T = 16;                 // target rows per wave (six count planes each, in registers)
-constexpr int CBB_NW = 8;                 // waves per workgroup: they share the LDS copy of the table rows
+constexpr int CBB_T = 8;                  // target rows per wave (six count planes each, in registers: < 128 VGPRs per wave)
+constexpr int CBB_NW = 16;                // waves per workgroup (four per SIMD): they share the LDS copy of the table rows
 
 int cbb_buckets() { return CBB_B; }
 int cbb_rows_per_wg() { return CBB_T * CBB_NW; }
@@ -328,21 +328,21 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
             // v_readlane then makes them scalars) -- a read + wait per target made the step a chain of LDS latencies
             const uint32_t myro = *reinterpret_cast<const uint32_t *>(ro + (lane & (T - 1)) * GP + 2 * dp);     // (lo0, hi0, lo1, hi1)
             // (an odd g: the second half of the last pair is a padding dimension's (0, 0): the mask is x & ~x = 0)
+            constexpr int TB = T < 8 ? T : 8;                    // targets per batch of row reads
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint32_t m0[T / 2], m1[T / 2];
+            for (int t0 = 0; t0 < T; t0 += TB) {
+                uint32_t m0[TB], m1[TB];
 #pragma unroll
-                for (int i = 0; i < T / 2; ++i) {                // all the row reads of eight targets fly together
-                    const int t = half * (T / 2) + i;
-                    const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane((int)myro, t);      // row numbers -> byte offsets (x 256)
+                for (int i = 0; i < TB; ++i) {                   // all the row reads of a batch fly together
+                    const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane((int)myro, t0 + i);   // row numbers -> byte offsets (x 256)
                     m0[i] = *reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFF00u))) &
                             ~*reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFFu) << 8));
                     m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 16) & 0xFF00u)) &
                             ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 8) & 0xFF00u));
                 }
 #pragma unroll
-                for (int i = 0; i < T / 2; ++i) {
-                    const int t = half * (T / 2) + i;
+                for (int i = 0; i < TB; ++i) {
+                    const int t = t0 + i;
                     // carry-save: (carry, ones) = ones + m0 + m1, then the carry ripples through the planes above
                     uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0xE8);
                     pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0x96);
@@ -358,28 +358,26 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
             __syncthreads();
             buf ^= 1;
         }
-        // inw >= thr ?  bit-sliced comparator per target, then the survivors into the ring
+        // inw >= thr ?  bit-sliced comparator per target (all T unrolled: the planes are registers), then the survivors
+        // into the ring, target by target
+        uint32_t gev[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const uint32_t thr_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_l[t]);
+            uint32_t gt = 0u, eq = 0xFFFFFFFFu;
+#pragma unroll
+            for (int b = 5; b >= 0; --b) {                       // (branch-free: the threshold's bit selects per plane)
+                const uint32_t tb = ((thr_in >> b) & 1u) ? 0xFFFFFFFFu : 0u;
+                gt |= eq & pl[t][b] & ~tb;
+                eq &= ~(pl[t][b] ^ tb);
+            }
+            gev[t] = thr_in < 64u ? ((gt | eq) & vmask) : 0u;
+        }
 #pragma unroll 1
         for (int t = 0; t < t_cnt; ++t) {
-            const uint32_t thr_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_l[t]);
-            uint32_t p[6];
+            uint32_t ge = gev[0];
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {                    // (t is a run-time index here: select the target's planes)
-                uint32_t v = pl[0][b];
-#pragma unroll
-                for (int tt = 1; tt < T; ++tt) v = (t == tt) ? pl[tt][b] : v;
-                p[b] = v;
-            }
-            uint32_t ge = 0u;
-            if (thr_in < 64u) {
-                uint32_t gt = 0u, eq = 0xFFFFFFFFu;
-#pragma unroll
-                for (int b = 5; b >= 0; --b) {
-                    if ((thr_in >> b) & 1u) eq &= p[b];
-                    else { gt |= eq & p[b]; eq &= ~p[b]; }
-                }
-                ge = (gt | eq) & vmask;
-            }
+            for (int tt = 1; tt < T; ++tt) ge = (t == tt) ? gev[tt] : ge;
             uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
             while (anyb != 0) {                                  // every lane with survivors hands over its lowest one
                 const bool has = ge != 0u;
@@ -452,8 +450,8 @@ static hipError_t cbb_launch_one(const float *xq, const uint16_t *rowoff, int64_
     const int64_t bps = (n_blocks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    const size_t lds = (size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 2 + CBB_T * CAP * 8 + CBB_T * 16 + 256 * 5);
-    static_assert((size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 2 + CBB_T * CAP * 8 + CBB_T * 16 + 256 * 5) <= 163840, "LDS budget");
+    constexpr size_t lds = (size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 2 + CBB_T * CAP * 8 + CBB_T * 16 + 256 * 5);
+    static_assert(lds <= 163840, "LDS budget");
     auto kern = &cbb_filter_kernel<GP, EPL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
