@@ -557,12 +557,13 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                 HIP_TRY(nabo::cbf_pack_refs_rows_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->yrow.as<float>(), st));
                 HIP_TRY(nabo::cbf_pack_refs8_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
                 HIP_TRY(hipStreamSynchronize(st));      // sc goes out of scope
-                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 16 blocks
-                // (NABO_CANBERRA_MODE=swar pins the 7-bit SWAR pass, =bits the bitmaps at any size): per-dimension
+                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 128 blocks (262k cells:
+                // measured 2.0x the SWAR pass at 1M x 1M, level with it at 100k x 100k where building its table costs
+                // what it saves; NABO_CANBERRA_MODE=swar pins the 7-bit SWAR pass, =bits the bitmaps at any size): per-dimension
                 // QUANTILE bucket edges from a strided sample of the references (any edges give correct results -- they
                 // only decide how sharp the count is), cumulative bitmaps per block of 2048 references.
                 ix->cb_bits = false;
-                const bool want_bits = cmode ? strcmp(cmode, "bits") == 0 : ix->n >= 16 * 2048;
+                const bool want_bits = cmode ? strcmp(cmode, "bits") == 0 : ix->n >= 128 * 2048;
                 if (want_bits && nabo::cbb_available(G, ix->cb_gp, 1)) {
                     const int B = nabo::cbb_buckets();
                     int64_t ns = ix->n < 2048 ? ix->n : 2048;          // (32 sample values per bucket; the sort is host time inside set_ref)
