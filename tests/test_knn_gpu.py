@@ -483,12 +483,19 @@ def test_locality_ordered_streaming_gives_the_same_bits(gpu_lib, flags, m, n, g,
     for b in (dx, di, dd, db):
         b.free()
     o2i, o2d = oracle.knn(X, Y, nc + 1, metric, 0.25, ref_mask=mask, nthreads=8)
-    # (a row whose list ENDS between the two tied references may keep either of them -- the filter does not order exact
-    # ties, the bound then equals their distance and the sharded protocol re-solves the row; such rows are left out)
-    clean = ~np.isin(o2i, (3, 7)).any(axis=1)
-    assert clean.sum() > 0.9 * m
-    assert np.array_equal((ci - 1000)[clean], o2i[clean, :nc]) and np.array_equal(cd[clean], o2d[clean, :nc])
-    assert (cb <= o2d[:, nc] ** 2 * (1 + 1e-12)).all()
+    # A candidate list holds the nc smallest FILTER scores, re-evaluated exactly and sorted: two references whose exact
+    # distances differ by less than the filter's error may change places across the END of the list (or exact ties: the
+    # filter does not order them).  What the protocol relies on, and what must hold for EVERY row: the emitted entries are
+    # exact and sorted, and `bound` bounds everything that was not emitted.  Almost all rows are the oracle's prefix itself.
+    same = (ci - 1000 == o2i[:, :nc]).all(axis=1) & (cd == o2d[:, :nc]).all(axis=1)
+    assert same.mean() > 0.999, same.mean()
+    assert (np.diff(cd, axis=1) >= 0).all()
+    left_out = np.array([next(d for j, d in zip(o2i[r], o2d[r]) if j not in set(ci[r] - 1000)) for r in range(m)])
+    assert (cb <= left_out ** 2 * (1 + 1e-12)).all()
+    for r in np.nonzero(~same)[0][:50]:                      # the rows that differ: a permutation of near-ties only
+        exact = oracle.pairwise(X[r:r + 1], Y[ci[r] - 1000], metric, 0.25)[0]
+        assert np.array_equal(exact, cd[r])
+        assert set(ci[r, :nc - 1] - 1000) <= set(o2i[r]) and abs(cd[r, -1] - o2d[r, nc - 1]) <= 1e-4 * o2d[r, nc - 1]
 
 
 @pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3s", 274), ("f16x3h", 274), ("f16x3q", 274)])

@@ -44,7 +44,7 @@ rec["traffic"][be["config"]["workload"]] = {
     "source": dst_prefix + "pmc_euclid_summary.csv (rocprofv3 --pmc, one counter group per pass, tools/r3_pmc.sh)"}
 bc = bench_line(os.path.join(src, "pmc_canberra_pass1.json"))
 ca = summary(os.path.join(src, "pmc_canberra_summary.csv"))
-kc = [k for k in ca if "cbf_filter_kernel" in k][0]
+kc = max([k for k in ca if "cbf_filter_kernel" in k or "cbb_filter_kernel" in k], key=lambda k: ca[k].get("SQ_INSTS_VALU", 0))
 rec["canberra"][bc["config"]["workload"]] = {
     "so_digest": bc["so_digest"], "src_digest": bc["roofline"]["kernel_src_digest"], "kernel": kc, "valu_insts_per_step": ca[kc]["SQ_INSTS_VALU"],
     "insts": {k: ca[kc][k] for k in ca[kc] if k.startswith("SQ_INSTS")},
