@@ -278,7 +278,7 @@ def main():
         kind, ranks = "launcher", env_world
     elif loop > 1:
         kind, ranks = "loopback", loop
-    elif a.gpus > 1:
+    elif a.gpus > 1 or os.environ.get("NABO_BENCH_FORCE_THREADS") == "1":      # (rehearsal: that path with the one rank a GPU allows)
         kind, ranks = "threads", a.gpus
     else:
         kind, ranks = ("launcher" if force_comm else "single"), 1

@@ -407,6 +407,22 @@ def test_bench_prints_the_baseline_layout_as_headline_and_the_2d_layout_beside_i
 
 
 @pytest.mark.gpu
+def test_bench_plain_launch_drives_its_ranks_from_one_process():
+    """`python bench.py --gpus N` with no launcher environment: nabo_comm_create_all (ncclCommInitAll), one persistent host
+    thread per rank, the shards resident in HBM -- rehearsed with the one rank a single GPU allows."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NABO_BENCH_LOOPBACK")}
+    env.update(NABO_BENCH_FORCE_THREADS="1", NABO_BENCH_CHECK="1")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--targets", "20001",
+           "--refs", "50000", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "one RCCL communicator per GPU" in line["config"]["launch"] and line["sharded"]["rccl_world"] == 1
+    assert "sharded == unsharded: True" in r.stdout and line["sampled_rows_equal_oracle"] is True
+
+
+@pytest.mark.gpu
 def test_bench_under_the_launcher_creates_its_communicator_without_torch():
     """The driver's launch line (python -m torch.distributed.run ... bench.py --gpus N) with the one rank a single
     GPU allows: RANK / WORLD_SIZE / LOCAL_RANK from the launcher, the unique id through the file, ncclCommInitRank,
