@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnabo_knn.so")
-SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "l2q_topk.hip", "l2s_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "order.hip"]
+SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "l2s_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "order.hip"]
 # per-file extra flags: -fno-honor-nans for the fp32 score kernel (scores are finite or +inf by construction; without it
 # every fminf tree starts with two v_max canonicalisations, and on gfx950 the fp32 MFMA cannot overlap vector-ALU work);
 # (NOT for l2h_topk.hip: its masked / padding cells carry an inf - inf = NaN low part, and the filter relies on NaN
@@ -23,7 +23,10 @@ SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "l2q_topk.hip",
 # kernel 755 -> 735 ms; no effect on l2h_topk.hip (372 ms either way);
 # keep MFMA accumulators in arch VGPRs so the C-in (||y||^2 block) needs no
 # v_accvgpr_write and the filter reads the scores without v_accvgpr_read (see l2_topk.hip)
-FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "l2q_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "l2s_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp"], "l2h_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "l2q_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+              # l2c_topk.hip: its scores are finite or +inf by construction (pack_ctiles_kernel<.,.,1>), so the filter's minimum tree
+              # needs no NaN canonicalisation (two v_max per row-block otherwise)
+              "l2c_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"], "l2s_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
               "canberra_f32.hip": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]}
 HEADERS = [os.path.join(CSRC, "knn_common.h"), os.path.join(CSRC, "topk_lists.h"), os.path.join(HERE, "..", "include", "nabo_knn.h")]
 ARCH = "gfx950"

@@ -22,7 +22,7 @@ SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
     "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
     "nabo_index_query_candidates",
-    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
+    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
     "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
     "nabo_comm_rank", "nabo_comm_world", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
@@ -57,6 +57,7 @@ def lib():
     L.nabo_index_query_candidates.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
     L.nabo_index_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.nabo_index_last_kernel.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.nabo_index_last_passes.argtypes = [vp, C.POINTER(i64)]
     L.nabo_merge_topk.argtypes = [i32, vp, vp, i32, i64, i32, i32, i32, vp, vp]
     L.nabo_snn_counts.argtypes = [i32, vp, i64, vp, i64, i32, vp]
     L.nabo_dev_malloc.argtypes = [i32, C.POINTER(vp), C.c_size_t]
@@ -96,7 +97,7 @@ def so_digest():
 # sources a kernel's counter record depends on (profiles/pmc.json): the kernel, what it includes, the operand packing,
 # the launch logic and the compiler flags
 KERNEL_SOURCES = {
-    "euclid": ["l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "order.hip", "api.hip", "_build.py"],
+    "euclid": ["l2c_topk.hip", "l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "order.hip", "api.hip", "_build.py"],
     "canberra": ["canberra_f32.hip", "canberra_bits.hip", "knn_common.h", "api.hip", "_build.py"],
 }
 

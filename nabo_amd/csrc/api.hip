@@ -34,10 +34,16 @@ int l2h_pick_kc(int g);
 // f16x3 variant with K-concatenated operands and reference tiles shared per workgroup through an LDS ring (l2s_topk.hip)
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
-                            bool layout16, hipStream_t st, const uint32_t *perm = nullptr);
+                            bool layout16, hipStream_t st, const uint32_t *perm = nullptr, int nseg = 3);
 hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
                               int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st,
-                              const uint32_t *perm = nullptr);
+                              const uint32_t *perm = nullptr, int nseg = 3);
+int l2q_pick_kc1(int g);
+// the one-product first pass (l2c_topk.hip; operands packed with layout16, nseg = 1)
+hipError_t l2c_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           int64_t pad_tile, hipStream_t st);
+int l2c_pick_kc(int g);
 // the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
@@ -232,17 +238,22 @@ struct nabo_index {
     int kc = 0;
     bool shared = false;
     bool q16 = false;              // l2q_topk.hip (16x16x32 MFMA shape; operands in the layout16 packing)
+    // One-product first pass (l2q kernel on [hi | norm | error] operands of kc1 steps, pack_ctiles_kernel<.,.,1>): rows it
+    // cannot certify go through the f16x3 pass (no_coarse), then the 64-entry lists, then the exact kernels.
+    bool coarse = false;
+    bool no_coarse = false;        // inside the f16x3 pass of the rows the one-product pass could not certify
+    int kc1 = 0;
     double hscale = 1.0;
     double fscale = 1.0;           // power-of-two input scale of the fp32 path: max |y~| * fscale in (1/2, 1]
     int ksteps = 0;
-    DevBuf centre, ypk, ycpk, normmax;
+    DevBuf centre, ypk, ycpk, ycpk1, normmax;
     // locality order (order.hip; l2q kernel only): reference keys / permutation (resident), target keys / permutation and
     // the waves' start tiles (per query), sort scratch
     bool order = false;            // decided at creation (NABO_L2Q_ORDER=0 streams in caller order: same results)
     int order_flags = 0;
     bool ref_ordered = false;      // the packed f16 tiles are in key order
     DevBuf rkeys, rperm, tkeys, tperm, wstart, okeys, opos, otemp;
-    bool packed_f32 = false, packed_c16 = false;
+    bool packed_f32 = false, packed_c16 = false, packed_c1 = false;
     int64_t ref_tiles = 0, ref_tiles_alloc = 0;
     double ymax_sqrt = 0.0, ymax_sqrt_c = 0.0;
     // Canberra path: exact kernel operands (yt) and the fp32 lower-bound filter's (ycf)
@@ -255,6 +266,8 @@ struct nabo_index {
 
     // query workspace
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
+    DevBuf xfail1, tmpi1, tmpd1, fails1;      // the same for the f16x3 pass behind the one-product pass (the passes nest)
+    int64_t pass_rows[2] = {0, 0};            // rows of the last query sent to the f16x3 pass / to the 64-entry lists
     float ms_keep[3] = {0, 0, 0};
     double ms_inner = 0.0;         // total of the most recent query_impl (read by the outer call of a retry)
     bool ms_keep_valid = false;
@@ -264,7 +277,7 @@ struct nabo_index {
 
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
-    char kernel[96] = "";          // dominant kernel of the last query (nabo_index_last_kernel)
+    char kernel[160] = "";          // dominant kernel of the last query (nabo_index_last_kernel)
 };
 
 namespace nabo {
@@ -305,10 +318,12 @@ static int order_rows(nabo_index *ix, const double *V, int64_t n, DevBuf &keys, 
     return NABO_OK;
 }
 
-// Pack the resident references for the fp32-MFMA kernel (want_h = false) or the f16x3 kernels (K-concatenated f16 tiles).
-static int ensure_packed(nabo_index *ix, bool want_h)
+// Pack the resident references for the fp32-MFMA kernel (want = 0), the f16x3 kernels (1: K-concatenated f16 tiles) or
+// the one-product pass of the l2q kernel (2).
+static int ensure_packed(nabo_index *ix, int want)
 {
-    if (want_h ? ix->packed_c16 : ix->packed_f32) return NABO_OK;
+    const bool want_h = want != 0;
+    if (want == 2 ? ix->packed_c1 : want == 1 ? ix->packed_c16 : ix->packed_f32) return NABO_OK;
     hipStream_t st = ix->stream;
     int rc;
     // normmax: [0] = max ||y~||^2 (float bits, SCALED units), [2..3] = max |y~ component| (double bits)
@@ -328,7 +343,19 @@ static int ensure_packed(nabo_index *ix, bool want_h)
     if (e2 > 480) e2 = 480;                                  // scale^2 must stay finite in float64
     if (e2 < -480) e2 = -480;
     double scale;
-    if (want_h) {
+    if (want == 2) {
+        if ((rc = ix->ycpk1.reserve((size_t)ix->ref_tiles_alloc * ix->kc1 * 1024 + 128))) return rc;
+        ix->hscale = scale = std::ldexp(1.0, e2 + 12);
+        ix->ref_ordered = false;
+        if (ix->order) {             // (the same keys, hence the same permutation, as the f16x3 operands of the second pass)
+            if ((rc = order_rows(ix, ix->dYp, ix->n, ix->rkeys, ix->rperm))) return rc;
+            ix->ref_ordered = true;
+        }
+        HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc1,
+                                       ix->ref_tiles_alloc, ix->dmask, ix->ycpk1.as<unsigned char>(),
+                                       ix->normmax.as<unsigned int>(), ix->q16, st,
+                                       ix->ref_ordered ? ix->rperm.as<uint32_t>() : nullptr, 1));
+    } else if (want_h) {
         if ((rc = ix->ycpk.reserve((size_t)ix->ref_tiles_alloc * ix->kc * 1024 + 128))) return rc;
         // |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
         ix->hscale = scale = std::ldexp(1.0, e2 + 12);
@@ -354,7 +381,8 @@ static int ensure_packed(nabo_index *ix, bool want_h)
     float fmax;
     memcpy(&fmax, &bits[0], sizeof(fmax));
     const double v = std::sqrt((double)fmax) / scale * (1.0 + 1e-6);      // unscaled units
-    if (want_h) { ix->ymax_sqrt_c = v; ix->packed_c16 = true; }
+    if (want == 2) { ix->ymax_sqrt_c = v; ix->packed_c1 = true; }
+    else if (want_h) { ix->ymax_sqrt_c = v; ix->packed_c16 = true; }
     else { ix->ymax_sqrt = v; ix->packed_f32 = true; }
     return NABO_OK;
 }
@@ -438,13 +466,20 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
             ix->shared = md && strcmp(md, "f16x3s") == 0 && nabo::l2s_pick_kc(g) == ix->kc;
             // default: the 16x16x32 MFMA shape (l2q_topk.hip; the chip holds a higher clock on it); =f16x3h pins the
             // 32x32x16 per-wave kernel, =f16x3s the shared-tile one (both use the 32x32 operand layout)
-            ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0));
+            ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0 || strcmp(md, "f16x1h") == 0));
             // NABO_L2Q_ORDER (bit flags; every setting gives the same results): 1 = references packed in key order,
             // 2 = targets packed in key order, 4 = home pre-pass of every wave; 0 = caller order, the DEFAULT: key order
             // cuts the list updates by 30 % and the hit episodes by 70 %, and the kernel is 20 % SLOWER on it -- sorted
             // operands cost more clock than the hit path they save (order.hip, profiles/r3_order_experiment.txt)
             ix->order_flags = ix->q16 ? env_int("NABO_L2Q_ORDER", 0) : 0;
             ix->order = (ix->order_flags & 1) != 0;
+            // DEFAULT first pass: the ONE-PRODUCT filter (hi x hi with the split's error as an operand slot: a rigorous
+            // lower bound of the f16x3 score at 2 / 5 of its matrix work); rows it cannot certify go through the f16x3
+            // pass.  NABO_L2_MODE=f16x3 pins the three-product filter as the first pass, =f16x1 is the default spelled out.
+            ix->kc1 = ix->q16 ? nabo::l2c_pick_kc(g) : nabo::l2q_pick_kc1(g);
+            // (=f16x1h: the one-product pass on the 32x32x16 shape, l2h_topk.hip -- an experiment)
+            ix->coarse = !ix->shared && (ix->order_flags == 0 || ix->q16) && ix->kc1 > 0 &&
+                         !(md && strncmp(md, "f16x3", 5) == 0);
         }
     }
     int cus = 0;
@@ -497,7 +532,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
     } else if (ix->metric != NABO_METRIC_MOD_CANBERRA) {
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 64;      // room for split padding (+inf-norm tiles; up to 32 splits)
-        ix->packed_f32 = ix->packed_c16 = false;
+        ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
         if (ix->metric == NABO_METRIC_COSINE) {
             // cosine: the filter sees unit-length rows, NOT centred (a shift changes angles)
@@ -509,7 +544,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
             HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
             ix->dYp = ix->dY;
         }
-        if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
+        if ((rc = ensure_packed(ix, ix->mode == 1 ? (ix->coarse ? 2 : 1) : 0))) return rc;
     } else {
         const int64_t chunks = (ix->n + 63) / 64;
         if ((rc = ix->yt.reserve((size_t)chunks * 64 * ix->g * sizeof(double)))) return rc;
@@ -611,8 +646,8 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
         HIP_TRY(hipStreamSynchronize(ix->stream));
     }
     if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0) {       // masked cells carry ||y||^2 = +inf in the packed tiles
-        ix->packed_f32 = ix->packed_c16 = false;
-        if ((rc = ensure_packed(ix, ix->mode == 1))) return rc;
+        ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
+        if ((rc = ensure_packed(ix, ix->mode == 1 ? (ix->coarse ? 2 : 1) : 0))) return rc;
     }
     return NABO_OK;
 }
@@ -706,6 +741,10 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             else if (!use_c) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
+        // the one-product first pass (l2q kernel, kc1-step operands); see nabo_index::coarse
+        const bool use_1 = use_h && !use_c && ix->coarse && !ix->no_coarse && !ix->wide_retry && !cand_mode;
+        const int kcq = use_1 ? ix->kc1 : ix->kc;
+        if (!ix->no_coarse && !ix->wide_retry) ix->pass_rows[0] = ix->pass_rows[1] = 0;
         // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
         // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
         bool r1 = false;
@@ -728,14 +767,19 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             }
         }
         const int epl_launch = r1 ? -1 : epl;
-        if (!ix->wide_retry) {
-            if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
+        if (!ix->wide_retry && !ix->no_coarse) {
+            // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
+            if (use_1 && ix->q16 && (ix->order_flags != 0 || env_int("NABO_COARSE_KERNEL_Q", 0) != 0))
+                snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq);
+            else if (use_1 && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2c_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2);
+            else if (use_1) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, one-product f16 filter with the split error as an operand slot)", kcq);
+            else if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
             else if (use_h && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, K-concatenated f16x3 split)", ix->kc);
             else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
             else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
                           r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 33 : 65);
         }
-        if ((rc = ensure_packed(ix, use_h))) return rc;
+        if ((rc = ensure_packed(ix, use_1 ? 2 : use_h ? 1 : 0))) return rc;
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
         const int64_t rows_pad = gx * rows_per_wg;
@@ -744,6 +788,9 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         int lkeep = kk + 8;
         if (lkeep < 16) lkeep = 16;
         if (ix->wide_retry) lkeep = lkeep_max;              // as many kept entries as the 64-entry lists allow
+        // one-product pass: its scores sit up to 2^-9 ||x|| ||y|| below the real ones, the gap above the k'-th distance
+        // has to cover that (1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass, k' + 17 almost none)
+        if (use_1) lkeep = kk + 8 + env_int("NABO_COARSE_SLACK", 5);
         if (cand_mode) lkeep = kk < 4 ? 4 : kk;
         if (lkeep > lkeep_max) lkeep = lkeep_max;
         { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }   // experiments
@@ -764,7 +811,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 int64_t s_hi = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
                 if (s_hi > 1024 / L) s_hi = 1024 / L;
                 // ms per reference tile and workgroup, measured: 105 ms / 31250 tiles (fp32, 256 rows, 25 k-steps); 1.2 us f16x3
-                const double t_tile = use_c ? 0.7e-3 * ix->kc / 10.0 : use_h ? 1.1e-3 * ix->kc / 10.0
+                const double t_tile = use_c ? 0.7e-3 * ix->kc / 10.0 : use_h ? 1.1e-3 * kcq / 10.0
                                                                         : 3.36e-3 * (rows_per_wg / 256.0) * (ix->ksteps / 25.0);
                 double best = 1e30;
                 for (int s2 = 1; s2 <= (int)s_hi; ++s2) {
@@ -793,7 +840,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
             return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
         const int64_t rows_main = gx_main * rows_per_wg, rows_tail = gx_tail * rows_per_wg;
-        const size_t xtile_bytes = use_h ? (size_t)ix->kc * 1024 : (size_t)Q * 256 * sizeof(float);
+        const size_t xtile_bytes = use_h ? (size_t)kcq * 1024 : (size_t)Q * 256 * sizeof(float);
         if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * xtile_bytes))) return rc;
         if ((rc = ix->xnorm.reserve((size_t)m * sizeof(double)))) return rc;
         if ((rc = ix->cand_idx.reserve((size_t)rows_main * S * L * sizeof(uint32_t) + 16))) return rc;
@@ -824,8 +871,9 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             wstart = ix->wstart.as<int32_t>();
         }
         if (use_h)
-            HIP_TRY(nabo::pack_cquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, ix->kc, rows_pad / 32,
-                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), ix->q16, st, tperm));
+            HIP_TRY(nabo::pack_cquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, kcq, rows_pad / 32,
+                                             ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), ix->q16, st, tperm,
+                                             use_1 ? 1 : 3));
         else
             HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->fscale, ix->ksteps, rows_pad / 32,
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
@@ -840,22 +888,38 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                               (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
                                               ix->cand_tau2.as<float>(), st));
         } else if (use_h && ix->q16) {
+            const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
+            // the l2q kernel on the one-product operands: A/B runs, and the locality-ordered stream (its home pre-pass)
+            static const bool coarse_on_q_env = env_int("NABO_COARSE_KERNEL_Q", 0) != 0;
+            const bool coarse_on_q = coarse_on_q_env || ix->order_flags != 0;
+            if (use_1 && !coarse_on_q) {
+                if (gx_main > 0)
+                    HIP_TRY(nabo::l2c_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
+                                                  ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
+                                                  ix->ref_tiles_alloc - 1, st));
+                if (gx_tail > 0)
+                    HIP_TRY(nabo::l2c_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
+                                                  rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
+                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st));
+            } else {
             if (gx_main > 0)
-                HIP_TRY(nabo::l2q_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
+                HIP_TRY(nabo::l2q_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,
                                               (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
                                               ix->cand_tau.as<float>(), ix->ref_tiles_alloc - 1, st, wstart));
             if (gx_tail > 0)
-                HIP_TRY(nabo::l2q_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
+                HIP_TRY(nabo::l2q_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,
                                               (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
                                               ix->ref_tiles_alloc - 1, st, wstart));
+            }
         } else if (use_h) {
+            const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
             if (gx_main > 0)
-                HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
+                HIP_TRY(nabo::l2h_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,
                                               (int)tps, S, (int)gx_main, 0, lkeep, ix->cand_idx.as<uint32_t>(), nullptr,
                                               ix->cand_tau.as<float>(), ix->ref_tiles_alloc - 1, st));
             if (gx_tail > 0)
-                HIP_TRY(nabo::l2h_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(),
+                HIP_TRY(nabo::l2h_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,
                                               (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
                                               ix->ref_tiles_alloc - 1, st));
@@ -883,7 +947,9 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // rounding-error coefficient of the filter score, relative to (||x|| + max||y||)^2
         // (f16x3: one fp32 accumulation per product term, 16 per step, plus the dropped lo*lo term and the
         // representation error of the hi + lo split)
-        const double err_coef = use_h ? 1.05 * ((16.0 * ix->kc + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
+        // (one-product pass: the hi x lo, lo x hi and lo x lo terms are INSIDE its score -- the error slot of
+        // pack_ctiles_kernel<.,.,1> -- so the same accumulation / representation coefficient applies to its kc1 steps)
+        const double err_coef = use_h ? 1.05 * ((16.0 * kcq + 8.0) * std::ldexp(1.0, -24) + std::ldexp(1.0, -20) + std::ldexp(1.0, -21))
                                       : 1.05 * (2.0 * ix->ksteps + 4.0) * std::ldexp(1.0, -24);
         const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0 / (ix->fscale * ix->fscale);
         const double ymax_sqrt = use_h ? ix->ymax_sqrt_c : ix->ymax_sqrt;
@@ -930,7 +996,30 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipStreamSynchronize(st));
         float ms_first[3] = {0, 0, 0};
         bool retried = false;
-        if (n_fail >= 16 && epl == 1 && !ix->wide_retry && env_int("NABO_WIDE_RETRY", 1) != 0) {
+        if (use_1 && n_fail > 0) {
+            // Rows the one-product pass could not certify: the f16x3 pass solves them as a dense batch (this very
+            // function with no_coarse set; it sends what IT cannot certify on to the 64-entry lists / the exact kernels).
+            for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms_first[i], ix->ev[i], ix->ev[i + 1]));
+            const int64_t nf = n_fail;
+            if ((rc = ix->fails1.reserve((size_t)nf * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->xfail1.reserve((size_t)nf * g * sizeof(double)))) return rc;
+            if ((rc = ix->tmpi1.reserve((size_t)nf * k * sizeof(int64_t)))) return rc;
+            if ((rc = ix->tmpd1.reserve((size_t)nf * k * sizeof(double)))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->fails1.p, ix->fails.p, (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(nabo::gather_rows_launch(dX, ix->fails1.as<uint32_t>(), nf, g, ix->xfail1.as<double>(), st));
+            HIP_TRY(hipStreamSynchronize(st));
+            ix->no_coarse = true;
+            rc = query_impl(ix, ix->xfail1.as<double>(), 1, nf, k, drop_first, ix->tmpi1.as<int64_t>(), ix->tmpd1.as<double>(), 1,
+                            false, nullptr);
+            ix->no_coarse = false;
+            if (rc) return rc;
+            ix->pass_rows[0] = nf;
+            n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
+            HIP_TRY(nabo::scatter_rows_launch(ix->tmpi1.as<int64_t>(), ix->tmpd1.as<double>(), ix->fails1.as<uint32_t>(), nf, k,
+                                              d_oidx, d_odist, st));
+            HIP_TRY(hipEventRecord(ix->ev[3], st));          // (ev[0..5] were reused by the inner call)
+            retried = true;
+        } else if (n_fail >= 16 && epl == 1 && !ix->wide_retry && env_int("NABO_WIDE_RETRY", 1) != 0) {
             // Second chance: rows the 32-entry lists could not certify (ties / near-ties reaching past the kept
             // entries) go through the same filter once more with 64-entry lists before anything is brute-forced.
             // The flagged rows are gathered into a dense batch; this very function solves it (wide_retry) and
@@ -949,6 +1038,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                             false, nullptr);
             ix->wide_retry = false;
             if (rc) return rc;
+            ix->pass_rows[1] = nf;
             n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
             HIP_TRY(nabo::scatter_rows_launch(ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), ix->fails2.as<uint32_t>(), nf, k,
                                               d_oidx, d_odist, st));
@@ -1197,6 +1287,14 @@ int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4
     if (!ix) return fail(NABO_E_INVALID, "NULL index");
     if (ms) memcpy(ms, ix->ms, sizeof(ix->ms));
     if (counters) memcpy(counters, ix->counters, sizeof(ix->counters));
+    return NABO_OK;
+}
+
+int nabo_index_last_passes(const nabo_index *ix, int64_t rows[2])
+{
+    if (!ix || !rows) return fail(NABO_E_INVALID, "NULL argument");
+    rows[0] = ix->pass_rows[0];
+    rows[1] = ix->pass_rows[1];
     return NABO_OK;
 }
 

@@ -1,0 +1,382 @@
+// l2c_topk.hip -- the ONE-PRODUCT Euclidean filter: the first pass of the default Euclidean / cosine query (gfx950).
+//
+// Operands: pack_ctiles_kernel<., true, 1> (l2s_topk.hip) -- a cell is ONE vector of g + 3 f16 slots,
+//   references [hi (g) | nh | nl | ey],  targets [-2 hi (g) | 2^15 | 2^15 | -tx],
+// so the contraction  ||rep_y||^2 - 2 hi_x.hi_y - tx ey  needs KS = ceil((g + 3) / 32) steps of v_mfma_f32_16x16x32_f16
+// (2 at g = 50) where the f16x3 split of l2q_topk.hip needs 5.  tx ey >= the split's dropped terms (hi x lo, lo x hi,
+// lo x lo), so the score is a rigorous LOWER bound of the f16x3 score: the same lists, the same certificate in
+// refine.hip (with this kernel's accumulation coefficient), and a row the bound is too weak for goes through the f16x3
+// pass afterwards (api.hip: no_coarse).  On 1M x 1M x 50 the bound costs 3 % more staged scores and ~1 % of the rows.
+//
+// What a tile costs was measured on the l2q kernel at KS = 2 (tools/r3_coarse_ablate3.sh, 1M x 1M): the bare MFMA loop
+// 62 ms = the matrix pipe's rate, + 24 ms of filter instructions (14 per 8 MFMAs, bunched behind the chains they read),
+// + 12-15 ms for the tile refills (fenced into the last chain of a tile), + 32 ms of hits -- nothing overlapped.  Hence:
+//   * the filter of a pair of row-blocks is 10 instructions (2 x (3 v_min3 + v_min + v_cmp)): no NaN canonicalisation --
+//     this file is compiled with -fno-honor-nans, and the operands make every score finite or +inf (padding TARGET rows
+//     carry the norm slots too, a masked reference has no error slot).  (One minimum over both row-blocks against the
+//     larger of the two thresholds is 9 -- and 1.5x the kernel time: a row's scores sit below its NEIGHBOUR's threshold
+//     all the time, thresholds differ by the local density of the cells.)
+//   * a ring of FOUR register sets for the reference tiles (a set is 4 KS registers): tile t + 3 is requested at the
+//     top of step t, no scheduling fences -- three whole steps ahead instead of one;
+//   * a tile's scores wait one step in registers: their filter reads nothing an MFMA in flight writes, its instructions
+//     are spread two per MFMA by scheduling groups, and there is one verdict branch per TILE (see the kernel body);
+//   * the staging / drain code sits out of line behind that unlikely branch, the drain itself behind a real call.
+#include <cstdio>
+#include <cstdlib>
+
+#include <hip/hip_fp16.h>
+
+#ifndef NABO_L2C_INLINE_DRAIN
+#define NABO_DRAIN_CALL 1
+#endif
+#include "knn_common.h"
+#include "topk_lists.h"
+
+namespace nabo {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef NABO_L2C_BUILTIN
+constexpr bool L2C_BUILTIN = true;
+#else
+constexpr bool L2C_BUILTIN = false;
+#endif
+#ifdef NABO_L2C_ABL
+constexpr bool L2C_ABLATED = true;
+#else
+constexpr bool L2C_ABLATED = false;
+#endif
+constexpr int L2C_NREC = 64;        // staging records (8 scores each) per wave
+constexpr int L2C_ROW = 33;         // list entries per row (odd)
+
+struct cacc { f32x4 v[2][2]; };     // [row-block of the pair][reference half]
+#define L2C_SG(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
+
+// One pair of row-blocks against one reference tile: four accumulators one after another (l2q_topk.hip).
+template <int KS>
+__device__ __forceinline__ cacc cchain(const f16x8 (&a)[2][KS], const f16x8 (&b0)[KS], const f16x8 (&b1)[KS])
+{
+    cacc acc;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        f32x4 r = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+            r = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[c & 1][s], (c >> 1) ? b1[s] : b0[s], r, 0, 0, 0);
+        acc.v[c >> 1][c & 1] = r;
+    }
+    return acc;
+}
+
+// lane minimum of the 8 scores of each row-block of the pair (3 v_min3 + v_min each)
+struct cmins { float m0, m1; };
+__device__ __forceinline__ cmins cmin8x2(const cacc &acc)
+{
+    cmins r;
+    r.m0 = fminf(fminf(acc.v[0][0][0], acc.v[0][0][1]), acc.v[0][0][2]);
+    r.m0 = fminf(fminf(r.m0, acc.v[0][0][3]), acc.v[0][1][0]);
+    r.m0 = fminf(fminf(r.m0, acc.v[0][1][1]), acc.v[0][1][2]);
+    r.m0 = fminf(r.m0, acc.v[0][1][3]);
+    r.m1 = fminf(fminf(acc.v[1][0][0], acc.v[1][0][1]), acc.v[1][0][2]);
+    r.m1 = fminf(fminf(r.m1, acc.v[1][0][3]), acc.v[1][1][0]);
+    r.m1 = fminf(fminf(r.m1, acc.v[1][1][1]), acc.v[1][1][2]);
+    r.m1 = fminf(r.m1, acc.v[1][1][3]);
+    return r;
+}
+
+// One pair of row-blocks against one reference tile WITH the filter of another pair (`old`, complete long ago) beside it,
+// scheduled by hand: 4 KS segments of one MFMA + its share of the filter's ten instructions (two 8-way minimum trees, two
+// compares), a scheduling fence after each.  The MFMAs are inline assembly so that an accumulator is one register quad
+// from its first step to its last reader -- hipcc gives the C = 0 step of every chain the SAME scratch quad, the trees'
+// temporaries then land on it while the next MFMA still reads it as C, and the hazard pads (s_nop 2..6, several per
+// tile) cost 11 ms of 87 at 1M x 1M.  What inline assembly MFMAs need (cdna_hip_programming.md, inline assembly, item 2):
+// D -> next MFMA taking it whole as C: nothing; D -> any other reader: 12 wait states -- every reader here is a tile
+// later, and the code after the loop pads explicitly; "=&v": D never overlaps an A operand whose last use this is.
+template <int KS>
+__device__ __forceinline__ void cpair(const f16x8 (&a)[2][KS], const f16x8 (&b0)[KS], const f16x8 (&b1)[KS], cacc &cur,
+                                      const cacc &old, float tau0, float tau1, cmins &mm, uint64_t &hit)
+{
+    static_assert(KS == 2, "hand schedule for two steps of 32 slots (g <= 61); other shapes take the builtin path");
+    float m0, m1;
+    uint64_t h0, h1;
+    f32x4 &r00 = cur.v[0][0], &r01 = cur.v[0][1], &r10 = cur.v[1][0], &r11 = cur.v[1][1];
+    // Two statements of four MFMAs, each MFMA followed by its share of the filter (<= 2 instructions: what fits beside 16
+    // matrix cycles).  Inside a statement nothing is padded and nothing needs to be: the filter's instructions depend on
+    // each other only (vector-ALU interlocks), never on an MFMA of this tile.
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %8, 0\n\t"
+                 "v_min_f32 %2, %10, %11\n\t"
+                 "v_min3_f32 %2, %2, %12, %13\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %5, %9, %0\n\t"
+                 "v_min3_f32 %2, %2, %14, %15\n\t"
+                 "v_min3_f32 %2, %2, %16, %17\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %6, %8, 0\n\t"
+                 "v_min_f32 %3, %18, %19\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %7, %9, %1\n\t"
+                 "v_min3_f32 %3, %3, %20, %21"
+                 : "=&v"(r00), "=&v"(r01), "=&v"(m0), "=&v"(m1)
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), "a"(b0[0]), "a"(b0[1]),
+                   "v"(old.v[0][0][0]), "v"(old.v[0][0][1]), "v"(old.v[0][0][2]), "v"(old.v[0][0][3]),
+                   "v"(old.v[0][1][0]), "v"(old.v[0][1][1]), "v"(old.v[0][1][2]), "v"(old.v[0][1][3]),
+                   "v"(old.v[1][0][0]), "v"(old.v[1][0][1]), "v"(old.v[1][0][2]), "v"(old.v[1][0][3]));
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %5, %9, 0\n\t"
+                 "v_min3_f32 %4, %4, %11, %12\n\t"
+                 "v_mfma_f32_16x16x32_f16 %0, %6, %10, %0\n\t"
+                 "v_min3_f32 %4, %4, %13, %14\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %7, %9, 0\n\t"
+                 "v_cmp_lt_f32_e64 %2, %15, %16\n\t"
+                 "v_mfma_f32_16x16x32_f16 %1, %8, %10, %1\n\t"
+                 "v_cmp_lt_f32_e64 %3, %4, %17"
+                 : "=&v"(r10), "=&v"(r11), "=&s"(h0), "=&s"(h1), "+v"(m1)
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), "a"(b1[0]), "a"(b1[1]),
+                   "v"(old.v[1][1][0]), "v"(old.v[1][1][1]), "v"(old.v[1][1][2]), "v"(old.v[1][1][3]),
+                   "v"(m0), "v"(tau0), "v"(tau1));
+    mm.m0 = m0;
+    mm.m1 = m1;
+    hit = h0 | h1;
+}
+
+// Staging of one row-block's hits (topk_lists.h: one record of 8 scores per hitting lane), with WAVE-UNIFORM control flow:
+// the record count lives in a scalar register, the only per-lane code is the record write.  When the hitting lanes do
+// not fit, the area is drained first (then it is empty and 64 lanes always fit) and the lanes look again at the
+// thresholds the drain left.
+template <typename C, int NB, int NREC>
+__device__ __forceinline__ void cstage(bool h, const f32x4 &lo, const f32x4 &hi, float m, int rb, uint32_t jb, unsigned char *w,
+                                       uint32_t &scnt, int lkeep, float (&tauv)[NB])
+{
+    uint64_t b = __builtin_amdgcn_ballot_w64(h);
+    if (b == 0) return;
+    uint32_t n = (uint32_t)__builtin_popcountll(b);
+    if (scnt + n > (uint32_t)NREC) {
+        lists_drain<C, NB>(w, scnt, lkeep, tauv);
+        scnt = 0;
+        h = h && (m < tauv[rb]);
+        b = __builtin_amdgcn_ballot_w64(h);
+        if (b == 0) return;
+        n = (uint32_t)__builtin_popcountll(b);
+    }
+    if (h) {
+        const uint32_t p = scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * C::RS);
+        rp[0] = lo;
+        rp[1] = hi;
+        C::shdr(w)[p] = make_uint2((uint32_t)(rb * C::RPB + (lane_id() & (C::RPB - 1))), jb);
+    }
+    scnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(scnt + n));
+}
+
+// Grid: x = target super-blocks (4 waves x 128 rows), y = reference splits.
+template <int KS, int EPL, int ROWN>
+__global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *__restrict__ Xpk,
+                                                          const unsigned char *__restrict__ Ypk,
+                                                          int tiles_per_split, int64_t tile_off, int lkeep,
+                                                          uint32_t *__restrict__ cand_idx,
+                                                          float *__restrict__ cand_key,
+                                                          float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg)
+{
+#ifdef NABO_EXPERIMENTS
+    const int dbg = dbg_arg;                           // timing ablations (knn_common.h: debug_ablate)
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
+    constexpr int NB = 8;                              // row-blocks of 16 targets per wave
+    constexpr int NP = NB / 2;                         // pairs
+    constexpr int NREC = L2C_NREC;
+    using C = ListCfg<EPL, ROWN, NB, NREC, 16>;
+    constexpr int TB = 2 * KS * 1024;                  // bytes per packed 32-cell tile (targets and references alike)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+    const int lane = lane_id();
+    const int lq = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int split = blockIdx.y;
+    const int S = gridDim.y;
+    const int64_t ltile0 = ((int64_t)blockIdx.x * 4 + wave) * (NB / 2);      // in 32-row tiles
+    const int64_t ttile0 = tile_off + ltile0;
+
+    f16x8 xb[NB][KS];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(Xpk + (ttile0 + (rb >> 1)) * TB);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            xb[rb][s] = p[((rb & 1) * KS + s) * 64 + lane];
+            asm volatile("" : "+a"(xb[rb][s]));        // pinned in AGPRs (l2h_topk.hip)
+        }
+    }
+    unsigned char *wl = smem_raw + (size_t)wave * C::BYTES;          // this wave's lists (topk_lists.h)
+    float tauv[NB];
+    const float tau0 = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) tauv[rb] = tau0;
+    uint32_t scnt = 0;
+    lists_init<C>(wl, lkeep, tau0);
+
+    const int t_begin = split * tiles_per_split;
+    const int t_end = t_begin + tiles_per_split;
+    // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop runs in fours
+    auto tile_ptr = [&](int ts) {
+        const int64_t tc = ts < t_end ? (int64_t)ts : pad_tile;
+        // dbg & 2 / dbg & 4 (timing experiments, garbage results): the stream wraps inside a window of 128 tiles / of 2
+        return Ypk + ((dbg & 2) ? (int64_t)(t_begin + ((ts - t_begin) & 127)) : (dbg & 4) ? (int64_t)(t_begin + ((ts - t_begin) & 1)) : tc) * TB;
+    };
+    auto tile_load = [&](f16x8(&a)[2][KS], int ts) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(tile_ptr(ts));
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[h][s] = p[(h * KS + s) * 64 + lane];
+    };
+
+    f16x8 a0[2][KS], a1[2][KS], a2[2][KS], a3[2][KS];
+    tile_load(a0, t_begin);
+    tile_load(a1, t_begin + 1);
+    tile_load(a2, t_begin + 2);
+
+    // Scores of a whole tile (NP pairs x 16 registers) stay in registers for one more step: their filter runs next to
+    // the NEXT tile's chains, on operands that were complete long before (a filter instruction that reads what the
+    // previous chain has just written costs three times one that does not: tools/coarse_lab.hip), and ONE branch per
+    // tile acts on the four verdicts (a compare-and-branch per chain costs ~37 cycles even when it falls through).
+    cacc accE[NP], accO[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) accO[p].v[r][h] = f32x4{__builtin_inff(), __builtin_inff(), __builtin_inff(), __builtin_inff()};
+
+#ifdef NABO_L2C_ABL
+    float abl_run = 1e30f;
+    int abl_cnt = 0;
+#endif
+    // chains of tile t into `cur` (set `a`; set `an` receives tile t + 3), filter of tile t - 1 (`old`) beside them
+    auto tile_step = [&](const f16x8(&a)[2][KS], f16x8(&an)[2][KS], cacc(&cur)[NP], const cacc(&old)[NP], int t) {
+        tile_load(an, t + 3);
+        cmins mm[NP];
+        uint64_t hit[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#if defined(NABO_L2C_ABL) && NABO_L2C_ABL == 1          // timing ablations (tools/ab): no filter at all
+            asm volatile("" ::"v"(old[p].v[0][0]), "v"(old[p].v[0][1]), "v"(old[p].v[1][0]), "v"(old[p].v[1][1]));
+            hit[p] = 0;
+#elif defined(NABO_L2C_ABL) && NABO_L2C_ABL == 2        // the minimum trees, no compare
+            mm[p] = cmin8x2(old[p]);
+            abl_run = fminf(abl_run, fminf(mm[p].m0, mm[p].m1));
+            hit[p] = 0;
+#elif defined(NABO_L2C_ABL) && NABO_L2C_ABL == 3        // trees + compares, verdicts folded into a register, no branch
+            mm[p] = cmin8x2(old[p]);
+            abl_cnt += ((mm[p].m0 < tauv[2 * p]) | (mm[p].m1 < tauv[2 * p + 1])) ? 1 : 0;
+            hit[p] = 0;
+#else
+            if constexpr (KS == 2 && !L2C_BUILTIN) {
+                cpair<KS>(a, xb[2 * p], xb[2 * p + 1], cur[p], old[p], tauv[2 * p], tauv[2 * p + 1], mm[p], hit[p]);
+            } else {                                    // hipcc's own schedule of builtin MFMAs (other shapes; A/B runs)
+                mm[p] = cmin8x2(old[p]);
+                hit[p] = __builtin_amdgcn_ballot_w64((mm[p].m0 < tauv[2 * p]) | (mm[p].m1 < tauv[2 * p + 1]));
+            }
+#endif
+            if constexpr (KS != 2 || L2C_BUILTIN || L2C_ABLATED) {
+                cur[p] = cchain<KS>(a, xb[2 * p], xb[2 * p + 1]);
+                // one MFMA, then at most two of the filter's instructions (what fits beside a 16-cycle MFMA)
+                L2C_SG(2) L2C_SG(2) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1)
+            }
+        }
+        if (__builtin_expect((hit[0] | hit[1] | hit[2] | hit[3]) != 0, 0)) {
+            const uint32_t jb = (uint32_t)((t - 1) * 32 + 4 * lq);           // (a padding step stages nothing)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                if (hit[p] != 0) {
+                    NABO_PROF_T0();
+                    cstage<C, NB, NREC>(mm[p].m0 < tauv[2 * p], old[p].v[0][0], old[p].v[0][1], mm[p].m0, 2 * p, jb, wl, scnt, lkeep, tauv);
+                    cstage<C, NB, NREC>(mm[p].m1 < tauv[2 * p + 1], old[p].v[1][0], old[p].v[1][1], mm[p].m1, 2 * p + 1, jb, wl, scnt, lkeep, tauv);
+                    NABO_PROF_ADD(wl, 0, 1);
+                    NABO_PROF_ADD(wl, 1, NABO_PROF_DT() >> 4);
+                }
+            }
+        }
+    };
+    static_assert(NP == 4, "four pairs per tile");
+    int t = t_begin;
+    for (; t < t_end; t += 4) {
+        tile_step(a0, a3, accE, accO, t);
+        tile_step(a1, a0, accO, accE, t + 1);
+        tile_step(a2, a1, accE, accO, t + 2);
+        tile_step(a3, a2, accO, accE, t + 3);
+    }
+#ifdef NABO_L2C_ABL
+    if (abl_run + (float)abl_cnt == 12345.0f) cand_tau[0] = abl_run;
+#endif
+    // the last step's scores (a padding step when the split's length is no multiple of four: all +inf); its MFMAs are
+    // inline assembly, so the wait states between them and the first reader are ours to insert (12 for this shape)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    {
+        const uint32_t jb = (uint32_t)((t - 1) * 32 + 4 * lq);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const cmins m = cmin8x2(accO[p]);
+            cstage<C, NB, NREC>(m.m0 < tauv[2 * p], accO[p].v[0][0], accO[p].v[0][1], m.m0, 2 * p, jb, wl, scnt, lkeep, tauv);
+            cstage<C, NB, NREC>(m.m1 < tauv[2 * p + 1], accO[p].v[1][0], accO[p].v[1][1], m.m1, 2 * p + 1, jb, wl, scnt, lkeep, tauv);
+        }
+    }
+
+    lists_flush<C, EPL, NB>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
+}
+
+template <int KS, int EPL, int ROWN>
+static hipError_t claunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                              int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                              int64_t pad_tile, hipStream_t st)
+{
+    const int dbg = debug_ablate();
+    constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, 8, L2C_NREC, 16>::BYTES;
+    static_assert(lds <= 163840, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    dim3 grid(gx, S), block(256);
+    hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
+                       cand_idx, cand_key, cand_tau, pad_tile, dbg);
+#ifdef NABO_LISTS_PROF
+    {
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(nabo_lists_prof), sizeof(h));
+        fprintf(stderr, "[lists prof, cumulative] episodes %llu (x16 cyc %llu) drains %llu (x16 cyc %llu) rounds %llu (%llu) "
+                        "records %llu appended %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    }
+#endif
+    return hipGetLastError();
+}
+
+// 512 rows per workgroup, one workgroup per CU, lists of <= 32 kept entries (l2q_topk.hip's geometry)
+void l2c_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
+{
+    (void)kc;
+    *rows_per_wg = 4 * 128;
+    *wg_per_cu = 1;
+    *lkeep_max = L2C_ROW < 32 ? L2C_ROW : 32;
+}
+
+// steps of 16 slots of the one-product operands (g components + two norm slots + the error slot), even (KS = kc / 2
+// steps of 32 slots), instantiated values only
+int l2c_pick_kc(int g)
+{
+    const int need = 2 * ((g + 3 + 31) / 32);
+    return need <= 6 ? need : -1;
+}
+
+// The split's padding must cover the ring: the kernel reads tiles up to t_end + 3 (as pad_tile) -- all of them are the
+// caller's padding tile, never past the allocation.
+hipError_t l2c_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           int64_t pad_tile, hipStream_t st)
+{
+    switch (kc) {
+    case 2: return claunch_one<1, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
+    case 4: return claunch_one<2, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
+    case 6: return claunch_one<3, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace nabo

@@ -93,7 +93,7 @@ template <typename C, int EPL, int NB, int NREC>
 __device__ __forceinline__ void qfilter_stage(const qacc &acc, const qverdict &v, int rb0, uint32_t jb, unsigned char *w,
                                               uint32_t &scnt, int lkeep, float (&tauv)[NB])
 {
-    if (v.any != 0) {
+    if (__builtin_expect(v.any != 0, 0)) {          // (unlikely: the staging code goes out of line, the common path falls through)
         NABO_PROF_T0();
         float s0[8], s1[8];
 #pragma unroll
@@ -302,6 +302,14 @@ void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
     *rows_per_wg = 4 * 128;
     *wg_per_cu = 1;
     *lkeep_max = L2Q_ROW < 32 ? L2Q_ROW : 32;
+}
+
+// steps of 16 slots of the one-product operands (g components + two norm slots + the error slot), even (KS = KC / 2
+// steps of 32 slots), instantiated values only
+int l2q_pick_kc1(int g)
+{
+    const int need = 2 * ((g + 3 + 31) / 32);
+    return need <= 12 ? need : -1;
 }
 
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,

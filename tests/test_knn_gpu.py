@@ -413,15 +413,16 @@ def test_zero_target_rows_is_a_no_op(gpu_lib):
                                           (2000, 30000, 30, 20, True), (130, 5000, 64, 30, False),
                                           (64, 3000, 100, 11, False)])
 def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
-    """The Euclidean filter runs on the f16 matrix pipe (f16x3 split, the default where it is instantiated:
-    g < 64 and k + drop + 4 <= 32; three kernels: 16x16x32 MFMA shape = default, 32x32x16 per-wave, 32x32x16 with shared
-    LDS tiles) or on the fp32 MFMA (everything else, or NABO_L2_MODE=f32): the float64 refine + certification make all
-    of them return exactly what the oracle does."""
+    """The Euclidean filter runs on the f16 matrix pipe -- the one-product first pass (l2c_topk.hip, the default where it
+    is instantiated: g < 64 and k + drop + 4 <= 32; rows it cannot certify go through the f16x3 pass), the f16x3 split as the
+    first pass (NABO_L2_MODE=f16x3; three kernels: 16x16x32 MFMA shape, 32x32x16 per-wave, 32x32x16 with shared LDS tiles) --
+    or on the fp32 MFMA (everything else, or NABO_L2_MODE=f32): the float64 refine + certification make all of them
+    return exactly what the oracle does."""
     Y = pca_like(n, g, seed=1000 + n + g)
     X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
     oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
     kernels = {}
-    for mode in ("f16x3", "f16x3h", "f16x3q", "f16x3s", "f32", None):
+    for mode in ("f16x1", "f16x1h", "f16x3", "f16x3h", "f16x3q", "f16x3s", "f32", None):
         if mode:
             os.environ["NABO_L2_MODE"] = mode
         try:
@@ -435,7 +436,7 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
         _check(gi, gd, oi, od)
         assert st["fallback_rows"] == 0
     assert "l2_topk_kernel" in kernels["f32"]
-    assert kernels[None] == kernels["f16x3"]                       # f16x3 is the default
+    assert kernels[None] == kernels["f16x1"]                       # the one-product first pass is the default
     # per-wave kernel (l2h) for g < 64 and k' + 4 <= 32; shared-tile kernel (l2s) for g <= 52 and k' + 4 <= 28
     kk = k + drop
     h_ok, s_ok = (g < 64 and kk + 4 <= 32), (g <= 52 and kk + 4 <= 28)
@@ -443,6 +444,8 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     assert kernels["f16x3s"].startswith("l2s_topk" if (g <= 52 and kk + 4 <= 24) else ("l2h_topk", "l2_topk")), kernels
     assert kernels["f16x3q"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels          # 16x16x32 MFMA shape
     assert kernels["f16x3"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels                 # the default f16x3 kernel
+    assert kernels["f16x1"].startswith("l2c_topk" if h_ok else "l2_topk") and ("one-product" in kernels["f16x1"]) == h_ok, kernels
+    assert kernels["f16x1h"].startswith("l2h_topk" if h_ok else "l2_topk") and ("one-product" in kernels["f16x1h"]) == h_ok, kernels
 
 
 @pytest.mark.parametrize("flags", ["7", "3", "1", "2"])
