@@ -42,7 +42,7 @@ int l2q_pick_kc1(int g);
 // the one-product first pass (l2c_topk.hip; operands packed with layout16, nseg = 1)
 hipError_t l2c_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st);
+                           int64_t pad_tile, hipStream_t st, int64_t rows_valid);
 int l2c_pick_kc(int g);
 // the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
@@ -267,6 +267,7 @@ struct nabo_index {
     // query workspace
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
     DevBuf xfail1, tmpi1, tmpd1, fails1;      // the same for the f16x3 pass behind the one-product pass (the passes nest)
+    int cand_slack = 3;                       // candidate mode on the one-product pass: kept entries beyond the emitted ones
     int64_t pass_rows[2] = {0, 0};            // rows of the last query sent to the f16x3 pass / to the 64-entry lists
     float ms_keep[3] = {0, 0, 0};
     double ms_inner = 0.0;         // total of the most recent query_impl (read by the outer call of a retry)
@@ -296,6 +297,7 @@ int64_t index_n(const nabo_index *ix) { return ix->n; }
 int index_metric(const nabo_index *ix) { return ix->metric; }
 bool index_can_emit_candidates(const nabo_index *ix) { return ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0; }
 void index_set_shard_mode(nabo_index *ix, bool on) { ix->shard_mode = on; }
+void index_set_cand_slack(nabo_index *ix, int s) { ix->cand_slack = s < 0 ? 0 : s; }
 }  // namespace nabo
 
 // Entries of the masked-reference list a row may continue with when it has fewer than k' unmasked references
@@ -742,7 +744,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
         // the one-product first pass (l2q kernel, kc1-step operands); see nabo_index::coarse
-        const bool use_1 = use_h && !use_c && ix->coarse && !ix->no_coarse && !ix->wide_retry && !cand_mode;
+        const bool use_1 = use_h && !use_c && ix->coarse && !ix->no_coarse && !ix->wide_retry &&
+                           (!cand_mode || kk + 3 <= lkeep_max);
         const int kcq = use_1 ? ix->kc1 : ix->kc;
         if (!ix->no_coarse && !ix->wide_retry) ix->pass_rows[0] = ix->pass_rows[1] = 0;
         // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
@@ -788,10 +791,14 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         int lkeep = kk + 8;
         if (lkeep < 16) lkeep = 16;
         if (ix->wide_retry) lkeep = lkeep_max;              // as many kept entries as the 64-entry lists allow
-        // one-product pass: its scores sit up to 2^-9 ||x|| ||y|| below the real ones, the gap above the k'-th distance
-        // has to cover that (1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass, k' + 17 almost none)
-        if (use_1) lkeep = kk + 8 + env_int("NABO_COARSE_SLACK", 5);
+        // one-product pass: its scores sit up to 2^-9 ||x|| ||y|| below the real ones and the gap above the k'-th distance
+        // has to cover that -- 1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass (7 ms), k' + 13 a
+        // third of that, but every five entries more cost 14 ms of list updates in the kernel: no extra slack by default
+        if (use_1) lkeep = kk + 8 + env_int("NABO_COARSE_SLACK", 0);
         if (cand_mode) lkeep = kk < 4 ? 4 : kk;
+        // (candidate mode on the one-product pass: three kept entries more than are emitted, so that the bound is the exact
+        // distance of the first candidate left out and not the one-product threshold, which sits 2^-9 ||x|| ||y|| lower)
+        if (cand_mode && use_1) lkeep += env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack);
         if (lkeep > lkeep_max) lkeep = lkeep_max;
         { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }   // experiments
         // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
@@ -896,11 +903,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 if (gx_main > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
                                                   ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
-                                                  ix->ref_tiles_alloc - 1, st));
+                                                  ix->ref_tiles_alloc - 1, st, m));
                 if (gx_tail > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
                                                   rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
-                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st));
+                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m));
             } else {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2q_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,

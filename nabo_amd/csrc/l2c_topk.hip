@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
                                                           uint32_t *__restrict__ cand_idx,
                                                           float *__restrict__ cand_key,
-                                                          float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg)
+                                                          float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg,
+                                                          int64_t rows_valid)
 {
 #ifdef NABO_EXPERIMENTS
     const int dbg = dbg_arg;                           // timing ablations (knn_common.h: debug_ablate)
@@ -207,10 +208,20 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
     unsigned char *wl = smem_raw + (size_t)wave * C::BYTES;          // this wave's lists (topk_lists.h)
     float tauv[NB];
     const float tau0 = (dbg & 1) ? -__builtin_inff() : __builtin_inff();
+    // Padding rows (beyond the query's last row; a 1-row query still is a 512-row workgroup) start from threshold -inf:
+    // nothing ever passes, so they cost no list work -- their operands are finite (pack_ctiles_kernel<.,.,1>) and would
+    // otherwise fill and refine lists like any row: 1.5 ms for a one-row query over 125k references, ~0.1 ms without.
+    const int64_t row0 = ttile0 * 32;                    // first row of the wave (position in the query)
 #pragma unroll
-    for (int rb = 0; rb < NB; ++rb) tauv[rb] = tau0;
+    for (int rb = 0; rb < NB; ++rb) tauv[rb] = (row0 + rb * 16 + (lane & 15)) < rows_valid ? tau0 : -__builtin_inff();
     uint32_t scnt = 0;
     lists_init<C>(wl, lkeep, tau0);
+    {
+        const int64_t nv = rows_valid - row0;            // valid rows of this wave
+        if (nv < C::NROWS)
+            for (int r = lane; r < C::NROWS; r += 64)
+                if (r >= nv) C::tauL(wl)[r] = -__builtin_inff();
+    }
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
 template <int KS, int EPL, int ROWN>
 static hipError_t claunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              int64_t pad_tile, hipStream_t st)
+                              int64_t pad_tile, hipStream_t st, int64_t rows_valid)
 {
     const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, 8, L2C_NREC, 16>::BYTES;
@@ -335,7 +346,7 @@ static hipError_t claunch_one(const unsigned char *Xpk, const unsigned char *Ypk
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(256);
     hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
-                       cand_idx, cand_key, cand_tau, pad_tile, dbg);
+                       cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid);
 #ifdef NABO_LISTS_PROF
     {
         unsigned long long h[8];
@@ -369,12 +380,12 @@ int l2c_pick_kc(int g)
 // caller's padding tile, never past the allocation.
 hipError_t l2c_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st)
+                           int64_t pad_tile, hipStream_t st, int64_t rows_valid)
 {
     switch (kc) {
-    case 2: return claunch_one<1, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
-    case 4: return claunch_one<2, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
-    case 6: return claunch_one<3, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st);
+    case 2: return claunch_one<1, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid);
+    case 4: return claunch_one<2, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid);
+    case 6: return claunch_one<3, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid);
     default: return hipErrorInvalidValue;
     }
 }

@@ -71,6 +71,7 @@ int64_t index_n(const nabo_index *ix);
 int index_metric(const nabo_index *ix);
 bool index_can_emit_candidates(const nabo_index *ix);
 void index_set_shard_mode(nabo_index *ix, bool on);
+void index_set_cand_slack(nabo_index *ix, int s);
 }  // namespace nabo
 
 namespace {
@@ -867,6 +868,11 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
                                c->ci.as<int64_t>() + ms * Ls, c->cd.as<double>() + ms * Ls, nx, c->cb.as<double>() + ms, ms_pad - ms);
             if (hipGetLastError() != hipSuccess) rc = api_fail(NABO_E_HIP, "fill_absent_kernel launch failed");
         }
+        // One-product first pass (api.hip): with few pieces a shard's Ls-th candidate is close to the global k'-th, and the
+        // certificate needs the exact distance of the first candidate left out, not the one-product threshold (three
+        // kept entries more than emitted); with many pieces it lies far beyond it and the shorter lists win (one rank of
+        // eight: 25 instead of 32 ms, one refused row at 1M x 1M).
+        nabo::index_set_cand_slack(ix, Ls >= kk ? 3 : 0);
         if (!rc && ms > 0)
             rc = nabo_index_query_candidates(ix, X + s0 * g, 1, ms, Ls, c->ci.as<int64_t>(), c->cd.as<double>(), c->cb.as<double>());
     } else {
