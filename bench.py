@@ -209,7 +209,7 @@ class Layout:
 
     def rank_stats(self):
         """mean over the timed steps, per rank: this process' ranks, or (launcher) the MAX over all ranks through RCCL"""
-        keys_i = ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")
+        keys_i = ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total", "seeded_pass_rows", "second_pass_rows", "wide_list_rows")
         keys_x = ("ms_local", "ms_topk_local", "ms_exchange", "ms_merge", "ms_second", "ms_gather", "ms_total")
         per = []
         for r in range(len(self.stats[0])):

@@ -128,12 +128,13 @@ int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4
  * launch logic picked -- the f16x3 split on the f16 matrix pipe (default where instantiated: g < 64 and
  * k + drop_first <= 28), the fp32-MFMA kernel (NABO_L2_MODE=f32 pins it), the Canberra filter, or the exact kernels. */
 int nabo_index_last_kernel(const nabo_index *ix, char *buf, size_t n);
-/* Rows of the LAST query that the first filter pass could not certify: rows[0] went through the f16x3 pass behind the
- * one-product first pass (the default Euclidean / cosine filter for g < 62, k + drop_first <= 28; NABO_L2_MODE=f16x3
- * makes the f16x3 filter the first pass), rows[1] through the 64-entry lists; what is left after both is
- * counters[0] of nabo_index_last_stats (exact float64 kernels).  Results are the same bits whichever pass answers
- * a row (the reference has one float64 path: nabo/_mapping.py:16-26). */
-int nabo_index_last_passes(const nabo_index *ix, int64_t rows[2]);
+/* Rows of the LAST query that a filter pass could not certify, by the pass they went on to: rows[0] the SEEDED
+ * one-product pass (every row starts from the threshold its failed certificate implies), rows[1] the f16x3 pass, rows[2]
+ * the 64-entry lists; what is left after all of them is counters[0] of nabo_index_last_stats (exact float64 kernels).
+ * The default Euclidean / cosine filter for g < 64 and k + drop_first <= 28 starts with the one-product pass;
+ * NABO_L2_MODE=f16x3 makes the f16x3 filter the first pass.  Results are the same bits whichever pass answers a row
+ * (the reference has one float64 path: nabo/_mapping.py:16-26). */
+int nabo_index_last_passes(const nabo_index *ix, int64_t rows[3]);
 
 /* ---- shard merge (reference rows sharded over GPUs) ---------------
  * parts_idx / parts_dist: [n_parts, m, kp] DEVICE arrays, each row sorted by the canonical

@@ -110,11 +110,11 @@ class KnnIndex:
         ms = (C.c_double * 5)()
         cn = (C.c_int64 * 4)()
         _lib.check(_lib.lib().nabo_index_last_stats(self._h, ms, cn))
-        ps = (C.c_int64 * 2)()
+        ps = (C.c_int64 * 3)()
         _lib.check(_lib.lib().nabo_index_last_passes(self._h, ps))
         return {"ms_pack": ms[0], "ms_topk": ms[1], "ms_refine": ms[2], "ms_fallback": ms[3], "ms_total": ms[4],
                 "fallback_rows": int(cn[0]), "splits": int(cn[1]), "list_len": int(cn[2]), "workgroups": int(cn[3]),
-                "second_pass_rows": int(ps[0]), "wide_list_rows": int(ps[1])}
+                "seeded_pass_rows": int(ps[0]), "second_pass_rows": int(ps[1]), "wide_list_rows": int(ps[2])}
 
     def last_kernel(self):
         """name of the dominant kernel the last query ran (which filter the launch logic picked)"""

@@ -40,10 +40,12 @@ hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *c
                               const uint32_t *perm = nullptr, int nseg = 3);
 int l2q_pick_kc1(int g);
 // the one-product first pass (l2c_topk.hip; operands packed with layout16, nseg = 1)
-hipError_t l2c_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
-                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st, int64_t rows_valid);
+hipError_t l2c_topk_launch(int kc, bool geo_b, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                           int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init);
 int l2c_pick_kc(int g);
+bool l2c_geometry_b(int kc, int lkeep_want);
+void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 // the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
@@ -68,7 +70,7 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          int n_masked_list, int64_t *out_idx, double *out_dist, uint32_t *fail_rows,
                          unsigned int *fail_count, hipStream_t st, int metric = 0, double cb_f = 0.0,
                          float cb_plateau = 0.0f, int lvalid = 0, const uint32_t *rperm = nullptr,
-                         const uint32_t *tperm = nullptr);
+                         const uint32_t *tperm = nullptr, float *fail_seed = nullptr);
 hipError_t refine_cand_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
                               const float *cand_tau, int S, int L, const double *xnorm, double err_coef,
                               double ymax_sqrt, double tau_scale, int kout, int64_t base, int64_t n_valid_total,
@@ -240,8 +242,13 @@ struct nabo_index {
     bool q16 = false;              // l2q_topk.hip (16x16x32 MFMA shape; operands in the layout16 packing)
     // One-product first pass (l2q kernel on [hi | norm | error] operands of kc1 steps, pack_ctiles_kernel<.,.,1>): rows it
     // cannot certify go through the f16x3 pass (no_coarse), then the 64-entry lists, then the exact kernels.
+    // Passes of a query, each on the rows the one before could not certify (pass_level while query_impl recurses):
+    //   0  one-product pass, lists built from +inf;  1  one-product pass SEEDED with the thresholds refine.hip derived
+    //   from the failed certificates (l2c kernel only; 32-entry lists);  2  the f16x3 pass;  then the 64-entry lists
+    //   (wide_retry) and the exact float64 kernels.
     bool coarse = false;
-    bool no_coarse = false;        // inside the f16x3 pass of the rows the one-product pass could not certify
+    int pass_level = 0;
+    const float *seed_tau = nullptr;      // level 1: one threshold per row of the batch
     int kc1 = 0;
     double hscale = 1.0;
     double fscale = 1.0;           // power-of-two input scale of the fp32 path: max |y~| * fscale in (1/2, 1]
@@ -266,9 +273,9 @@ struct nabo_index {
 
     // query workspace
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
-    DevBuf xfail1, tmpi1, tmpd1, fails1;      // the same for the f16x3 pass behind the one-product pass (the passes nest)
+    DevBuf xfailp[2], tmpip[2], tmpdp[2], failsp[2], seedp[2], failseed;      // the same for passes 1 and 2 (the passes nest)
     int cand_slack = 3;                       // candidate mode on the one-product pass: kept entries beyond the emitted ones
-    int64_t pass_rows[2] = {0, 0};            // rows of the last query sent to the f16x3 pass / to the 64-entry lists
+    int64_t pass_rows[3] = {0, 0, 0};         // rows of the last query sent to the seeded pass / the f16x3 pass / the 64-entry lists
     float ms_keep[3] = {0, 0, 0};
     double ms_inner = 0.0;         // total of the most recent query_impl (read by the outer call of a retry)
     bool ms_keep_valid = false;
@@ -744,10 +751,21 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
         // the one-product first pass (l2q kernel, kc1-step operands); see nabo_index::coarse
-        const bool use_1 = use_h && !use_c && ix->coarse && !ix->no_coarse && !ix->wide_retry &&
+        const bool use_1 = use_h && !use_c && ix->coarse && ix->pass_level < 2 && !ix->wide_retry &&
                            (!cand_mode || kk + 3 <= lkeep_max);
         const int kcq = use_1 ? ix->kc1 : ix->kc;
-        if (!ix->no_coarse && !ix->wide_retry) ix->pass_rows[0] = ix->pass_rows[1] = 0;
+        // ... on the l2c kernel (unless the locality order or an A/B run sends its operands through the l2q kernel), in one
+        // of two geometries by the list length the pass wants (l2c_topk.hip: two waves per SIMD up to 23 kept entries)
+        const bool on_l2c = use_1 && ix->q16 && ix->order_flags == 0 && env_int("NABO_COARSE_KERNEL_Q", 0) == 0;
+        bool geo_b = false;
+        if (on_l2c) {
+            int want = cand_mode ? (kk < 4 ? 4 : kk) + env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack)
+                                 : kk + 8 + env_int("NABO_COARSE_SLACK", 0);
+            if (ix->pass_level == 1) want = 32;
+            geo_b = nabo::l2c_geometry_b(kcq, want);
+            nabo::l2c_topk_geometry(kcq, want, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        }
+        if (ix->pass_level == 0 && !ix->wide_retry) ix->pass_rows[0] = ix->pass_rows[1] = ix->pass_rows[2] = 0;
         // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
         // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
         bool r1 = false;
@@ -770,11 +788,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             }
         }
         const int epl_launch = r1 ? -1 : epl;
-        if (!ix->wide_retry && !ix->no_coarse) {
+        if (!ix->wide_retry && ix->pass_level == 0) {
             // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
-            if (use_1 && ix->q16 && (ix->order_flags != 0 || env_int("NABO_COARSE_KERNEL_Q", 0) != 0))
+            if (use_1 && ix->q16 && !on_l2c)
                 snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq);
-            else if (use_1 && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2c_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2);
+            else if (use_1 && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2c_topk_kernel<%d,1,%s> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2, geo_b ? "23,6,32,8" : "33,8,64,4");
             else if (use_1) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, one-product f16 filter with the split error as an operand slot)", kcq);
             else if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
             else if (use_h && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, K-concatenated f16x3 split)", ix->kc);
@@ -795,6 +813,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // has to cover that -- 1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass (7 ms), k' + 13 a
         // third of that, but every five entries more cost 14 ms of list updates in the kernel: no extra slack by default
         if (use_1) lkeep = kk + 8 + env_int("NABO_COARSE_SLACK", 0);
+        if (use_1 && ix->pass_level == 1) lkeep = lkeep_max;       // seeded pass: room for everything below the seed
         if (cand_mode) lkeep = kk < 4 ? 4 : kk;
         // (candidate mode on the one-product pass: three kept entries more than are emitted, so that the bound is the exact
         // distance of the first candidate left out and not the one-product threshold, which sits 2^-9 ||x|| ||y|| lower)
@@ -885,6 +904,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(nabo::pack_query_launch(dXp, m, g, ix->centre.as<double>(), ix->fscale, ix->ksteps, rows_pad / 32,
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
         HIP_TRY(hipEventRecord(ix->ev[1], st));
+        bool seedable = false;               // the l2c kernel ran: its failed rows can go through a seeded pass
         if (use_c) {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2s_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(), (int)tps, S,
@@ -897,17 +917,18 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         } else if (use_h && ix->q16) {
             const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
             // the l2q kernel on the one-product operands: A/B runs, and the locality-ordered stream (its home pre-pass)
-            static const bool coarse_on_q_env = env_int("NABO_COARSE_KERNEL_Q", 0) != 0;
-            const bool coarse_on_q = coarse_on_q_env || ix->order_flags != 0;
+            const bool coarse_on_q = !on_l2c;
+            seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0;
+            const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             if (use_1 && !coarse_on_q) {
                 if (gx_main > 0)
-                    HIP_TRY(nabo::l2c_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
+                    HIP_TRY(nabo::l2c_topk_launch(kcq, geo_b, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
                                                   ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
-                                                  ix->ref_tiles_alloc - 1, st, m));
+                                                  ix->ref_tiles_alloc - 1, st, m, seeds));
                 if (gx_tail > 0)
-                    HIP_TRY(nabo::l2c_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
+                    HIP_TRY(nabo::l2c_topk_launch(kcq, geo_b, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
                                                   rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
-                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m));
+                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m, seeds));
             } else {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2q_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,
@@ -987,43 +1008,61 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             ix->counters[3] = gx_main * S + gx_tail * S2;
             return NABO_OK;
         }
+        float *fail_seed = nullptr;          // seeds for a seeded pass of the rows that fail (pass 0 on the l2c kernel)
+        if (seedable && ix->pass_level == 0) {
+            if ((rc = ix->failseed.reserve((size_t)m * sizeof(float)))) return rc;
+            fail_seed = ix->failseed.as<float>();
+        }
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f,
-                                    lkeep, rperm, tperm));
+                                    lkeep, rperm, tperm, fail_seed));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
-                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep, rperm, tperm));
+                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep, rperm, tperm,
+                                        fail_seed));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         float ms_first[3] = {0, 0, 0};
         bool retried = false;
         if (use_1 && n_fail > 0) {
-            // Rows the one-product pass could not certify: the f16x3 pass solves them as a dense batch (this very
-            // function with no_coarse set; it sends what IT cannot certify on to the 64-entry lists / the exact kernels).
+            // Rows this one-product pass could not certify go on as a dense batch through this very function at the next
+            // level: from level 0 on the l2c kernel to the SEEDED one-product pass (level 1: every row starts from the
+            // threshold refine.hip derived from its failed certificate), otherwise to the f16x3 pass (level 2), which
+            // sends what IT cannot certify on to the 64-entry lists / the exact kernels.
             for (int i = 0; i < 3; ++i) HIP_TRY(hipEventElapsedTime(&ms_first[i], ix->ev[i], ix->ev[i + 1]));
             const int64_t nf = n_fail;
-            if ((rc = ix->fails1.reserve((size_t)nf * sizeof(uint32_t)))) return rc;
-            if ((rc = ix->xfail1.reserve((size_t)nf * g * sizeof(double)))) return rc;
-            if ((rc = ix->tmpi1.reserve((size_t)nf * k * sizeof(int64_t)))) return rc;
-            if ((rc = ix->tmpd1.reserve((size_t)nf * k * sizeof(double)))) return rc;
-            HIP_TRY(hipMemcpyAsync(ix->fails1.p, ix->fails.p, (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-            HIP_TRY(nabo::gather_rows_launch(dX, ix->fails1.as<uint32_t>(), nf, g, ix->xfail1.as<double>(), st));
+            const int here = ix->pass_level;
+            const int next = (here == 0 && fail_seed) ? 1 : 2;
+            const int b = here;                              // buffer set of this frame (levels 0 and 1 recurse from here)
+            if ((rc = ix->failsp[b].reserve((size_t)nf * sizeof(uint32_t)))) return rc;
+            if ((rc = ix->xfailp[b].reserve((size_t)nf * g * sizeof(double)))) return rc;
+            if ((rc = ix->tmpip[b].reserve((size_t)nf * k * sizeof(int64_t)))) return rc;
+            if ((rc = ix->tmpdp[b].reserve((size_t)nf * k * sizeof(double)))) return rc;
+            HIP_TRY(hipMemcpyAsync(ix->failsp[b].p, ix->fails.p, (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            if (next == 1) {
+                if ((rc = ix->seedp[b].reserve((size_t)nf * sizeof(float)))) return rc;
+                HIP_TRY(hipMemcpyAsync(ix->seedp[b].p, fail_seed, (size_t)nf * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+            HIP_TRY(nabo::gather_rows_launch(dX, ix->failsp[b].as<uint32_t>(), nf, g, ix->xfailp[b].as<double>(), st));
             HIP_TRY(hipStreamSynchronize(st));
-            ix->no_coarse = true;
-            rc = query_impl(ix, ix->xfail1.as<double>(), 1, nf, k, drop_first, ix->tmpi1.as<int64_t>(), ix->tmpd1.as<double>(), 1,
-                            false, nullptr);
-            ix->no_coarse = false;
+            const float *seed_saved = ix->seed_tau;
+            ix->pass_level = next;
+            ix->seed_tau = next == 1 ? ix->seedp[b].as<float>() : nullptr;
+            rc = query_impl(ix, ix->xfailp[b].as<double>(), 1, nf, k, drop_first, ix->tmpip[b].as<int64_t>(),
+                            ix->tmpdp[b].as<double>(), 1, false, nullptr);
+            ix->pass_level = here;
+            ix->seed_tau = seed_saved;
             if (rc) return rc;
-            ix->pass_rows[0] = nf;
+            ix->pass_rows[next - 1] = nf;
             n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
-            HIP_TRY(nabo::scatter_rows_launch(ix->tmpi1.as<int64_t>(), ix->tmpd1.as<double>(), ix->fails1.as<uint32_t>(), nf, k,
-                                              d_oidx, d_odist, st));
+            HIP_TRY(nabo::scatter_rows_launch(ix->tmpip[b].as<int64_t>(), ix->tmpdp[b].as<double>(), ix->failsp[b].as<uint32_t>(),
+                                              nf, k, d_oidx, d_odist, st));
             HIP_TRY(hipEventRecord(ix->ev[3], st));          // (ev[0..5] were reused by the inner call)
             retried = true;
         } else if (n_fail >= 16 && epl == 1 && !ix->wide_retry && env_int("NABO_WIDE_RETRY", 1) != 0) {
@@ -1045,7 +1084,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                             false, nullptr);
             ix->wide_retry = false;
             if (rc) return rc;
-            ix->pass_rows[1] = nf;
+            ix->pass_rows[2] = nf;
             n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
             HIP_TRY(nabo::scatter_rows_launch(ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), ix->fails2.as<uint32_t>(), nf, k,
                                               d_oidx, d_odist, st));
@@ -1297,11 +1336,12 @@ int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4
     return NABO_OK;
 }
 
-int nabo_index_last_passes(const nabo_index *ix, int64_t rows[2])
+int nabo_index_last_passes(const nabo_index *ix, int64_t rows[3])
 {
     if (!ix || !rows) return fail(NABO_E_INVALID, "NULL argument");
     rows[0] = ix->pass_rows[0];
     rows[1] = ix->pass_rows[1];
+    rows[2] = ix->pass_rows[2];
     return NABO_OK;
 }
 

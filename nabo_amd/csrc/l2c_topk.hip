@@ -46,8 +46,15 @@ constexpr bool L2C_ABLATED = true;
 #else
 constexpr bool L2C_ABLATED = false;
 #endif
-constexpr int L2C_NREC = 64;        // staging records (8 scores each) per wave
-constexpr int L2C_ROW = 33;         // list entries per row (odd)
+// Two geometries (claunch_one):
+//   A  one wave per SIMD: 4 waves x 128 rows, lists of <= 32 kept entries (33-entry rows), 64 staging records;
+//   B  TWO waves per SIMD: 8 waves x 96 rows, lists of <= 23 kept entries (23-entry rows: k' + 8 at k' = 15), 32 staging
+//      records -- 8 x 20 096 bytes of LDS.  While one wave of a SIMD stages hits or drains its lists, the other one's
+//      MFMAs keep the matrix pipe busy; the price is 8 x 4 KB of tile per 24 MFMAs instead of 4 x 4 KB per 32.
+constexpr int L2C_NREC = 64;        // staging records (8 scores each) per wave, geometry A
+constexpr int L2C_ROW = 33;         // list entries per row (odd), geometry A
+constexpr int L2C_NREC_B = 32;
+constexpr int L2C_ROW_B = 23;
 
 struct cacc { f32x4 v[2][2]; };     // [row-block of the pair][reference half]
 #define L2C_SG(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
@@ -92,7 +99,35 @@ __device__ __forceinline__ cmins cmin8x2(const cacc &acc)
 // tile) cost 11 ms of 87 at 1M x 1M.  What inline assembly MFMAs need (cdna_hip_programming.md, inline assembly, item 2):
 // D -> next MFMA taking it whole as C: nothing; D -> any other reader: 12 wait states -- every reader here is a tile
 // later, and the code after the loop pads explicitly; "=&v": D never overlaps an A operand whose last use this is.
-template <int KS>
+#define L2C_PAIR_STATEMENTS(BC) \
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %8, 0\n\t" \
+                 "v_min_f32 %2, %10, %11\n\t" \
+                 "v_min3_f32 %2, %2, %12, %13\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %5, %9, %0\n\t" \
+                 "v_min3_f32 %2, %2, %14, %15\n\t" \
+                 "v_min3_f32 %2, %2, %16, %17\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %6, %8, 0\n\t" \
+                 "v_min_f32 %3, %18, %19\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %7, %9, %1\n\t" \
+                 "v_min3_f32 %3, %3, %20, %21" \
+                 : "=&v"(r00), "=&v"(r01), "=&v"(m0), "=&v"(m1) \
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), BC(b0[0]), BC(b0[1]), \
+                   "v"(old.v[0][0][0]), "v"(old.v[0][0][1]), "v"(old.v[0][0][2]), "v"(old.v[0][0][3]), \
+                   "v"(old.v[0][1][0]), "v"(old.v[0][1][1]), "v"(old.v[0][1][2]), "v"(old.v[0][1][3]), \
+                   "v"(old.v[1][0][0]), "v"(old.v[1][0][1]), "v"(old.v[1][0][2]), "v"(old.v[1][0][3])); \
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %5, %9, 0\n\t" \
+                 "v_min3_f32 %4, %4, %11, %12\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %6, %10, %0\n\t" \
+                 "v_min3_f32 %4, %4, %13, %14\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %7, %9, 0\n\t" \
+                 "v_cmp_lt_f32_e64 %2, %15, %16\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %8, %10, %1\n\t" \
+                 "v_cmp_lt_f32_e64 %3, %4, %17" \
+                 : "=&v"(r10), "=&v"(r11), "=&s"(h0), "=&s"(h1), "+v"(m1) \
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), BC(b1[0]), BC(b1[1]), \
+                   "v"(old.v[1][1][0]), "v"(old.v[1][1][1]), "v"(old.v[1][1][2]), "v"(old.v[1][1][3]), \
+                   "v"(m0), "v"(tau0), "v"(tau1));
+template <int KS, bool BAGPR>
 __device__ __forceinline__ void cpair(const f16x8 (&a)[2][KS], const f16x8 (&b0)[KS], const f16x8 (&b1)[KS], cacc &cur,
                                       const cacc &old, float tau0, float tau1, cmins &mm, uint64_t &hit)
 {
@@ -103,76 +138,60 @@ __device__ __forceinline__ void cpair(const f16x8 (&a)[2][KS], const f16x8 (&b0)
     // Two statements of four MFMAs, each MFMA followed by its share of the filter (<= 2 instructions: what fits beside 16
     // matrix cycles).  Inside a statement nothing is padded and nothing needs to be: the filter's instructions depend on
     // each other only (vector-ALU interlocks), never on an MFMA of this tile.
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %8, 0\n\t"
-                 "v_min_f32 %2, %10, %11\n\t"
-                 "v_min3_f32 %2, %2, %12, %13\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %5, %9, %0\n\t"
-                 "v_min3_f32 %2, %2, %14, %15\n\t"
-                 "v_min3_f32 %2, %2, %16, %17\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %6, %8, 0\n\t"
-                 "v_min_f32 %3, %18, %19\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %7, %9, %1\n\t"
-                 "v_min3_f32 %3, %3, %20, %21"
-                 : "=&v"(r00), "=&v"(r01), "=&v"(m0), "=&v"(m1)
-                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), "a"(b0[0]), "a"(b0[1]),
-                   "v"(old.v[0][0][0]), "v"(old.v[0][0][1]), "v"(old.v[0][0][2]), "v"(old.v[0][0][3]),
-                   "v"(old.v[0][1][0]), "v"(old.v[0][1][1]), "v"(old.v[0][1][2]), "v"(old.v[0][1][3]),
-                   "v"(old.v[1][0][0]), "v"(old.v[1][0][1]), "v"(old.v[1][0][2]), "v"(old.v[1][0][3]));
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %5, %9, 0\n\t"
-                 "v_min3_f32 %4, %4, %11, %12\n\t"
-                 "v_mfma_f32_16x16x32_f16 %0, %6, %10, %0\n\t"
-                 "v_min3_f32 %4, %4, %13, %14\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %7, %9, 0\n\t"
-                 "v_cmp_lt_f32_e64 %2, %15, %16\n\t"
-                 "v_mfma_f32_16x16x32_f16 %1, %8, %10, %1\n\t"
-                 "v_cmp_lt_f32_e64 %3, %4, %17"
-                 : "=&v"(r10), "=&v"(r11), "=&s"(h0), "=&s"(h1), "+v"(m1)
-                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), "a"(b1[0]), "a"(b1[1]),
-                   "v"(old.v[1][1][0]), "v"(old.v[1][1][1]), "v"(old.v[1][1][2]), "v"(old.v[1][1][3]),
-                   "v"(m0), "v"(tau0), "v"(tau1));
+    // (BAGPR: the B operands are pinned in AGPRs -- one wave per SIMD; at two waves per SIMD they stay in arch VGPRs, see
+    // the kernel: with AGPRs in play hipcc parks accumulators there and copies them right behind these statements)
+    if constexpr (BAGPR) {
+        L2C_PAIR_STATEMENTS("a")
+    } else {
+        L2C_PAIR_STATEMENTS("v")
+    }
     mm.m0 = m0;
     mm.m1 = m1;
     hit = h0 | h1;
 }
 
 // Staging of one row-block's hits (topk_lists.h: one record of 8 scores per hitting lane), with WAVE-UNIFORM control flow:
-// the record count lives in a scalar register, the only per-lane code is the record write.  When the hitting lanes do
-// not fit, the area is drained first (then it is empty and 64 lanes always fit) and the lanes look again at the
-// thresholds the drain left.
+// the record count lives in a scalar register, the only per-lane code is the record write.  Lanes that do not fit wait
+// for a drain and then look again at the thresholds it left (NREC may be smaller than a wave: up to 64 lanes hit at once).
 template <typename C, int NB, int NREC>
 __device__ __forceinline__ void cstage(bool h, const f32x4 &lo, const f32x4 &hi, float m, int rb, uint32_t jb, unsigned char *w,
                                        uint32_t &scnt, int lkeep, float (&tauv)[NB])
 {
     uint64_t b = __builtin_amdgcn_ballot_w64(h);
-    if (b == 0) return;
-    uint32_t n = (uint32_t)__builtin_popcountll(b);
-    if (scnt + n > (uint32_t)NREC) {
-        lists_drain<C, NB>(w, scnt, lkeep, tauv);
-        scnt = 0;
-        h = h && (m < tauv[rb]);
+    while (b != 0) {
+        const uint32_t room = (uint32_t)NREC - scnt;
+        if (room == 0) {
+            lists_drain<C, NB>(w, scnt, lkeep, tauv);
+            scnt = 0;
+            h = h && (m < tauv[rb]);
+            b = __builtin_amdgcn_ballot_w64(h);
+            continue;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        const bool take = h && rank < room;
+        if (take) {
+            const uint32_t p = scnt + rank;
+            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * C::RS);
+            rp[0] = lo;
+            rp[1] = hi;
+            C::shdr(w)[p] = make_uint2((uint32_t)(rb * C::RPB + (lane_id() & (C::RPB - 1))), jb);
+        }
+        const uint32_t n = (uint32_t)__builtin_popcountll(b);
+        scnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(scnt + (n < room ? n : room)));
+        h = h && !take;
         b = __builtin_amdgcn_ballot_w64(h);
-        if (b == 0) return;
-        n = (uint32_t)__builtin_popcountll(b);
     }
-    if (h) {
-        const uint32_t p = scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * C::RS);
-        rp[0] = lo;
-        rp[1] = hi;
-        C::shdr(w)[p] = make_uint2((uint32_t)(rb * C::RPB + (lane_id() & (C::RPB - 1))), jb);
-    }
-    scnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(scnt + n));
 }
 
 // Grid: x = target super-blocks (4 waves x 128 rows), y = reference splits.
-template <int KS, int EPL, int ROWN>
-__global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *__restrict__ Xpk,
+template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned char *__restrict__ Xpk,
                                                           const unsigned char *__restrict__ Ypk,
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
                                                           uint32_t *__restrict__ cand_idx,
                                                           float *__restrict__ cand_key,
                                                           float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg,
-                                                          int64_t rows_valid)
+                                                          int64_t rows_valid, const float *__restrict__ tau_init)
 {
 #ifdef NABO_EXPERIMENTS
     const int dbg = dbg_arg;                           // timing ablations (knn_common.h: debug_ablate)
@@ -180,9 +199,9 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
     constexpr int dbg = 0;
     (void)dbg_arg;
 #endif
-    constexpr int NB = 8;                              // row-blocks of 16 targets per wave
+    constexpr int NB = NBv;                            // row-blocks of 16 targets per wave
     constexpr int NP = NB / 2;                         // pairs
-    constexpr int NREC = L2C_NREC;
+    constexpr int NREC = NRECv;
     using C = ListCfg<EPL, ROWN, NB, NREC, 16>;
     constexpr int TB = 2 * KS * 1024;                  // bytes per packed 32-cell tile (targets and references alike)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int split = blockIdx.y;
     const int S = gridDim.y;
-    const int64_t ltile0 = ((int64_t)blockIdx.x * 4 + wave) * (NB / 2);      // in 32-row tiles
+    const int64_t ltile0 = ((int64_t)blockIdx.x * WAVES + wave) * (NB / 2);  // in 32-row tiles
     const int64_t ttile0 = tile_off + ltile0;
 
     f16x8 xb[NB][KS];
@@ -202,7 +221,10 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             xb[rb][s] = p[((rb & 1) * KS + s) * 64 + lane];
-            asm volatile("" : "+a"(xb[rb][s]));        // pinned in AGPRs (l2h_topk.hip)
+            // pinned in AGPRs (l2h_topk.hip) at one wave per SIMD.  NOT at two: with 256 registers per wave hipcc then
+            // parks ACCUMULATORS in the spare AGPRs and copies them (v_accvgpr_write) right behind the inline-assembly
+            // MFMA that is still writing them -- a hazard it cannot see (wrong neighbours in 3 of 9 test shapes).
+            if (WAVES <= 4) asm volatile("" : "+a"(xb[rb][s]));
         }
     }
     unsigned char *wl = smem_raw + (size_t)wave * C::BYTES;          // this wave's lists (topk_lists.h)
@@ -212,8 +234,17 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
     // nothing ever passes, so they cost no list work -- their operands are finite (pack_ctiles_kernel<.,.,1>) and would
     // otherwise fill and refine lists like any row: 1.5 ms for a one-row query over 125k references, ~0.1 ms without.
     const int64_t row0 = ttile0 * 32;                    // first row of the wave (position in the query)
+    // SEEDED pass (tau_init, one value per row of the query; api.hip: the second pass of the rows whose first-pass
+    // certificate failed): a row starts from the threshold refine.hip worked out for it -- below it lie the few
+    // references that can still enter or tie with the first k', nothing is built up from +inf.  The kept list starts as
+    // lkeep entries (tau_init, no index): its maximum IS the threshold until every one of them has been replaced, and from
+    // then on the list behaves like any other (a row with more than lkeep references below its seed loses its
+    // certificate again and goes on to the f16x3 pass).
 #pragma unroll
-    for (int rb = 0; rb < NB; ++rb) tauv[rb] = (row0 + rb * 16 + (lane & 15)) < rows_valid ? tau0 : -__builtin_inff();
+    for (int rb = 0; rb < NB; ++rb) {
+        const int64_t r = row0 + rb * 16 + (lane & 15);
+        tauv[rb] = r < rows_valid ? ((tau_init && !(dbg & 1)) ? tau_init[r] : tau0) : -__builtin_inff();
+    }
     uint32_t scnt = 0;
     lists_init<C>(wl, lkeep, tau0);
     {
@@ -221,11 +252,20 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
         if (nv < C::NROWS)
             for (int r = lane; r < C::NROWS; r += 64)
                 if (r >= nv) C::tauL(wl)[r] = -__builtin_inff();
+        if (tau_init && !(dbg & 1)) {
+            uint2 *rows = C::rows(wl);
+            for (int e = lane; e < C::NROWS * lkeep; e += 64) {
+                const int r = e / lkeep, sl = e - r * lkeep;
+                if (r < nv) rows[r * C::ROW + sl].x = __float_as_uint(tau_init[row0 + r]);
+            }
+            for (int r = lane; r < C::NROWS; r += 64)
+                if (r < nv) C::tauL(wl)[r] = tau_init[row0 + r];
+        }
     }
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
-    // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop runs in fours
+    // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop runs in fours (twos)
     auto tile_ptr = [&](int ts) {
         const int64_t tc = ts < t_end ? (int64_t)ts : pad_tile;
         // dbg & 2 / dbg & 4 (timing experiments, garbage results): the stream wraps inside a window of 128 tiles / of 2
@@ -239,10 +279,15 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
             for (int s = 0; s < KS; ++s) a[h][s] = p[(h * KS + s) * 64 + lane];
     };
 
+    // tile sets in flight: four at one wave per SIMD (tile t + 3 is requested at the top of step t); two at two waves per
+    // SIMD, where the other wave covers the latency and 256 registers have to hold everything
+    constexpr int RING = WAVES > 4 ? 2 : 4;
     f16x8 a0[2][KS], a1[2][KS], a2[2][KS], a3[2][KS];
     tile_load(a0, t_begin);
-    tile_load(a1, t_begin + 1);
-    tile_load(a2, t_begin + 2);
+    if (RING == 4) {
+        tile_load(a1, t_begin + 1);
+        tile_load(a2, t_begin + 2);
+    }
 
     // Scores of a whole tile (NP pairs x 16 registers) stay in registers for one more step: their filter runs next to
     // the NEXT tile's chains, on operands that were complete long before (a filter instruction that reads what the
@@ -262,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
 #endif
     // chains of tile t into `cur` (set `a`; set `an` receives tile t + 3), filter of tile t - 1 (`old`) beside them
     auto tile_step = [&](const f16x8(&a)[2][KS], f16x8(&an)[2][KS], cacc(&cur)[NP], const cacc(&old)[NP], int t) {
-        tile_load(an, t + 3);
+        tile_load(an, t + RING - 1);
         cmins mm[NP];
         uint64_t hit[NP];
 #pragma unroll
@@ -280,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
             hit[p] = 0;
 #else
             if constexpr (KS == 2 && !L2C_BUILTIN) {
-                cpair<KS>(a, xb[2 * p], xb[2 * p + 1], cur[p], old[p], tauv[2 * p], tauv[2 * p + 1], mm[p], hit[p]);
+                cpair<KS, (WAVES <= 4)>(a, xb[2 * p], xb[2 * p + 1], cur[p], old[p], tauv[2 * p], tauv[2 * p + 1], mm[p], hit[p]);
             } else {                                    // hipcc's own schedule of builtin MFMAs (other shapes; A/B runs)
                 mm[p] = cmin8x2(old[p]);
                 hit[p] = __builtin_amdgcn_ballot_w64((mm[p].m0 < tauv[2 * p]) | (mm[p].m1 < tauv[2 * p + 1]));
@@ -292,7 +337,10 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
                 L2C_SG(2) L2C_SG(2) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1)
             }
         }
-        if (__builtin_expect((hit[0] | hit[1] | hit[2] | hit[3]) != 0, 0)) {
+        uint64_t any = hit[0];
+#pragma unroll
+        for (int p = 1; p < NP; ++p) any |= hit[p];
+        if (__builtin_expect(any != 0, 0)) {
             const uint32_t jb = (uint32_t)((t - 1) * 32 + 4 * lq);           // (a padding step stages nothing)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -306,13 +354,19 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
             }
         }
     };
-    static_assert(NP == 4, "four pairs per tile");
     int t = t_begin;
-    for (; t < t_end; t += 4) {
-        tile_step(a0, a3, accE, accO, t);
-        tile_step(a1, a0, accO, accE, t + 1);
-        tile_step(a2, a1, accE, accO, t + 2);
-        tile_step(a3, a2, accO, accE, t + 3);
+    if (RING == 4) {
+        for (; t < t_end; t += 4) {
+            tile_step(a0, a3, accE, accO, t);
+            tile_step(a1, a0, accO, accE, t + 1);
+            tile_step(a2, a1, accE, accO, t + 2);
+            tile_step(a3, a2, accO, accE, t + 3);
+        }
+    } else {
+        for (; t < t_end; t += 2) {
+            tile_step(a0, a1, accE, accO, t);
+            tile_step(a1, a0, accO, accE, t + 1);
+        }
     }
 #ifdef NABO_L2C_ABL
     if (abl_run + (float)abl_cnt == 12345.0f) cand_tau[0] = abl_run;
@@ -333,20 +387,20 @@ __global__ __launch_bounds__(256, 1) void l2c_topk_kernel(const unsigned char *_
     lists_flush<C, EPL, NB>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }
 
-template <int KS, int EPL, int ROWN>
-static hipError_t claunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES>
+static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              int64_t pad_tile, hipStream_t st, int64_t rows_valid)
+                              int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
     const int dbg = debug_ablate();
-    constexpr size_t lds = (size_t)4 * ListCfg<EPL, ROWN, 8, L2C_NREC, 16>::BYTES;
+    constexpr size_t lds = (size_t)WAVES * ListCfg<EPL, ROWN, NBv, NRECv, 16>::BYTES;
     static_assert(lds <= 163840, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid(gx, S), block(256);
-    hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
-                       cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid);
+    dim3 grid(gx, S), block(64 * WAVES);
+    hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
+                       cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init);
 #ifdef NABO_LISTS_PROF
     {
         unsigned long long h[8];
@@ -359,13 +413,39 @@ static hipError_t claunch_one(const unsigned char *Xpk, const unsigned char *Ypk
     return hipGetLastError();
 }
 
-// 512 rows per workgroup, one workgroup per CU, lists of <= 32 kept entries (l2q_topk.hip's geometry)
-void l2c_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
+template <int KS>
+static hipError_t claunch_one(bool geo_b, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+                              int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                              int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
-    (void)kc;
-    *rows_per_wg = 4 * 128;
+    if constexpr (KS <= 2) {
+        if (geo_b)
+            return claunch_geo<KS, 1, L2C_ROW_B, 6, L2C_NREC_B, 8>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx,
+                                                                  cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    }
+    return claunch_geo<KS, 1, L2C_ROW, 8, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau,
+                                                      pad_tile, st, rows_valid, tau_init);
+}
+
+// Which geometry serves lists of `lkeep_want` kept entries: B (two waves per SIMD) up to 23, KS <= 2 (its 256 registers
+// per wave hold two steps of operands); A otherwise.  NABO_L2C_GEO=a|b pins one where it can serve the lists at all.
+bool l2c_geometry_b(int kc, int lkeep_want)
+{
+    static const char *pin = getenv("NABO_L2C_GEO");
+    if (kc > 4 || lkeep_want > L2C_ROW_B) return false;
+    return !(pin && pin[0] == 'a');
+}
+
+void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
+{
+    if (l2c_geometry_b(kc, lkeep_want)) {
+        *rows_per_wg = 8 * 96;
+        *lkeep_max = L2C_ROW_B;
+    } else {
+        *rows_per_wg = 4 * 128;
+        *lkeep_max = L2C_ROW < 32 ? L2C_ROW : 32;
+    }
     *wg_per_cu = 1;
-    *lkeep_max = L2C_ROW < 32 ? L2C_ROW : 32;
 }
 
 // steps of 16 slots of the one-product operands (g components + two norm slots + the error slot), even (KS = kc / 2
@@ -377,15 +457,16 @@ int l2c_pick_kc(int g)
 }
 
 // The split's padding must cover the ring: the kernel reads tiles up to t_end + 3 (as pad_tile) -- all of them are the
-// caller's padding tile, never past the allocation.
-hipError_t l2c_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
-                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st, int64_t rows_valid)
+// caller's padding tile, never past the allocation.  geo_b: what l2c_geometry_b said when the caller sized its grid.
+hipError_t l2c_topk_launch(int kc, bool geo_b, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                           int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
+    if (geo_b && (kc > 4 || lkeep > L2C_ROW_B)) return hipErrorInvalidValue;
     switch (kc) {
-    case 2: return claunch_one<1, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid);
-    case 4: return claunch_one<2, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid);
-    case 6: return claunch_one<3, 1, L2C_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid);
+    case 2: return claunch_one<1>(geo_b, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 4: return claunch_one<2>(geo_b, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 6: return claunch_one<3>(false, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
     default: return hipErrorInvalidValue;
     }
 }

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
                                                      uint32_t *__restrict__ fail_rows,
                                                      unsigned int *__restrict__ fail_count, int stage_rows,
                                                      const uint32_t *__restrict__ rperm,
-                                                     const uint32_t *__restrict__ tperm)
+                                                     const uint32_t *__restrict__ tperm, float *__restrict__ fail_seed)
 {
     // rows [row0, m) of the filter's row order; candidate arrays are indexed by the row LOCAL to this launch.
     // Locality order (order.hip): the filter worked on permuted rows -- position prow holds target row tperm[prow]
@@ -221,6 +221,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
     for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
 
     bool certified = true;
+    // A row that fails its certificate hands the next pass a SEED (fail_seed, Euclidean / cosine): the filter threshold, in
+    // the filter's score units, below which every reference that can still enter or tie with the first k' must fall --
+    // the k'-th exact distance among THESE candidates bounds the true one from above.  A pass that starts from it
+    // (l2c_topk.hip: tau_init) only collects those few references instead of building its lists from +inf.
+    float seed = __builtin_inff();
     if (nreal >= kk) {
         // exact k'-th distance
         const int e = kk - 1;
@@ -265,6 +270,16 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
             const double E = err_coef * (sx + ymax_sqrt) * (sx + ymax_sqrt);
             const double bound = ((double)tmin * tau_scale + xnorm[prow] - E) * (1.0 - 1e-12);   // tau in score units
             certified = MET == 2 ? (0.5 * bound - 2e-13 > dk) : (bound > dk * dk * (1.0 + 1e-12));
+            if (!certified) {
+                // threshold T with  (T tau_scale + ||x||^2 - E)(1 - 1e-12) > d_k'^2 (1 + 1e-12)  (cosine: the same bound on
+                // ||x^ - y^||^2 = 2 c), rounded UP to fp32: a pass that drops nothing below T certifies the row
+                const double t2 = MET == 2 ? 2.0 * (dk + 2e-13) * (1.0 + 4e-12) + 4e-13 : dk * dk * (1.0 + 4e-12);
+                const double v = (t2 - xnorm[prow] + E) / tau_scale;
+                float sf = (float)v;
+                if ((double)sf < v)            // next float up (sf is finite here, or NaN and dropped below)
+                    sf = sf > 0.0f ? __uint_as_float(__float_as_uint(sf) + 1u) : sf < 0.0f ? __uint_as_float(__float_as_uint(sf) - 1u) : 1.0e-45f;
+                if (sf == sf) seed = sf;
+            }
         }
     } else {
         // fewer candidates than k': only legitimate when EVERY unmasked reference is a candidate
@@ -272,7 +287,11 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         certified = (int64_t)nreal >= n_valid_total;
     }
     if (!certified) {
-        if (lane == 0) fail_rows[atomicAdd(fail_count, 1u)] = (uint32_t)row;
+        if (lane == 0) {
+            const unsigned int slot = atomicAdd(fail_count, 1u);
+            fail_rows[slot] = (uint32_t)row;
+            if (fail_seed) fail_seed[slot] = seed;
+        }
         return;
     }
     int64_t *oi = out_idx + row * k;
@@ -617,7 +636,7 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
                          const uint32_t *masked_list, int n_masked_list, int64_t *out_idx, double *out_dist,
                          uint32_t *fail_rows, unsigned int *fail_count, hipStream_t st, int metric = 0,
                          double cb_f = 0.0, float cb_plateau = 0.0f, int lvalid = 0, const uint32_t *rperm = nullptr,
-                         const uint32_t *tperm = nullptr)
+                         const uint32_t *tperm = nullptr, float *fail_seed = nullptr)
 {
     const int ncl = (S * L + 63) / 64;
     if (m <= row0) return hipSuccess;
@@ -630,7 +649,8 @@ hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double 
 #define NABO_RF2(N, MV, SV)                                                                                          \
     hipLaunchKernelGGL((refine_kernel<N, MV, SV>), grid, block, SV ? stage_bytes : 0, st, X, row0, m, Y, g, cand_idx,   \
                        cand_tau, S, L, xnorm, err_coef, ymax_sqrt, tau_scale, cb_f, cb_plateau, k, drop, base,       \
-                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count, stage_rows, rperm, tperm)
+                       n_valid_total, masked_list, n_masked_list, out_idx, out_dist, fail_rows, fail_count, stage_rows, rperm, tperm, \
+                       fail_seed)
 #define NABO_RF(N)                                                                                               \
     do {                                                                                                         \
         if (metric == 1) NABO_RF2(N, 1, false);                                                                  \
