@@ -169,7 +169,23 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
                 // reads past lkeep (the next row, the header area) are masked
                 float t = -__builtin_inff();
                 uint32_t p = 0;
-                for (int i0 = 0; i0 < lkeep; i0 += RESCAN) {
+                int i0 = 0;
+                // whole batches need no bounds test (three instructions per key: compare, two selects) ...
+                for (; i0 + RESCAN <= lkeep; i0 += RESCAN) {
+                    float kq[RESCAN];
+#pragma unroll
+                    for (int j = 0; j < RESCAN; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
+                    uint32_t pj = 0xFFFFFFFFu;                      // position inside the batch, if the maximum moved into it
+#pragma unroll
+                    for (int j = 0; j < RESCAN; ++j) {
+                        const bool gt = kq[j] > t;
+                        t = gt ? kq[j] : t;
+                        pj = gt ? (uint32_t)j : pj;
+                    }
+                    p = pj != 0xFFFFFFFFu ? (uint32_t)i0 + pj : p;
+                }
+                // ... the last, partial one masks what lies past lkeep
+                if (i0 < lkeep) {
                     float kq[RESCAN];
 #pragma unroll
                     for (int j = 0; j < RESCAN; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
