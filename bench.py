@@ -377,9 +377,13 @@ def main():
                        "launch": {"single": "one process, one GPU", "launcher": "one process per GPU (launcher environment)",
                                   "threads": "one process, one host thread + one RCCL communicator per GPU",
                                   "loopback": "%d shard-ranks on ONE GPU, loopback transport (rehearsal)" % ranks}[kind],
-                       "arithmetic": "low-precision score filter on the matrix pipe, float64 re-evaluation + certification: "
-                                     "indices and distances equal the reference's float64 path"},
-            "phases_ms": per_rank[0]["index"],
+                       "arithmetic": "low-precision score filter on the matrix pipe (one f16 product per pair as a rigorous lower "
+                                     "bound; rows it cannot certify go on to the seeded pass / the f16x3 pass / the exact kernels), "
+                                     "float64 re-evaluation + certification: indices and distances equal the reference's float64 path"},
+            "phases_ms": {kk: v for kk, v in per_rank[0]["index"].items() if kk.startswith("ms_")},
+            "rows_by_pass": {"seeded_one_product_pass": int(per_rank[0]["index"]["seeded_pass_rows"]),
+                             "f16x3_pass": int(per_rank[0]["index"]["second_pass_rows"]),
+                             "wide_lists": int(per_rank[0]["index"]["wide_list_rows"]), "exact_float64": head["fallback_rows"]},
             "fallback_rows": head["fallback_rows"],
             "sampled_rows_equal_oracle": sampled,
             "so_digest": _lib.so_digest(), "src_digest": _lib.src_digest(),
@@ -398,6 +402,7 @@ def main():
                 "traffic": (rec or {}).get("bytes_per_step"), "traffic_record": rec,
                 "algorithmic_bytes": 4.0 * d * (m / slices + lay_n_shard(n, shards)) + 12.0 * k * (m / slices),
                 "kernel": kern, "kernel_ms": t_kernel * 1e3, "kernel_src_digest": dig,
+                "executed_over_algorithmic_flops": executed_flops_factor(kern, d),
                 "matrix_pipe_busy": (rec or {}).get("matrix_pipe_busy"),
                 "clock_ghz_held": (rec or {}).get("clock_ghz_held")}
         else:
@@ -414,7 +419,9 @@ def main():
             line["alt_layout"] = alt_layout
         extras = kind == "single" and not a.no_extras and not ablate
         if extras and a.metric == "euclidean" and not os.environ.get("NABO_L2_MODE"):
-            line["alt"] = alt_block(nabo_amd, _knn, kern, dev, n, m, d, k, lay.dY, lay.dXb, gi, gd, lay.sync)
+            line["alt"] = alt_block(nabo_amd, _knn, "f32" if "f16" in kern else "f16x3", dev, n, m, d, k, lay.dY, lay.dXb, gi, gd, lay.sync)
+            if "one-product" in kern:           # ... and the f16x3 split as the first pass (round 2's default)
+                line["alt_f16x3"] = alt_block(nabo_amd, _knn, "f16x3", dev, n, m, d, k, lay.dY, lay.dXb, gi, gd, lay.sync)
         if extras and a.metric == "euclidean" and (m, n) == (1000000, 1000000):
             line["canberra"] = canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, lay.dY, lay.dXb, X, Yfull, lay.sync)
         if not a.no_cpu_baseline and kind == "single":
@@ -481,9 +488,23 @@ def canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, dY, dX, X, Yfull, sync
             "roofline": canberra_roofline(pmc_record("canberra", workload, dig), st["ms_topk"] * 1e-3, kern, dig)}
 
 
-def alt_block(nabo_amd, _knn, kern, dev, n, m, d, k, dY, dX, gi, gd, sync):
-    """The same step with the OTHER Euclidean filter kernel (fp32 MFMA <-> f16x3 split); results must be the same bits."""
-    other = "f32" if "f16" in kern else "f16x3"
+def executed_flops_factor(kern, d):
+    """MFMA flops the filter kernel executes per algorithmic flop (2 m n d): K slots per pair / d."""
+    import re
+    mt = re.match(r"l2c_topk_kernel<(\d+),", kern)
+    if mt:
+        return 32.0 * int(mt.group(1)) / d                 # one-product operands: g + 3 slots in steps of 32
+    mt = re.match(r"l2[qhs]_topk_kernel<(\d+)", kern)
+    if mt:
+        return 16.0 * int(mt.group(1)) / d                 # K-concatenated f16 operands in steps of 16 (f16x3: 3 (g + 1) slots)
+    mt = re.match(r"l2_topk_kernel<(\d+),", kern)
+    if mt:
+        return 2.0 * int(mt.group(1)) / d                  # fp32: k-steps of 2
+    return None
+
+
+def alt_block(nabo_amd, _knn, other, dev, n, m, d, k, dY, dX, gi, gd, sync):
+    """The same step with ANOTHER Euclidean filter (fp32 MFMA, or the f16x3 split as the first pass); results must be the same bits."""
     os.environ["NABO_L2_MODE"] = other
     try:
         alt = nabo_amd.KnnIndex(n, d, metric=nabo_amd.EUCLIDEAN, device=dev)

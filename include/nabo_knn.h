@@ -125,8 +125,9 @@ int nabo_index_query_candidates(nabo_index *ix, const double *X, int32_t x_on_de
  * counters[2] candidates per list (L), counters[3] workgroups of the dominant kernel. */
 int nabo_index_last_stats(const nabo_index *ix, double ms[5], int64_t counters[4]);
 /* Name of the dominant kernel the LAST query on this index ran (NUL-terminated into buf[n]): which filter the
- * launch logic picked -- the f16x3 split on the f16 matrix pipe (default where instantiated: g < 64 and
- * k + drop_first <= 28), the fp32-MFMA kernel (NABO_L2_MODE=f32 pins it), the Canberra filter, or the exact kernels. */
+ * launch logic picked -- the one-product pass on the f16 matrix pipe (default where instantiated: g < 64 and
+ * k + drop_first <= 28), the f16x3 split (NABO_L2_MODE=f16x3 pins it as the first pass), the fp32-MFMA kernel
+ * (NABO_L2_MODE=f32), the Canberra filter, or the exact kernels. */
 int nabo_index_last_kernel(const nabo_index *ix, char *buf, size_t n);
 /* Rows of the LAST query that a filter pass could not certify, by the pass they went on to: rows[0] the SEEDED
  * one-product pass (every row starts from the threshold its failed certificate implies), rows[1] the f16x3 pass, rows[2]

@@ -819,7 +819,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // distance of the first candidate left out and not the one-product threshold, which sits 2^-9 ||x|| ||y|| lower)
         if (cand_mode && use_1) lkeep += env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack);
         if (lkeep > lkeep_max) lkeep = lkeep_max;
-        { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }   // experiments
+        // (experiments and tests: the first pass's list length; the passes behind it keep theirs)
+        if (ix->pass_level == 0 && !ix->wide_retry) { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }
         // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
         // chip is full.  Many rows: the last, partially filled round of workgroups is launched with
         // its own split factor S2 so that it takes ~1/S2 of a round instead of a whole one.

@@ -8,7 +8,7 @@
 // refine.hip (with this kernel's accumulation coefficient), and a row the bound is too weak for goes through the f16x3
 // pass afterwards (api.hip: no_coarse).  On 1M x 1M x 50 the bound costs 3 % more staged scores and ~1 % of the rows.
 //
-// What a tile costs was measured on the l2q kernel at KS = 2 (tools/r3_coarse_ablate3.sh, 1M x 1M): the bare MFMA loop
+// What a tile costs was measured on the l2q kernel at KS = 2 (tools/r3_coarse_ab.sh, 1M x 1M): the bare MFMA loop
 // 62 ms = the matrix pipe's rate, + 24 ms of filter instructions (14 per 8 MFMAs, bunched behind the chains they read),
 // + 12-15 ms for the tile refills (fenced into the last chain of a tile), + 32 ms of hits -- nothing overlapped.  Hence:
 //   * the filter of a pair of row-blocks is 10 instructions (2 x (3 v_min3 + v_min + v_cmp)): no NaN canonicalisation --
@@ -431,7 +431,7 @@ static hipError_t claunch_one(bool geo_b, const unsigned char *Xpk, const unsign
 // per wave hold two steps of operands); A otherwise.  NABO_L2C_GEO=a|b pins one where it can serve the lists at all.
 bool l2c_geometry_b(int kc, int lkeep_want)
 {
-    static const char *pin = getenv("NABO_L2C_GEO");
+    const char *pin = getenv("NABO_L2C_GEO");
     if (kc > 4 || lkeep_want > L2C_ROW_B) return false;
     return !(pin && pin[0] == 'a');
 }

@@ -884,3 +884,92 @@ def _knn_mod():
 
 def _knn_buf(gpu_lib, arr):
     return _knn_mod().DeviceBuffer(arr.nbytes).upload(arr)
+
+
+def _offset_clusters(n, g, seed, offset):
+    """Tight clusters far from the origin of the centred data: ||x|| ||y|| is large next to the neighbour distances, which is
+    where the one-product pass's bound (2^-9 ||x|| ||y|| below the real score) is weakest."""
+    centres = np.random.default_rng(5).standard_normal((6, g)) * offset
+    rng = np.random.default_rng(seed)
+    lab = rng.integers(0, 6, size=n)
+    return centres[lab] + rng.standard_normal((n, g)) * 0.5
+
+
+@pytest.mark.parametrize("geo", ["a", "b"])
+@pytest.mark.parametrize("offset", [0.5, 10.0, 40.0, 400.0])
+def test_one_product_pass_chain_equals_the_oracle(gpu_lib, geo, offset):
+    """The default Euclidean filter starts with the one-product pass (l2c_topk.hip, geometry A = one wave per SIMD / 32-entry
+    lists, B = two waves per SIMD / 23-entry lists); rows its lower bound cannot certify go through the SEEDED one-product pass,
+    then the f16x3 pass, the 64-entry lists and the exact kernels.  The further the clusters sit from the origin the more rows
+    travel down that chain -- the answer is the oracle's bits wherever a row ends up."""
+    n, m, g, k = 30000, 3000, 40, 15
+    Y = _offset_clusters(n, g, 11, offset)
+    X = _offset_clusters(m, g, 12, offset)
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    os.environ["NABO_L2C_GEO"] = geo
+    try:
+        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, k)
+        st, kern = ix.last_stats(), ix.last_kernel()
+        os.environ["NABO_SEEDED_PASS"] = "0"             # the chain without its seeded link
+        hi, hd = ix.query(X, k)
+        st2 = ix.last_stats()
+        ix.close()
+    finally:
+        os.environ.pop("NABO_L2C_GEO", None)
+        os.environ.pop("NABO_SEEDED_PASS", None)
+    _check(gi, gd, oi, od)
+    _check(hi, hd, oi, od)
+    assert kern.startswith("l2c_topk_kernel<2,1,%s>" % ("33,8,64,4" if geo == "a" else "23,6,32,8")), kern
+    assert st2["seeded_pass_rows"] == 0 and st2["second_pass_rows"] == st["seeded_pass_rows"]
+    if offset <= 0.5:
+        assert st["seeded_pass_rows"] < m // 10          # well-centred data: the first pass answers (nearly) everything
+    if offset >= 10.0:
+        assert st["seeded_pass_rows"] > 0                # the weak bound really sends rows on ...
+    if offset <= 40.0:
+        assert st["fallback_rows"] <= m // 20            # ... and the filter passes, not the exact kernels, answer them
+    # (offset 400: clusters 800 noise widths from the centre of the data -- even the fp32 filter's error bound exceeds the
+    # neighbour gaps, and the exact kernels answer; a global centre cannot serve such data, the result is right anyway)
+
+
+def test_seeded_pass_serves_most_of_what_the_first_pass_leaves(gpu_lib):
+    """Lists without slack (NABO_LKEEP = k': the threshold IS the k'-th kept one-product score, which lies below the k'-th exact
+    distance) make the first pass fail nearly every row; the seeded pass -- every row starts from the threshold its failed
+    certificate implies -- answers them without the f16x3 pass."""
+    n, m, g, k = 60000, 5000, 50, 15
+    Y = pca_like(n, g, seed=71)
+    X = pca_like(m, g, seed=72)
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    os.environ["NABO_LKEEP"] = str(k)
+    os.environ["NABO_SPLITS"] = "1"                  # (one reference split: S splits would hand refine S lists per row)
+    try:
+        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, k)
+        st = ix.last_stats()
+        ix.close()
+    finally:
+        os.environ.pop("NABO_LKEEP", None)
+        os.environ.pop("NABO_SPLITS", None)
+    _check(gi, gd, oi, od)
+    assert st["seeded_pass_rows"] > m // 10, st
+    assert st["second_pass_rows"] <= st["seeded_pass_rows"] // 20, st
+    assert st["fallback_rows"] == 0, st
+
+
+def test_small_query_pads_cost_no_list_work(gpu_lib):
+    """One row is still a whole workgroup of the filter: the padding rows start from threshold -inf (l2c_topk.hip), so the
+    kernel time of a 1-row query stays a fraction of a 512-row one over the same references."""
+    n, g, k = 200000, 50, 15
+    Y = pca_like(n, g, seed=81)
+    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    X = pca_like(512, g, seed=82)
+    oi, od = oracle.knn(X[:1], Y, k, 0, nthreads=8)
+    ix.query(X, k)
+    t512 = ix.last_stats()["ms_topk"]
+    best1 = 1e9
+    for _ in range(3):
+        gi, gd = ix.query(X[:1], k)
+        best1 = min(best1, ix.last_stats()["ms_topk"])
+    ix.close()
+    _check(gi, gd, oi, od)
+    assert best1 < 0.6 * t512, (best1, t512)
