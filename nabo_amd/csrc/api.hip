@@ -40,11 +40,11 @@ hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *c
                               const uint32_t *perm = nullptr, int nseg = 3);
 int l2q_pick_kc1(int g);
 // the one-product first pass (l2c_topk.hip; operands packed with layout16, nseg = 1)
-hipError_t l2c_topk_launch(int kc, bool geo_b, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init);
 int l2c_pick_kc(int g);
-bool l2c_geometry_b(int kc, int lkeep_want);
+int l2c_geometry(int kc, int lkeep_want);
 void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 // the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
@@ -489,6 +489,12 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
             // (=f16x1h: the one-product pass on the 32x32x16 shape, l2h_topk.hip -- an experiment)
             ix->coarse = !ix->shared && (ix->order_flags == 0 || ix->q16) && ix->kc1 > 0 &&
                          !(md && strncmp(md, "f16x3", 5) == 0);
+        } else if (!(md && (strcmp(md, "f32") == 0 || strncmp(md, "f16x3", 5) == 0)) && ix->ksteps > 0 && nabo::l2c_pick_kc(g) > 0) {
+            // 64 <= g <= 125: no f16x3 kernel is instantiated, but the one-product operands (g + 3 slots: four steps of 32)
+            // are -- the one-product pass runs first, the fp32-MFMA filter takes the rows it cannot certify
+            ix->q16 = true;
+            ix->kc1 = nabo::l2c_pick_kc(g);
+            ix->coarse = true;
         }
     }
     int cus = 0;
@@ -544,16 +550,22 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
         if (ix->metric == NABO_METRIC_COSINE) {
-            // cosine: the filter sees unit-length rows, NOT centred (a shift changes angles)
+            // cosine: the filter sees the unit-length rows x^, y^ and works on ||x^ - y^||^2 = 2 (1 - cos).  That quantity is
+            // translation invariant like any Euclidean distance, so the UNIT rows are centred (a shift BEFORE the
+            // normalisation would change angles; after it, it only shortens the vectors the error bounds scale with:
+            // unit rows of PCA-like data sit in a cap around their mean direction, ||x^ - c|| is a fraction of 1)
             if ((rc = ix->ynbuf.reserve(ybytes))) return rc;
             HIP_TRY(nabo::normalise_rows_launch(ix->dY, ix->n, ix->g, ix->ynbuf.as<double>(), st));
-            HIP_TRY(hipMemsetAsync(ix->centre.p, 0, (size_t)ix->g * sizeof(double), st));
+            if (env_int("NABO_COSINE_CENTRE", 1) != 0)
+                HIP_TRY(nabo::centre_launch(ix->ynbuf.as<double>(), ix->n, ix->g, ix->centre.as<double>(), st));
+            else
+                HIP_TRY(hipMemsetAsync(ix->centre.p, 0, (size_t)ix->g * sizeof(double), st));
             ix->dYp = ix->ynbuf.as<double>();
         } else {
             HIP_TRY(nabo::centre_launch(ix->dY, ix->n, ix->g, ix->centre.as<double>(), st));
             ix->dYp = ix->dY;
         }
-        if ((rc = ensure_packed(ix, ix->mode == 1 ? (ix->coarse ? 2 : 1) : 0))) return rc;
+        if ((rc = ensure_packed(ix, ix->coarse ? 2 : ix->mode == 1 ? 1 : 0))) return rc;
     } else {
         const int64_t chunks = (ix->n + 63) / 64;
         if ((rc = ix->yt.reserve((size_t)chunks * 64 * ix->g * sizeof(double)))) return rc;
@@ -656,7 +668,7 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
     }
     if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0) {       // masked cells carry ||y||^2 = +inf in the packed tiles
         ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
-        if ((rc = ensure_packed(ix, ix->mode == 1 ? (ix->coarse ? 2 : 1) : 0))) return rc;
+        if ((rc = ensure_packed(ix, ix->coarse ? 2 : ix->mode == 1 ? 1 : 0))) return rc;
     }
     return NABO_OK;
 }
@@ -750,21 +762,32 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             else if (!use_c) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
             use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
         }
-        // the one-product first pass (l2q kernel, kc1-step operands); see nabo_index::coarse
-        const bool use_1 = use_h && !use_c && ix->coarse && ix->pass_level < 2 && !ix->wide_retry &&
-                           (!cand_mode || kk + 3 <= lkeep_max);
-        const int kcq = use_1 ? ix->kc1 : ix->kc;
-        // ... on the l2c kernel (unless the locality order or an A/B run sends its operands through the l2q kernel), in one
-        // of two geometries by the list length the pass wants (l2c_topk.hip: two waves per SIMD up to 23 kept entries)
-        const bool on_l2c = use_1 && ix->q16 && ix->order_flags == 0 && env_int("NABO_COARSE_KERNEL_Q", 0) == 0;
-        bool geo_b = false;
-        if (on_l2c) {
-            int want = cand_mode ? (kk < 4 ? 4 : kk) + env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack)
-                                 : kk + 8 + env_int("NABO_COARSE_SLACK", 0);
-            if (ix->pass_level == 1) want = 32;
-            geo_b = nabo::l2c_geometry_b(kcq, want);
-            nabo::l2c_topk_geometry(kcq, want, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        // The one-product first pass (kc1-step operands; see nabo_index::coarse) -- on the l2c kernel, in the geometry that
+        // serves the list length the pass wants (l2c_topk.hip: two waves per SIMD up to 23 kept entries, 32-entry lists,
+        // 64-entry lists for k' > 24), unless the locality order, the 32x32x16 experiment or an A/B run sends the operands
+        // through the l2q / l2h kernel (those serve 32-entry lists and g < 64 only).
+        const bool pass1 = ix->coarse && ix->pass_level < 2 && !ix->wide_retry && (!cand_mode || kk + 3 <= 32);
+        // (k' > 24, the 64-entry lists: six entries more -- there a row the first pass fails is expensive, the pass behind the
+        // seeded one is the fp32 filter: cosine 1M x 1M, d = 100, k = 50: 689 -> 597 ms per step)
+        const int slack1 = env_int("NABO_COARSE_SLACK", epl == 2 ? 6 : 0);
+        int want = cand_mode ? (kk < 4 ? 4 : kk) + env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack) : kk + 8 + slack1;
+        if (ix->pass_level == 1) want = L;                   // seeded pass: room for everything below the seed
+        if (epl == 1 && want > 32) want = 32;                // (the emitted lists hold 32 epl entries)
+        if (epl == 2) want = want < 33 ? 33 : (want > 64 ? 64 : want);
+        int geo = -1;
+        if (pass1 && ix->q16 && ix->order_flags == 0 && env_int("NABO_COARSE_KERNEL_Q", 0) == 0 && kk + 4 <= L) {
+            geo = nabo::l2c_geometry(ix->kc1, want);
+            if (epl == 1 && geo == 2) geo = 0;               // (NABO_L2C_GEO=c with 32-entry emitted lists: geometry A)
         }
+        const bool on_l2c = geo >= 0;
+        const bool use_1 = on_l2c || (pass1 && use_h && !use_c);
+        if (on_l2c) {
+            use_h = true;
+            use_c = false;
+            nabo::l2c_topk_geometry(ix->kc1, want, &rows_per_wg, &wg_per_cu, &lkeep_max);
+            if (geo == 0) { rows_per_wg = 4 * 128; lkeep_max = 32; }
+        }
+        const int kcq = use_1 ? ix->kc1 : ix->kc;
         if (ix->pass_level == 0 && !ix->wide_retry) ix->pass_rows[0] = ix->pass_rows[1] = ix->pass_rows[2] = 0;
         // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
         // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
@@ -792,7 +815,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
             if (use_1 && ix->q16 && !on_l2c)
                 snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq);
-            else if (use_1 && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2c_topk_kernel<%d,1,%s> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2, geo_b ? "23,6,32,8" : "33,8,64,4");
+            else if (use_1 && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2c_topk_kernel<%d,%s> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2, geo == 1 ? "1,23,6,32,8" : geo == 2 ? "2,65,4,64,4" : "1,33,8,64,4");
             else if (use_1) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, one-product f16 filter with the split error as an operand slot)", kcq);
             else if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
             else if (use_h && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, K-concatenated f16x3 split)", ix->kc);
@@ -812,8 +835,9 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // one-product pass: its scores sit up to 2^-9 ||x|| ||y|| below the real ones and the gap above the k'-th distance
         // has to cover that -- 1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass (7 ms), k' + 13 a
         // third of that, but every five entries more cost 14 ms of list updates in the kernel: no extra slack by default
-        if (use_1) lkeep = kk + 8 + env_int("NABO_COARSE_SLACK", 0);
+        if (use_1) lkeep = kk + 8 + slack1;
         if (use_1 && ix->pass_level == 1) lkeep = lkeep_max;       // seeded pass: room for everything below the seed
+        if (on_l2c && lkeep > want) lkeep = want;
         if (cand_mode) lkeep = kk < 4 ? 4 : kk;
         // (candidate mode on the one-product pass: three kept entries more than are emitted, so that the bound is the exact
         // distance of the first candidate left out and not the one-product threshold, which sits 2^-9 ||x|| ||y|| lower)
@@ -923,11 +947,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             if (use_1 && !coarse_on_q) {
                 if (gx_main > 0)
-                    HIP_TRY(nabo::l2c_topk_launch(kcq, geo_b, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
+                    HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
                                                   ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
                                                   ix->ref_tiles_alloc - 1, st, m, seeds));
                 if (gx_tail > 0)
-                    HIP_TRY(nabo::l2c_topk_launch(kcq, geo_b, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
+                    HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
                                                   rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
                                                   ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m, seeds));
             } else {

@@ -46,15 +46,18 @@ constexpr bool L2C_ABLATED = true;
 #else
 constexpr bool L2C_ABLATED = false;
 #endif
-// Two geometries (claunch_one):
+// Three geometries (claunch_one), by the list length a pass wants:
 //   A  one wave per SIMD: 4 waves x 128 rows, lists of <= 32 kept entries (33-entry rows), 64 staging records;
 //   B  TWO waves per SIMD: 8 waves x 96 rows, lists of <= 23 kept entries (23-entry rows: k' + 8 at k' = 15), 32 staging
 //      records -- 8 x 20 096 bytes of LDS.  While one wave of a SIMD stages hits or drains its lists, the other one's
 //      MFMAs keep the matrix pipe busy; the price is 8 x 4 KB of tile per 24 MFMAs instead of 4 x 4 KB per 32.
+//   C  one wave per SIMD: 4 waves x 64 rows, lists of <= 64 kept entries (65-entry rows, emitted lists of 64): k' up to 56
+//      (BASELINE configs[4]: k = 50), which the fp32-MFMA kernel served before.
 constexpr int L2C_NREC = 64;        // staging records (8 scores each) per wave, geometry A
 constexpr int L2C_ROW = 33;         // list entries per row (odd), geometry A
 constexpr int L2C_NREC_B = 32;
 constexpr int L2C_ROW_B = 23;
+constexpr int L2C_ROW_C = 65;
 
 struct cacc { f32x4 v[2][2]; };     // [row-block of the pair][reference half]
 #define L2C_SG(n) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, n, 0);
@@ -414,59 +417,65 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
 }
 
 template <int KS>
-static hipError_t claunch_one(bool geo_b, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
+static hipError_t claunch_one(int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
     if constexpr (KS <= 2) {
-        if (geo_b)
+        if (geo == 1)
             return claunch_geo<KS, 1, L2C_ROW_B, 6, L2C_NREC_B, 8>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx,
                                                                   cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
     }
+    if (geo == 2)
+        return claunch_geo<KS, 2, L2C_ROW_C, 4, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
+                                                            cand_tau, pad_tile, st, rows_valid, tau_init);
     return claunch_geo<KS, 1, L2C_ROW, 8, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau,
                                                       pad_tile, st, rows_valid, tau_init);
 }
 
-// Which geometry serves lists of `lkeep_want` kept entries: B (two waves per SIMD) up to 23, KS <= 2 (its 256 registers
-// per wave hold two steps of operands); A otherwise.  NABO_L2C_GEO=a|b pins one where it can serve the lists at all.
-bool l2c_geometry_b(int kc, int lkeep_want)
+// Which geometry serves lists of `lkeep_want` kept entries: 1 = B (two waves per SIMD) up to 23 entries and KS <= 2 (its
+// 256 registers per wave hold two steps of operands), 0 = A up to 32, 2 = C up to 64; -1: none.  NABO_L2C_GEO=a|b|c pins
+// one where it can serve the lists at all.
+int l2c_geometry(int kc, int lkeep_want)
 {
     const char *pin = getenv("NABO_L2C_GEO");
-    if (kc > 4 || lkeep_want > L2C_ROW_B) return false;
-    return !(pin && pin[0] == 'a');
+    if (lkeep_want > 64) return -1;
+    if (lkeep_want > 32 || (pin && pin[0] == 'c')) return 2;
+    if (kc > 4 || lkeep_want > L2C_ROW_B || (pin && pin[0] == 'a')) return 0;
+    return 1;
 }
 
 void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 {
-    if (l2c_geometry_b(kc, lkeep_want)) {
-        *rows_per_wg = 8 * 96;
-        *lkeep_max = L2C_ROW_B;
-    } else {
-        *rows_per_wg = 4 * 128;
-        *lkeep_max = L2C_ROW < 32 ? L2C_ROW : 32;
+    switch (l2c_geometry(kc, lkeep_want)) {
+    case 1: *rows_per_wg = 8 * 96; *lkeep_max = L2C_ROW_B; break;
+    case 2: *rows_per_wg = 4 * 64; *lkeep_max = 64; break;
+    default: *rows_per_wg = 4 * 128; *lkeep_max = L2C_ROW < 32 ? L2C_ROW : 32; break;
     }
     *wg_per_cu = 1;
 }
 
 // steps of 16 slots of the one-product operands (g components + two norm slots + the error slot), even (KS = kc / 2
-// steps of 32 slots), instantiated values only
+// steps of 32 slots), instantiated values only: g <= 125
 int l2c_pick_kc(int g)
 {
     const int need = 2 * ((g + 3 + 31) / 32);
-    return need <= 6 ? need : -1;
+    return need <= 8 ? need : -1;
 }
 
 // The split's padding must cover the ring: the kernel reads tiles up to t_end + 3 (as pad_tile) -- all of them are the
-// caller's padding tile, never past the allocation.  geo_b: what l2c_geometry_b said when the caller sized its grid.
-hipError_t l2c_topk_launch(int kc, bool geo_b, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+// caller's padding tile, never past the allocation.  geo: what l2c_geometry said when the caller sized its grid.
+hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
-    if (geo_b && (kc > 4 || lkeep > L2C_ROW_B)) return hipErrorInvalidValue;
+    if (geo < 0 || geo > 2 || (geo == 1 && (kc > 4 || lkeep > L2C_ROW_B)) || (geo == 0 && lkeep > 32) || lkeep > 64)
+        return hipErrorInvalidValue;
     switch (kc) {
-    case 2: return claunch_one<1>(geo_b, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
-    case 4: return claunch_one<2>(geo_b, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
-    case 6: return claunch_one<3>(false, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 2: return claunch_one<1>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 4: return claunch_one<2>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 6: return claunch_one<3>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 8: return claunch_one<4>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
     default: return hipErrorInvalidValue;
     }
 }

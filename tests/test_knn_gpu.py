@@ -444,8 +444,10 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     assert kernels["f16x3s"].startswith("l2s_topk" if (g <= 52 and kk + 4 <= 24) else ("l2h_topk", "l2_topk")), kernels
     assert kernels["f16x3q"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels          # 16x16x32 MFMA shape
     assert kernels["f16x3"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels                 # the default f16x3 kernel
-    assert kernels["f16x1"].startswith("l2c_topk" if h_ok else "l2_topk") and ("one-product" in kernels["f16x1"]) == h_ok, kernels
-    assert kernels["f16x1h"].startswith("l2h_topk" if h_ok else "l2_topk") and ("one-product" in kernels["f16x1h"]) == h_ok, kernels
+    # the one-product pass: g <= 125 and k' + 4 <= 64 (lists of 23 / 32 / 64 kept entries: geometries B / A / C of l2c_topk.hip)
+    c_ok = g <= 125 and kk + 4 <= 64
+    assert kernels["f16x1"].startswith("l2c_topk" if c_ok else "l2_topk") and ("one-product" in kernels["f16x1"]) == c_ok, kernels
+    assert kernels["f16x1h"].startswith("l2h_topk" if h_ok else ("l2c_topk" if c_ok else "l2_topk")), kernels
 
 
 @pytest.mark.parametrize("flags", ["7", "3", "1", "2"])
@@ -973,3 +975,38 @@ def test_small_query_pads_cost_no_list_work(gpu_lib):
     ix.close()
     _check(gi, gd, oi, od)
     assert best1 < 0.6 * t512, (best1, t512)
+
+
+@pytest.mark.parametrize("m,n,g,k,drop,metric", [
+    (3000, 40000, 100, 50, False, 2),        # BASELINE configs[4]'s metric / shape: cosine, d = 100, k = 50 -> four steps, 64-entry lists
+    (2000, 30000, 100, 50, True, 0),
+    (1500, 20000, 64, 30, False, 0),         # first g without an f16x3 kernel, lists of 38
+    (2500, 50000, 30, 40, False, 0),         # g < 64 with k' > 28: 64-entry lists on two steps (the hand-scheduled statements)
+    (700, 9000, 125, 15, False, 0),          # the last g the one-product operands are instantiated for (128 slots)
+    (700, 9000, 126, 15, False, 0),          # ... and the first one beyond: fp32 filter
+    (900, 12000, 90, 56, False, 0),          # k' = 56: the longest lists (64 kept entries)
+    (900, 12000, 90, 56, True, 0),           # k' = 57: beyond them, the exact kernels
+])
+def test_one_product_pass_wide_lists_and_many_components(gpu_lib, m, n, g, k, drop, metric):
+    """The one-product pass serves every g <= 125 (g + 3 operand slots in steps of 32) and every k' <= 56 (geometry C of
+    l2c_topk.hip: 64-entry lists); behind it sit the seeded pass and, where no f16x3 kernel exists (g >= 64 or k' > 28), the
+    fp32-MFMA filter.  Same bits as the oracle, and as the fp32 filter run alone."""
+    Y = pca_like(n, g, seed=4100 + n + g)
+    X = Y[:m].copy() if drop else pca_like(m, g, seed=4200 + m + g)
+    oi, od = oracle.knn(X, Y, k, metric, 0.25, drop_first=drop, nthreads=8)
+    ix = gpu_lib.KnnIndex(n, g, metric=metric).set_ref(Y)
+    gi, gd = ix.query(X, k, drop_first=drop)
+    st, kern = ix.last_stats(), ix.last_kernel()
+    ix.close()
+    _check(gi, gd, oi, od)
+    kk = k + (1 if drop else 0)
+    if kk > 56:                                          # NABO_MAX_K: the exact float64 kernels answer every row
+        assert kern.startswith("exact_dist_rows_kernel"), kern
+        return
+    if g <= 125:
+        ks = (g + 3 + 31) // 32
+        geo = "1,23,6,32,8" if (kk + 8 <= 23 and ks <= 2) else ("1,33,8,64,4" if kk <= 24 else "2,65,4,64,4")
+        assert kern.startswith("l2c_topk_kernel<%d,%s>" % (ks, geo)), kern
+    else:
+        assert kern.startswith("l2_topk_kernel"), kern
+    assert st["fallback_rows"] <= m // 50, st
