@@ -247,6 +247,10 @@ struct nabo_index {
     //   from the failed certificates (l2c kernel only; 32-entry lists);  2  the f16x3 pass;  then the 64-entry lists
     //   (wide_retry) and the exact float64 kernels.
     bool coarse = false;
+    // Set when the one-product passes of a query (>= 1024 rows) left more than a quarter of the rows to the pass behind
+    // them: the bound 2^-9 ||x|| ||y|| is too weak for this reference set (tight clusters far from the centre of the data),
+    // and the next queries start with the pass behind it right away.  Cleared by set_ref / set_mask.
+    bool coarse_weak = false;
     int pass_level = 0;
     const float *seed_tau = nullptr;      // level 1: one threshold per row of the batch
     int kc1 = 0;
@@ -548,6 +552,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         ix->ref_tiles = (ix->n + 31) / 32;
         ix->ref_tiles_alloc = ix->ref_tiles + 64;      // room for split padding (+inf-norm tiles; up to 32 splits)
         ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
+        ix->coarse_weak = false;
         if ((rc = ix->centre.reserve((size_t)ix->g * sizeof(double)))) return rc;
         if (ix->metric == NABO_METRIC_COSINE) {
             // cosine: the filter sees the unit-length rows x^, y^ and works on ||x^ - y^||^2 = 2 (1 - cos).  That quantity is
@@ -668,6 +673,7 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
     }
     if (ix->metric != NABO_METRIC_MOD_CANBERRA && ix->ksteps > 0) {       // masked cells carry ||y||^2 = +inf in the packed tiles
         ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
+        ix->coarse_weak = false;
         if ((rc = ensure_packed(ix, ix->coarse ? 2 : ix->mode == 1 ? 1 : 0))) return rc;
     }
     return NABO_OK;
@@ -766,7 +772,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // serves the list length the pass wants (l2c_topk.hip: two waves per SIMD up to 23 kept entries, 32-entry lists,
         // 64-entry lists for k' > 24), unless the locality order, the 32x32x16 experiment or an A/B run sends the operands
         // through the l2q / l2h kernel (those serve 32-entry lists and g < 64 only).
-        const bool pass1 = ix->coarse && ix->pass_level < 2 && !ix->wide_retry && (!cand_mode || kk + 3 <= 32);
+        const bool pass1 = ix->coarse && !(ix->coarse_weak && env_int("NABO_COARSE_ADAPT", 1) != 0) && ix->pass_level < 2 &&
+                           !ix->wide_retry && (!cand_mode || kk + 3 <= 32);
         // (k' > 24, the 64-entry lists: six entries more -- there a row the first pass fails is expensive, the pass behind the
         // seeded one is the fp32 filter: cosine 1M x 1M, d = 100, k = 50: 689 -> 597 ms per step)
         const int slack1 = env_int("NABO_COARSE_SLACK", epl == 2 ? 6 : 0);
@@ -1085,6 +1092,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             ix->seed_tau = seed_saved;
             if (rc) return rc;
             ix->pass_rows[next - 1] = nf;
+            if (here == 0 && m >= 1024 && ix->pass_rows[1] > m / 4) ix->coarse_weak = true;
             n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
             HIP_TRY(nabo::scatter_rows_launch(ix->tmpip[b].as<int64_t>(), ix->tmpdp[b].as<double>(), ix->failsp[b].as<uint32_t>(),
                                               nf, k, d_oidx, d_odist, st));

@@ -55,7 +55,10 @@ constexpr bool L2C_ABLATED = false;
 //      (BASELINE configs[4]: k = 50), which the fp32-MFMA kernel served before.
 constexpr int L2C_NREC = 64;        // staging records (8 scores each) per wave, geometry A
 constexpr int L2C_ROW = 33;         // list entries per row (odd), geometry A
-constexpr int L2C_NREC_B = 32;
+#ifndef NABO_L2C_NREC_B
+#define NABO_L2C_NREC_B 32
+#endif
+constexpr int L2C_NREC_B = NABO_L2C_NREC_B;
 constexpr int L2C_ROW_B = 23;
 constexpr int L2C_ROW_C = 65;
 

@@ -913,13 +913,15 @@ def test_one_product_pass_chain_equals_the_oracle(gpu_lib, geo, offset):
         ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
         gi, gd = ix.query(X, k)
         st, kern = ix.last_stats(), ix.last_kernel()
-        os.environ["NABO_SEEDED_PASS"] = "0"             # the chain without its seeded link
+        os.environ["NABO_SEEDED_PASS"] = "0"             # the chain without its seeded link ...
+        os.environ["NABO_COARSE_ADAPT"] = "0"            # ... and with the first pass even where the first query found it weak
         hi, hd = ix.query(X, k)
         st2 = ix.last_stats()
         ix.close()
     finally:
         os.environ.pop("NABO_L2C_GEO", None)
         os.environ.pop("NABO_SEEDED_PASS", None)
+        os.environ.pop("NABO_COARSE_ADAPT", None)
     _check(gi, gd, oi, od)
     _check(hi, hd, oi, od)
     assert kern.startswith("l2c_topk_kernel<2,1,%s>" % ("33,8,64,4" if geo == "a" else "23,6,32,8")), kern
@@ -1010,3 +1012,25 @@ def test_one_product_pass_wide_lists_and_many_components(gpu_lib, m, n, g, k, dr
     else:
         assert kern.startswith("l2_topk_kernel"), kern
     assert st["fallback_rows"] <= m // 50, st
+
+
+def test_weak_one_product_bound_is_remembered_until_the_references_change(gpu_lib):
+    """Tight clusters far from the centre of the data: the one-product passes leave (nearly) every row to the f16x3 pass.  The
+    index notices (more than a quarter of >= 1024 rows) and starts the NEXT queries with the f16x3 filter; set_ref starts over.
+    Same bits every time."""
+    n, m, g, k = 30000, 3000, 40, 15
+    Y, X = _offset_clusters(n, g, 21, 40.0), _offset_clusters(m, g, 22, 40.0)
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    kernels, second = [], []
+    for it in range(3):
+        if it == 2:
+            ix.set_ref(Y)
+        gi, gd = ix.query(X, k)
+        _check(gi, gd, oi, od)
+        kernels.append(ix.last_kernel())
+        second.append(ix.last_stats()["second_pass_rows"])
+    ix.close()
+    assert kernels[0].startswith("l2c_topk") and second[0] > m // 4, (kernels, second)
+    assert kernels[1].startswith("l2q_topk") and second[1] == 0, (kernels, second)
+    assert kernels[2].startswith("l2c_topk"), kernels
