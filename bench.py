@@ -341,20 +341,28 @@ def main():
     alt_layout = None
     want_alt = (ranks >= 4 and ranks % 2 == 0 and R == ranks and a.metric != "canberra" and not a.no_extras and not ablate
                 and not os.environ.get("NABO_REF_SHARDS"))
+    alt_slices = None
     if want_alt:
+        def other_layout(R2):
+            """the same ranks laid out as R2 reference pieces x ranks / R2 target slices: timed like the headline, same bits required"""
+            lay2 = Layout(a, kind, ranks, R2, comm, rank, dev, X, Yfull, metric_id)
+            dt2 = lay2.run()
+            per2, max2 = lay2.rank_stats()
+            ai, ad = lay2.result()
+            out = {"layout": {"ref_shards": R2, "target_slices": ranks // R2},
+                   "workload": "refs sharded %d-way x %d target slices" % (R2, ranks // R2),
+                   "ms_per_step": dt2 / a.steps * 1e3, "value": m * n * a.steps / dt2,
+                   "same_bits_as_headline_layout": bool(np.array_equal(ai, gi) and np.array_equal(ad, gd)),
+                   "candidates_per_shard": int(lay2.xstats[-1][0]["candidates"]),
+                   "second_round_rows": int(max(x[0]["uncertified"] for x in lay2.xstats)),
+                   "max_over_ranks_ms": max2, "per_rank_ms": per2}
+            return lay2, out
         lay.close()
-        lay2 = Layout(a, kind, ranks, 2, comm, rank, dev, X, Yfull, metric_id)
-        dt2 = lay2.run()
-        per2, max2 = lay2.rank_stats()
-        ai, ad = lay2.result()
-        alt_layout = {"layout": {"ref_shards": 2, "target_slices": ranks // 2},
-                      "workload": "refs sharded 2-way x %d target slices" % (ranks // 2),
-                      "ms_per_step": dt2 / a.steps * 1e3, "value": m * n * a.steps / dt2,
-                      "same_bits_as_headline_layout": bool(np.array_equal(ai, gi) and np.array_equal(ad, gd)),
-                      "candidates_per_shard": int(lay2.xstats[-1][0]["candidates"]),
-                      "second_round_rows": int(max(x[0]["uncertified"] for x in lay2.xstats)),
-                      "max_over_ranks_ms": max2, "per_rank_ms": per2}
-        lay = lay2
+        lay, alt_layout = other_layout(2)
+        # ... and pure target slicing (every rank holds all the references and certifies its own slice: no exchange, one
+        # all-gather) -- not BASELINE configs[3]'s layout, reported beside it because it is the cheapest one at every N
+        lay.close()
+        lay, alt_slices = other_layout(1)
 
     if rank == 0:
         shards, slices = R, ranks // R
@@ -417,6 +425,8 @@ def main():
                                "max_over_ranks_ms": rank_max, "per_rank_ms": hx if kind != "launcher" else hx[:1]}
         if alt_layout is not None:
             line["alt_layout"] = alt_layout
+        if alt_slices is not None:
+            line["alt_layout_target_slices"] = alt_slices
         extras = kind == "single" and not a.no_extras and not ablate
         if extras and a.metric == "euclidean" and not os.environ.get("NABO_L2_MODE"):
             line["alt"] = alt_block(nabo_amd, _knn, "f32" if "f16" in kern else "f16x3", dev, n, m, d, k, lay.dY, lay.dXb, gi, gd, lay.sync)

@@ -828,7 +828,9 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
             rc = api_fail(NABO_E_UNSUPPORTED, "global certification needs the Euclidean / cosine filter and k'/N <= 32");
         else {
             global = protocol == 1 || (protocol == 0 && can_cand && N > 1);
-            Ls = global ? nabo_candidates_per_shard(kk, R, m) : 0;
+            // (R = 1, pure target slicing: a rank holds ALL the references, its own certified first k' entries ARE the answer --
+            // they travel through the same merge / certificate / gather with a bound of +inf)
+            Ls = global ? (R == 1 ? kk : nabo_candidates_per_shard(kk, R, m)) : 0;
             // the owner's merge sorts one wave-wide batch of at most 1024 (distance, index) pairs per row
             if (global && (int64_t)R * Ls > 1024)
                 rc = api_fail(NABO_E_UNSUPPORTED, "ref_shards * candidates per shard = %d x %d exceeds the merge width 1024", R, Ls);
@@ -873,7 +875,13 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
         // kept entries more than emitted); with many pieces it lies far beyond it and the shorter lists win (one rank of
         // eight: 25 instead of 32 ms, one refused row at 1M x 1M).
         nabo::index_set_cand_slack(ix, Ls >= kk ? 3 : 0);
-        if (!rc && ms > 0)
+        if (!rc && ms > 0 && R == 1) {
+            // one piece: the certified local query (with its whole chain of passes behind the first filter), nothing is left out
+            hipLaunchKernelGGL(fill_absent_kernel, dim3((unsigned)((ms + blk - 1) / blk)), dim3(blk), 0, st, (int64_t *)nullptr,
+                               (double *)nullptr, (int64_t)0, c->cb.as<double>(), ms);
+            if (hipGetLastError() != hipSuccess) rc = api_fail(NABO_E_HIP, "fill_absent_kernel launch failed");
+            if (!rc) rc = local_topk(c, ix, X + s0 * g, ms, kk, c->ci.as<int64_t>(), c->cd.as<double>());
+        } else if (!rc && ms > 0)
             rc = nabo_index_query_candidates(ix, X + s0 * g, 1, ms, Ls, c->ci.as<int64_t>(), c->cd.as<double>(), c->cb.as<double>());
     } else {
         // local certification: every shard's own first k' order-row entries

@@ -403,6 +403,10 @@ def test_bench_prints_the_baseline_layout_as_headline_and_the_2d_layout_beside_i
     assert line["sharded"]["layout"] == {"ref_shards": 8, "target_slices": 1} and len(line["sharded"]["per_rank_ms"]) == 8
     assert line["alt_layout"]["layout"] == {"ref_shards": 2, "target_slices": 4}
     assert line["alt_layout"]["same_bits_as_headline_layout"] is True and line["sampled_rows_equal_oracle"] is True
+    # pure target slicing (every rank holds all the references, certifies its own slice, no exchange) beside both
+    ts = line["alt_layout_target_slices"]
+    assert ts["layout"] == {"ref_shards": 1, "target_slices": 8} and ts["same_bits_as_headline_layout"] is True
+    assert ts["second_round_rows"] == 0
     assert all("ms_exchange" in e["sharded"] and "ms_topk" in e["index"] for e in line["sharded"]["per_rank_ms"])
 
 
