@@ -47,6 +47,9 @@ constexpr int CBB_B = NABO_CBB_B;         // quantile buckets per dimension (sur
 constexpr int CBB_ROWS = CBB_B + 1;       // cumulative rows per dimension (row 0: empty set)
 constexpr int CBB_BLK = 2048;             // references per block: 64 lanes x 32 bits
 constexpr int CBB_T = 8;                  // target rows per wave (six count planes each, in registers: < 128 VGPRs per wave)
+#ifndef NABO_CBB_TB
+#define NABO_CBB_TB 8
+#endif
 constexpr int CBB_NW = 16;                // waves per workgroup (four per SIMD): they share the LDS copy of the table rows
 
 int cbb_buckets() { return CBB_B; }
@@ -159,6 +162,7 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                        uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau)
 {
     constexpr int T = CBB_T, NW = CBB_NW;
+    constexpr int TB = T < NABO_CBB_TB ? T : NABO_CBB_TB;      // targets per batch of row reads (their LDS reads fly together)
     constexpr int L = 32 * EPL, CAP = L + 16 * EPL;      // kept + pending entries per list
     constexpr int WLN = 256;                             // work-list ring (entries; <= 63 pending + 64 new)
     constexpr int ROWW = CBB_ROWS * 64;                  // words of one dimension's rows
@@ -319,45 +323,65 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int b = 0; b < 6; ++b) pl[t][b] = 0u;
-        for (int dp = 0; dp < npair; ++dp) {
-            // the next pair's rows (the next block's first behind the last) travel while this one is counted
-            const bool more = dp + 1 < npair || blk + 1 < b_end;
-            if (more) fetch(dp + 1 < npair ? blk : blk + 1, dp + 1 < npair ? dp + 1 : 0);
-            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + buf * 2 * ROWW + lane);
-            // ONE LDS read hands the pair's row offsets of all T targets to the wave (lane t holds target t's two words;
-            // v_readlane then makes them scalars) -- a read + wait per target made the step a chain of LDS latencies
-            const uint32_t myro = *reinterpret_cast<const uint32_t *>(ro + (lane & (T - 1)) * GP + 2 * dp);     // (lo0, hi0, lo1, hi1)
-            // (an odd g: the second half of the last pair is a padding dimension's (0, 0): the mask is x & ~x = 0)
-            constexpr int TB = T < 8 ? T : 8;                    // targets per batch of row reads
-#pragma unroll
-            for (int t0 = 0; t0 < T; t0 += TB) {
-                uint32_t m0[TB], m1[TB];
-#pragma unroll
-                for (int i = 0; i < TB; ++i) {                   // all the row reads of a batch fly together
-                    const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane((int)myro, t0 + i);   // row numbers -> byte offsets (x 256)
-                    m0[i] = *reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFF00u))) &
-                            ~*reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFFu) << 8));
-                    m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 16) & 0xFF00u)) &
-                            ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 8) & 0xFF00u));
-                }
-#pragma unroll
-                for (int i = 0; i < TB; ++i) {
-                    const int t = t0 + i;
-                    // carry-save: (carry, ones) = ones + m0 + m1, then the carry ripples through the planes above
-                    uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0xE8);
-                    pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0x96);
-#pragma unroll
-                    for (int b = 1; b < 6; ++b) {
-                        const uint32_t carry = pl[t][b] & c;
-                        pl[t][b] ^= c;
-                        c = carry;
-                    }
-                }
-            }
-            if (more) commit(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
+        // Steps come in twos (round 3): the carries out of the lowest plane of two consecutive steps (weight 2 each) wait in a
+        // register and enter plane 1 TOGETHER through a second 3:2 compressor, and only its carry (weight 4) ripples through
+        // planes 2..5 -- 14 instructions per two steps and target instead of 24 (MODE 1: first of two, 2: second, 0: a
+        // single step with the full ripple, the last one of an odd number).
+        // One straight-line copy of the step per role, no lambdas around the plane arrays (captured arrays went to scratch):
+        // STASH = first of two (the weight-2 carry waits in c1a), otherwise it combines (a lone last step combines with 0).
+        uint32_t c1a[T];
+#define CBB_STEP(DP, STASH)                                                                                              \
+        {                                                                                                                \
+            const int dp_ = (DP);                                                                                        \
+            const bool more = dp_ + 1 < npair || blk + 1 < b_end;                                                        \
+            if (more) fetch(dp_ + 1 < npair ? blk : blk + 1, dp_ + 1 < npair ? dp_ + 1 : 0);                             \
+            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + buf * 2 * ROWW + lane);            \
+            const uint32_t myro = *reinterpret_cast<const uint32_t *>(ro + (lane & (T - 1)) * GP + 2 * dp_);             \
+            _Pragma("unroll") for (int t0 = 0; t0 < T; t0 += TB) {                                                       \
+                uint32_t m0[TB], m1[TB];                                                                                 \
+                _Pragma("unroll") for (int i = 0; i < TB; ++i) {                                                         \
+                    const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane((int)myro, t0 + i);                          \
+                    m0[i] = *reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFF00u))) &                                 \
+                            ~*reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFFu) << 8));                              \
+                    m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 16) & 0xFF00u)) &                \
+                            ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 8) & 0xFF00u));                 \
+                }                                                                                                        \
+                _Pragma("unroll") for (int i = 0; i < TB; ++i) {                                                         \
+                    const int t = t0 + i;                                                                                \
+                    uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0xE8);                              \
+                    pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0x96);                                \
+                    if (STASH) {                                                                                         \
+                        c1a[t] = c;                                                                                      \
+                    } else {                                                                                             \
+                        const uint32_t c4 = __builtin_amdgcn_bitop3_b32(pl[t][1], c1a[t], c, 0xE8);                      \
+                        pl[t][1] = __builtin_amdgcn_bitop3_b32(pl[t][1], c1a[t], c, 0x96);                               \
+                        c = c4;                                                                                          \
+                        _Pragma("unroll") for (int b = 2; b < 6; ++b) {                                                  \
+                            const uint32_t carry = pl[t][b] & c;                                                         \
+                            pl[t][b] ^= c;                                                                               \
+                            c = carry;                                                                                   \
+                        }                                                                                                \
+                    }                                                                                                    \
+                }                                                                                                        \
+            }                                                                                                            \
+            if (more) commit(buf ^ 1);                                                                                   \
+            __syncthreads();                                                                                             \
+            buf ^= 1;                                                                                                    \
         }
+        // ONE LDS read hands the pair's row offsets of all T targets to the wave (lane t holds target t's two words;
+        // v_readlane then makes them scalars) -- a read + wait per target made the step a chain of LDS latencies; all the row
+        // reads of a batch of TB targets fly together.  (An odd g: the second half of the last pair is a padding
+        // dimension's (0, 0): the mask is x & ~x = 0.)
+        for (int dp0 = 0; dp0 < npair; dp0 += 2) {
+            const bool lone = dp0 + 1 >= npair;
+            if (!lone) CBB_STEP(dp0, true)
+            else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) c1a[t] = 0u;
+            }
+            CBB_STEP(lone ? dp0 : dp0 + 1, false)
+        }
+#undef CBB_STEP
         // inw >= thr ?  bit-sliced comparator per target (all T unrolled: the planes are registers), then the survivors
         // into the ring, target by target
         uint32_t gev[T];
