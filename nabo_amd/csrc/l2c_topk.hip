@@ -133,11 +133,51 @@ __device__ __forceinline__ cmins cmin8x2(const cacc &acc)
                  : "v"(a[0][0]), "v"(a[0][1]), "v"(a[1][0]), "v"(a[1][1]), BC(b1[0]), BC(b1[1]), \
                    "v"(old.v[1][1][0]), "v"(old.v[1][1][1]), "v"(old.v[1][1][2]), "v"(old.v[1][1][3]), \
                    "v"(m0), "v"(tau0), "v"(tau1));
+// The same for FOUR steps of 32 slots (94 <= g <= 125: BASELINE configs[4], d = 100): two statements of eight MFMAs, one
+// filter instruction behind each of the first ten.
+#define L2C_PAIR4_STATEMENTS(BC) \
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %4, %12, 0\n\t" \
+                 "v_min_f32 %2, %16, %17\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %5, %13, %0\n\t" \
+                 "v_min3_f32 %2, %2, %18, %19\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %6, %14, %0\n\t" \
+                 "v_min3_f32 %2, %2, %20, %21\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %7, %15, %0\n\t" \
+                 "v_min3_f32 %2, %2, %22, %23\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %8, %12, 0\n\t" \
+                 "v_min_f32 %3, %24, %25\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %9, %13, %1\n\t" \
+                 "v_min3_f32 %3, %3, %26, %27\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %10, %14, %1\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %11, %15, %1" \
+                 : "=&v"(r00), "=&v"(r01), "=&v"(m0), "=&v"(m1) \
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3]), \
+                   BC(b0[0]), BC(b0[1]), BC(b0[2]), BC(b0[3]), \
+                   "v"(old.v[0][0][0]), "v"(old.v[0][0][1]), "v"(old.v[0][0][2]), "v"(old.v[0][0][3]), \
+                   "v"(old.v[0][1][0]), "v"(old.v[0][1][1]), "v"(old.v[0][1][2]), "v"(old.v[0][1][3]), \
+                   "v"(old.v[1][0][0]), "v"(old.v[1][0][1]), "v"(old.v[1][0][2]), "v"(old.v[1][0][3])); \
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %5, %13, 0\n\t" \
+                 "v_min3_f32 %4, %4, %17, %18\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %6, %14, %0\n\t" \
+                 "v_min3_f32 %4, %4, %19, %20\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %7, %15, %0\n\t" \
+                 "v_cmp_lt_f32_e64 %2, %21, %22\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %0, %8, %16, %0\n\t" \
+                 "v_cmp_lt_f32_e64 %3, %4, %23\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %9, %13, 0\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %10, %14, %1\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %11, %15, %1\n\t" \
+                 "v_mfma_f32_16x16x32_f16 %1, %12, %16, %1" \
+                 : "=&v"(r10), "=&v"(r11), "=&s"(h0), "=&s"(h1), "+v"(m1) \
+                 : "v"(a[0][0]), "v"(a[0][1]), "v"(a[0][2]), "v"(a[0][3]), "v"(a[1][0]), "v"(a[1][1]), "v"(a[1][2]), "v"(a[1][3]), \
+                   BC(b1[0]), BC(b1[1]), BC(b1[2]), BC(b1[3]), \
+                   "v"(old.v[1][1][0]), "v"(old.v[1][1][1]), "v"(old.v[1][1][2]), "v"(old.v[1][1][3]), \
+                   "v"(m0), "v"(tau0), "v"(tau1));
 template <int KS, bool BAGPR>
 __device__ __forceinline__ void cpair(const f16x8 (&a)[2][KS], const f16x8 (&b0)[KS], const f16x8 (&b1)[KS], cacc &cur,
                                       const cacc &old, float tau0, float tau1, cmins &mm, uint64_t &hit)
 {
-    static_assert(KS == 2, "hand schedule for two steps of 32 slots (g <= 61); other shapes take the builtin path");
+    static_assert(KS == 2 || KS == 4, "hand schedules for two (g <= 61) and four (94 <= g <= 125) steps of 32 slots; other shapes take the builtin path");
     float m0, m1;
     uint64_t h0, h1;
     f32x4 &r00 = cur.v[0][0], &r01 = cur.v[0][1], &r10 = cur.v[1][0], &r11 = cur.v[1][1];
@@ -146,7 +186,10 @@ __device__ __forceinline__ void cpair(const f16x8 (&a)[2][KS], const f16x8 (&b0)
     // each other only (vector-ALU interlocks), never on an MFMA of this tile.
     // (BAGPR: the B operands are pinned in AGPRs -- one wave per SIMD; at two waves per SIMD they stay in arch VGPRs, see
     // the kernel: with AGPRs in play hipcc parks accumulators there and copies them right behind these statements)
-    if constexpr (BAGPR) {
+    if constexpr (KS == 4) {
+        static_assert(BAGPR, "four steps: one wave per SIMD only");
+        L2C_PAIR4_STATEMENTS("a")
+    } else if constexpr (BAGPR) {
         L2C_PAIR_STATEMENTS("a")
     } else {
         L2C_PAIR_STATEMENTS("v")
@@ -287,7 +330,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
 
     // tile sets in flight: four at one wave per SIMD (tile t + 3 is requested at the top of step t); two at two waves per
     // SIMD, where the other wave covers the latency and 256 registers have to hold everything
-    constexpr int RING = WAVES > 4 ? 2 : 4;
+    // (... and at four operand steps with eight row-blocks: 4 x 32 + 2 x 64 + ... arch VGPRs would not fit 256, hipcc would
+    // park values in AGPRs -- see the B operands above for why that must not happen next to inline-assembly MFMAs)
+    constexpr int RING = (WAVES > 4 || (KS >= 4 && NBv >= 8)) ? 2 : 4;
     f16x8 a0[2][KS], a1[2][KS], a2[2][KS], a3[2][KS];
     tile_load(a0, t_begin);
     if (RING == 4) {
@@ -330,14 +375,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             abl_cnt += ((mm[p].m0 < tauv[2 * p]) | (mm[p].m1 < tauv[2 * p + 1])) ? 1 : 0;
             hit[p] = 0;
 #else
-            if constexpr (KS == 2 && !L2C_BUILTIN) {
+            if constexpr ((KS == 2 || KS == 4) && !L2C_BUILTIN) {
                 cpair<KS, (WAVES <= 4)>(a, xb[2 * p], xb[2 * p + 1], cur[p], old[p], tauv[2 * p], tauv[2 * p + 1], mm[p], hit[p]);
             } else {                                    // hipcc's own schedule of builtin MFMAs (other shapes; A/B runs)
                 mm[p] = cmin8x2(old[p]);
                 hit[p] = __builtin_amdgcn_ballot_w64((mm[p].m0 < tauv[2 * p]) | (mm[p].m1 < tauv[2 * p + 1]));
             }
 #endif
-            if constexpr (KS != 2 || L2C_BUILTIN || L2C_ABLATED) {
+            if constexpr ((KS != 2 && KS != 4) || L2C_BUILTIN || L2C_ABLATED) {
                 cur[p] = cchain<KS>(a, xb[2 * p], xb[2 * p + 1]);
                 // one MFMA, then at most two of the filter's instructions (what fits beside a 16-cycle MFMA)
                 L2C_SG(2) L2C_SG(2) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1) L2C_SG(1)

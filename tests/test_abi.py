@@ -91,8 +91,8 @@ def test_inline_assembly_mfma_kernels_keep_accumulators_out_of_agprs():
     """l2c_topk.hip issues its MFMAs from inline assembly (hand-scheduled with the filter's instructions): hipcc neither knows
     their latency nor pads their hazards, so it must never touch an accumulator right behind them -- which it does as soon as
     it parks accumulators in AGPRs (v_accvgpr_write / _read copies; seen at two waves per SIMD with the B operands pinned in
-    AGPRs: wrong neighbours).  Compile the file to assembly and require that the hand-scheduled kernels (two steps of 32
-    slots, both geometries) contain no AGPR copy at all and spill nothing."""
+    AGPRs: wrong neighbours).  Compile the file to assembly and require that the hand-scheduled kernels (two and four steps
+    of 32 slots, every geometry) contain no AGPR copy at all and spill nothing."""
     import re
     import subprocess
     from nabo_amd import _build
@@ -102,12 +102,12 @@ def test_inline_assembly_mfma_kernels_keep_accumulators_out_of_agprs():
     assert r.returncode == 0, r.stderr[-2000:]
     asm = r.stdout
     seen = 0
-    for m in re.finditer(r"^(_ZN4nabo15l2c_topk_kernelILi2E\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
-        name, body = m.group(1), m.group(2)
+    for m in re.finditer(r"^(_ZN4nabo15l2c_topk_kernelILi([24])E\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
+        name, body = m.group(1), m.group(3)
         seen += 1
         assert body.count("v_mfma_f32_16x16x32_f16") >= 48, name
         assert "v_accvgpr" not in body, name
         assert "scratch_" not in body, name
-    assert seen == 3, seen        # geometries A, B, C
+    assert seen == 5, seen        # two steps: geometries A, B, C; four steps: A, C
     for m in re.finditer(r"\.name:\s+(_ZN4nabo15l2c_topk_kernel\w+)\n(?:.*\n){1,12}?\s+\.vgpr_spill_count:\s+(\d+)", asm):
         assert int(m.group(2)) == 0, m.group(0)
