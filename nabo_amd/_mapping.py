@@ -676,8 +676,11 @@ class Mapping:
             node, nb, w = et, ej, ew
         # group by node, keep insertion order inside a node, drop repeated (node, neighbour) pairs:
         # a dict keeps the first position and the last value, as networkx's adjacency does
-        seq = np.arange(node.shape[0])
-        o = np.lexsort((seq, nb, node))
+        # (ONE stable sort of the composite key node << 32 | neighbour is np.lexsort((position, neighbour, node)) at a third
+        # of its time on 30M rows: node and neighbour are cell positions < 2^32)
+        if node.shape[0] and (int(node.max()) >> 32 or int(nb.max()) >> 32 or int(node.min()) < 0 or int(nb.min()) < 0):
+            raise ValueError("cell positions must fit 32 bits")
+        o = np.argsort((node.astype(np.uint64) << np.uint64(32)) | nb.astype(np.uint64), kind="stable")
         node_o, nb_o = node[o], nb[o]
         first = np.ones(o.shape[0], dtype=bool)
         first[1:] = (node_o[1:] != node_o[:-1]) | (nb_o[1:] != nb_o[:-1])
@@ -687,7 +690,10 @@ class Mapping:
         keep_first = o[first]
         w_keep = w[o[last_of]]
         node_k, nb_k = node[keep_first], nb[keep_first]
-        o2 = np.lexsort((keep_first, node_k))                   # by node, then insertion order
+        # by node, then insertion order (the keys are unique: the first positions are; < 2^32 rows)
+        if keep_first.shape[0] and int(keep_first.max()) >> 32:
+            raise ValueError("more than 2^32 edge rows")
+        o2 = np.argsort((node_k.astype(np.uint64) << np.uint64(32)) | keep_first.astype(np.uint64))
         node_k, nb_k, w_keep = node_k[o2], nb_k[o2], w_keep[o2]
         counts = np.bincount(node_k, minlength=n_t)
         starts = np.concatenate([[0], np.cumsum(counts)])
