@@ -334,6 +334,9 @@ class Mapping:
     communicator per GPU behind nabo_sharded_query, include/nabo_knn.h; results equal the one-GPU run bit for bit as
     long as at least k (+1 for the reference graph) reference cells are not ignored -- with fewer the one-GPU path
     continues a row with the ignored cells, as numpy.ma does, and the sharded one raises a ValueError).
+    `ref_shards` lays the devices out as that many pieces of the references x len(devices) / ref_shards slices of the
+    target rows (`nabo_comm_set_ref_shards`); 1 = every device holds all the references and answers its own slice of
+    the rows, the cheapest layout whenever the references fit one GPU.
     `graph_layout="columnar"`: the SNN graphs as four arrays per graph (node names, row pointers, neighbour positions,
     weights) instead of the reference's one dataset per node (nabo/_mapping.py:252-273) -- at 1M cells the per-node
     format IS the run time (23 of 28 s); `nabo_amd.get_mapping_score*` read either, `nabo_amd.expand_graph` rewrites a
@@ -346,7 +349,7 @@ class Mapping:
 
     def __init__(self, mapping_h5_fn, ref_name, ref_pca_fn, ref_pca_grp_name, overwrite=False, *,
                  device=0, devices=None, layout="per_cell", target_metric=None, shard_transport="rccl", store_k=None,
-                 graph_layout="per_node"):
+                 graph_layout="per_node", ref_shards=None):
         self._h5Fn = mapping_h5_fn
         if ref_name.find("__") != -1:
             raise ValueError("ERROR: Underscores are not allowed in the value for `ref_name` parameter")
@@ -365,6 +368,9 @@ class Mapping:
         self._devices = [int(d) for d in devices] if devices else [int(device)]
         self._device = self._devices[0]
         self._shardTransport = shard_transport       # "rccl", or "loopback" (device-to-device copies; devices may repeat)
+        # layout of the devices: None = one piece of the references per device (BASELINE's form); R = R pieces x
+        # len(devices) / R slices of the target rows; 1 = every device holds all the references and answers its own slice
+        self._refShards = None if ref_shards is None else int(ref_shards)
         self._layout = layout
         if graph_layout not in ("per_node", "columnar"):
             raise ValueError("ERROR: graph_layout must be 'per_node' or 'columnar'")
@@ -535,7 +541,7 @@ class Mapping:
                 raise ValueError("ERROR: only %d reference cells are not ignored, fewer than the %d neighbours to keep: "
                                  "map on one device (devices=None) or ignore fewer cells" % (n_ref - n_ign, k_store + drop))
             grp = ShardedGroup(self._devices, n_ref, self._useComps, metric, ref, dist_factor=float(self._distFactor),
-                               ref_mask=mask, transport=self._shardTransport)
+                               ref_mask=mask, transport=self._shardTransport, ref_shards=self._refShards)
             try:
                 idx, dist = grp.set_ref().query(X, k_store, drop_first=bool(drop))
             finally:

@@ -822,12 +822,15 @@ static int sharded_query_impl(nabo_comm *c, nabo_index *ix, const double *X, int
         // protocol: 0 auto, 1 global certification, 2 local certification
         const bool can_cand = nabo::index_can_emit_candidates(ix) && (kk + R - 1) / R <= 32;
         if (protocol < 0 || protocol > 2) rc = api_fail(NABO_E_INVALID, "protocol %d (0 auto, 1 global, 2 local certification)", protocol);
-        else if (R != N && (protocol == 2 || !can_cand))
+        else if (R != N && R != 1 && (protocol == 2 || !can_cand))
             rc = api_fail(NABO_E_UNSUPPORTED, "the 2-D shard layout (ref_shards = %d of %d ranks) needs the global-certification protocol", R, N);
-        else if (protocol == 1 && !can_cand)
+        else if (R == 1 && N > 1 && protocol == 2)
+            rc = api_fail(NABO_E_UNSUPPORTED, "pure target slicing (ref_shards = 1) runs through the global protocol's merge and gather (protocol 0 or 1)");
+        else if (protocol == 1 && !can_cand && R != 1)
             rc = api_fail(NABO_E_UNSUPPORTED, "global certification needs the Euclidean / cosine filter and k'/N <= 32");
         else {
-            global = protocol == 1 || (protocol == 0 && can_cand && N > 1);
+            // (R = 1: every metric -- a rank's certified local query of its own slice needs no candidate lists)
+            global = protocol == 1 || (protocol == 0 && (can_cand || R == 1) && N > 1);
             // (R = 1, pure target slicing: a rank holds ALL the references, its own certified first k' entries ARE the answer --
             // they travel through the same merge / certificate / gather with a bound of +inf)
             Ls = global ? (R == 1 ? kk : nabo_candidates_per_shard(kk, R, m)) : 0;

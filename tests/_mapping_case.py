@@ -239,6 +239,18 @@ def run_case(tag):
         _, tedges6, _ = read_graph_like_reference(map5, tn0_, "target")
         _, tedges0, _ = read_graph_like_reference(map_fn, tn0_, "target")
         out["sharded_devices_same_graphs"] = (edges6 == edges) and (tedges6 == tedges0)
+        # ... and the same devices as target slices (ref_shards = 1: every rank holds all the references; Euclidean for the
+        # reference graph, the modified-Canberra default for the target -- the layout serves every metric)
+        map7 = os.path.join(td, "mapping_slices.h5")
+        with redirect_stdout(buf):
+            m7 = nabo_amd.Mapping(map7, "WT", ref_fn, "data", overwrite=True, devices=[0, 0, 0], shard_transport="loopback",
+                                  ref_shards=1)
+            m7.set_parameters(uc, k, f, chunk)
+            m7.make_ref_graph()
+            m7.map_target(tn0_, os.path.join(td, "t_%s.h5" % tn0_), "data", ignore_ref_cells=ign0_)
+        _, edges7, _ = read_graph_like_reference(map7, "WT", "reference")
+        _, tedges7, _ = read_graph_like_reference(map7, tn0_, "target")
+        out["target_slices_same_graphs"] = (edges7 == edges) and (tedges7 == tedges0)
         # dense [N, n_comps] input (rows deliberately NOT in name order) gives the same graph
         ref_dense = os.path.join(td, "ref_dense.h5")
         perm = np.random.default_rng(3).permutation(len(rn))

@@ -59,6 +59,7 @@ def test_mapping_end_to_end_vs_reference_outputs(mode):
             assert v < 1e-9, (k, v)
     assert res["stored_distances_same_graph"] and res["columnar_same_graph"] and res["dense_input_same_graph"]
     assert res["sharded_devices_same_graphs"]
+    assert res["target_slices_same_graphs"]
     assert res["store_k_serves_larger_k_per_cell"] and res["store_k_serves_larger_k_columnar"] and res["no_store_k_raises"]
     assert res["target_metric_euclidean"]
     assert res["columnar_graph_same_scores"] and res["columnar_graph_expands_to_the_wire_format"]

@@ -280,7 +280,8 @@ def test_abort_from_another_thread_releases_the_waiting_ranks(gpu_lib):
 @pytest.mark.parametrize("N,R,m,n,g,k,drop,metric,sorted_refs", [
     (8, 2, 3001, 9000, 24, 15, False, 0, False), (4, 2, 700, 5000, 50, 11, True, 0, False),
     (8, 4, 1234, 12000, 30, 10, False, 2, False), (6, 3, 999, 6000, 16, 15, True, 0, True),
-    (8, 1, 515, 4000, 20, 7, False, 0, False), (4, 2, 5, 3000, 12, 6, False, 0, False)])
+    (8, 1, 515, 4000, 20, 7, False, 0, False), (4, 2, 5, 3000, 12, 6, False, 0, False),
+    (4, 1, 777, 5000, 30, 11, True, 1, False), (3, 1, 100, 2500, 64, 30, False, 2, False)])      # target slices: any metric
 def test_two_dimensional_layout_equals_oracle(gpu_lib, N, R, m, n, g, k, drop, metric, sorted_refs):
     """nabo_comm_set_ref_shards: R reference pieces x N / R target slices (exchange, merge and certificate inside each
     group of R ranks, the gather over all N) -- same answer as one device, on every rank, ragged slices and the second
