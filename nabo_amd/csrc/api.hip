@@ -223,6 +223,9 @@ struct nabo_index {
     int64_t base = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[6] = {};
+    // second stream: the refine of the main launch's rows runs beside the (short, split) tail launch of the filter
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_main = nullptr, ev_ref = nullptr;
     bool have_ref = false;
 
     const double *dY = nullptr;      // [n,g] float64 on device (borrowed or == ybuf)
@@ -506,6 +509,9 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
         ix->n_cu = cus;
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipEventCreate(&ix->ev[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_main, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ix->ev_ref, hipEventDisableTiming);
     if (e != hipSuccess) {
         nabo_index_destroy(ix);
         return fail(NABO_E_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
@@ -526,6 +532,9 @@ int nabo_index_destroy(nabo_index *ix)
     for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
         if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
+    if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
+    if (ix->ev_main) (void)hipEventDestroy(ix->ev_main);
+    if (ix->ev_ref) (void)hipEventDestroy(ix->ev_ref);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
     return NABO_OK;
@@ -883,6 +892,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             } else if (gx % slots != 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && ix->ref_tiles >= 256) {
                 const int64_t tail = gx % slots;
                 double best = 1.0;
+                // (at most 8 splits: 11 would fill the chip exactly at 1M x 1M -- kernel 0.6 ms shorter, refine of the tail
+                // rows' 11 lists 1.1 ms longer)
                 for (int s2 = 2; s2 <= 8; ++s2) {
                     const double t = (double)((tail * s2 + slots - 1) / slots) / s2;
                     if (t < best - 1e-9) { best = t; S2 = s2; }
@@ -937,6 +948,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                             ix->xpk.as<float>(), ix->xnorm.as<double>(), st));
         HIP_TRY(hipEventRecord(ix->ev[1], st));
         bool seedable = false;               // the l2c kernel ran: its failed rows can go through a seeded pass
+        bool refine_beside_tail = false;
         if (use_c) {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2s_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(), (int)tps, S,
@@ -957,6 +969,12 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                     HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
                                                   ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
                                                   ix->ref_tiles_alloc - 1, st, m, seeds));
+                // the tail launch (a fraction of a round, reference splits) leaves most CUs idle: the refine of the main
+                // launch's rows (an HBM gather) runs beside it on the second stream
+                if (gx_main > 0 && gx_tail > 0 && !cand_mode && env_int("NABO_REFINE_OVERLAP", 1) != 0) {
+                    HIP_TRY(hipEventRecord(ix->ev_main, st));
+                    refine_beside_tail = true;
+                }
                 if (gx_tail > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
                                                   rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
@@ -1045,11 +1063,17 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if ((rc = ix->failseed.reserve((size_t)m * sizeof(float)))) return rc;
             fail_seed = ix->failseed.as<float>();
         }
+        hipStream_t st_main = st;
+        if (refine_beside_tail) {
+            st_main = ix->stream2;
+            HIP_TRY(hipStreamWaitEvent(st_main, ix->ev_main, 0));
+        }
         HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
-                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f,
+                                    ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st_main, cosine ? 2 : 0, 0.0, 0.0f,
                                     lkeep, rperm, tperm, fail_seed));
+        if (refine_beside_tail) HIP_TRY(hipEventRecord(ix->ev_ref, st_main));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
                                         ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
@@ -1057,6 +1081,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                         tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
                                         ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep, rperm, tperm,
                                         fail_seed));
+        if (refine_beside_tail) HIP_TRY(hipStreamWaitEvent(st, ix->ev_ref, 0));
         HIP_TRY(hipEventRecord(ix->ev[3], st));
         HIP_TRY(hipMemcpyAsync(&n_fail, ix->failcnt.p, sizeof(n_fail), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -5,8 +5,10 @@
 // so the contraction  ||rep_y||^2 - 2 hi_x.hi_y - tx ey  needs KS = ceil((g + 3) / 32) steps of v_mfma_f32_16x16x32_f16
 // (2 at g = 50) where the f16x3 split of l2q_topk.hip needs 5.  tx ey >= the split's dropped terms (hi x lo, lo x hi,
 // lo x lo), so the score is a rigorous LOWER bound of the f16x3 score: the same lists, the same certificate in
-// refine.hip (with this kernel's accumulation coefficient), and a row the bound is too weak for goes through the f16x3
-// pass afterwards (api.hip: no_coarse).  On 1M x 1M x 50 the bound costs 3 % more staged scores and ~1 % of the rows.
+// refine.hip (with this kernel's accumulation coefficient), and a row the bound is too weak for goes on (api.hip:
+// pass_level) -- first through THIS kernel again, seeded (tau_init: the row starts from the threshold its failed
+// certificate implies and only collects what lies below it), then through the f16x3 / fp32 filter.  On 1M x 1M x 50 the
+// bound costs 3 % more staged scores and 0.7 % of the rows.  KS = 1 .. 4: every g <= 125.
 //
 // What a tile costs was measured on the l2q kernel at KS = 2 (tools/r3_coarse_ab.sh, 1M x 1M): the bare MFMA loop
 // 62 ms = the matrix pipe's rate, + 24 ms of filter instructions (14 per 8 MFMAs, bunched behind the chains they read),
@@ -18,9 +20,14 @@
 //     all the time, thresholds differ by the local density of the cells.)
 //   * a ring of FOUR register sets for the reference tiles (a set is 4 KS registers): tile t + 3 is requested at the
 //     top of step t, no scheduling fences -- three whole steps ahead instead of one;
-//   * a tile's scores wait one step in registers: their filter reads nothing an MFMA in flight writes, its instructions
-//     are spread two per MFMA by scheduling groups, and there is one verdict branch per TILE (see the kernel body);
-//   * the staging / drain code sits out of line behind that unlikely branch, the drain itself behind a real call.
+//   * a tile's scores wait one step in registers: their filter reads nothing an MFMA in flight writes, and there is one
+//     verdict branch per TILE (see the kernel body);
+//   * MFMAs and filter instructions are hand-scheduled inline-assembly statements for KS = 2 and 4 (cpair: one or two
+//     filter instructions behind each MFMA, an accumulator is ONE register quad from its first step to its last reader);
+//     the other shapes leave the same loop to hipcc with scheduling groups;
+//   * the staging / drain code sits out of line behind that unlikely branch, the drain itself behind a real call;
+//   * every vector instruction next to the MFMAs costs its ~4 issue cycles whoever issues it (also a second wave of the
+//     same SIMD): what counts is the instruction COUNT -- two waves per SIMD (geometry B) hide latency, not issue.
 #include <cstdio>
 #include <cstdlib>
 
