@@ -1,3 +1,4 @@
+# Canberra parity subset + the 1M x 1M step on the product library and on tools/ab variants:   bash tools/r3_cb3.sh product [variant ...]
 O=$PWD/gpurun_out/r3cb3; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_knn_gpu.py tests/test_mapping.py -m gpu -q -x -k "canberra or mapping" > $O/pytest.log 2>&1; rc=$?; echo "pytest rc=$rc $(tail -1 $O/pytest.log | cut -c1-200)"; if [ $rc != 0 ]; then tail -30 $O/pytest.log; exit 1; fi
 for v in "$@"; do

@@ -1,3 +1,4 @@
+# all layouts of eight loopback ranks on one GPU (ref_shards = 1, 2, 4, 8): GPU time of the whole protocol, second-round rows, slowest rank's phases
 mkdir -p gpurun_out/r3lb
 for R in 1 2 4 8; do
 NABO_REF_SHARDS=$R NABO_BENCH_LOOPBACK=8 NABO_BENCH_CHECK=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/r3lb/R$R.json 2> gpurun_out/r3lb/R$R.err; echo "R=$R rc=$?"
