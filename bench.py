@@ -19,13 +19,14 @@ N>1 runs however the file is launched:
     per GPU (nabo_comm_create_all = ncclCommInitAll) and one host thread per rank (nabo_amd.ShardedGroup).  Fewer than
     N visible GPUs is an error (exit code 2), never a silent one-GPU run.
 The N>1 headline is the layout BASELINE configs[3] names -- references sharded N ways, one piece per rank; the
-2 x N/2 layout (two reference pieces x N/2 target slices) is measured in the same invocation as the
-`alt_layout` block and must give the same bits.  (NABO_BENCH_LOOPBACK=N rehearses all of it with N shard-ranks on ONE
-GPU through the loopback transport.)
+2 x N/2 layout (two reference pieces x N/2 target slices; N >= 4) and pure target slicing (every
+rank holds all the references and answers its own m/N rows: no exchange) are measured in the same invocation as the
+`alt_layout` / `alt_layout_target_slices` blocks and must give the same bits.  (NABO_BENCH_LOOPBACK=N rehearses all of
+it with N shard-ranks on ONE GPU through the loopback transport.)
 
 The default N=1 line also carries (outside the timed region): `canberra` -- the reference's default target<->reference
 metric (nabo/_mapping.py:122-124) on the same 1M x 1M workload, checked against the oracle on sampled rows;
-`alt` -- the other Euclidean filter kernel on the same step (same bits required); `cpu_baseline` -- the oracle on this
+`alt`, `alt_f16x3` -- the fp32-MFMA filter / the f16x3 split as the first pass on the same step (same bits required); `cpu_baseline` -- the oracle on this
 box's host cores (OpenMP and single thread) and the reference-style end-to-end run of BASELINE configs[0].
 """
 import argparse
@@ -339,7 +340,7 @@ def main():
 
     # the other layout of the same ranks, same invocation, same bits required (every rank takes part)
     alt_layout = None
-    want_alt = (ranks >= 4 and ranks % 2 == 0 and R == ranks and a.metric != "canberra" and not a.no_extras and not ablate
+    want_alt = (ranks >= 2 and R == ranks and a.metric != "canberra" and not a.no_extras and not ablate
                 and not os.environ.get("NABO_REF_SHARDS"))
     alt_slices = None
     if want_alt:
@@ -357,8 +358,9 @@ def main():
                    "second_round_rows": int(max(x[0]["uncertified"] for x in lay2.xstats)),
                    "max_over_ranks_ms": max2, "per_rank_ms": per2}
             return lay2, out
-        lay.close()
-        lay, alt_layout = other_layout(2)
+        if ranks >= 4 and ranks % 2 == 0:
+            lay.close()
+            lay, alt_layout = other_layout(2)
         # ... and pure target slicing (every rank holds all the references and certifies its own slice: no exchange, one
         # all-gather) -- not BASELINE configs[3]'s layout, reported beside it because it is the cheapest one at every N
         lay.close()
