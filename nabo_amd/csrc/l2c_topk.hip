@@ -206,37 +206,74 @@ __device__ __forceinline__ void cpair(const f16x8 (&a)[2][KS], const f16x8 (&b0)
     hit = h0 | h1;
 }
 
-// Staging of one row-block's hits (topk_lists.h: one record of 8 scores per hitting lane), with WAVE-UNIFORM control flow:
-// the record count lives in a scalar register, the only per-lane code is the record write.  Lanes that do not fit wait
-// for a drain and then look again at the thresholds it left (NREC may be smaller than a wave: up to 64 lanes hit at once).
-template <typename C, int NB, int NREC>
-__device__ __forceinline__ void cstage(bool h, const f32x4 &lo, const f32x4 &hi, float m, int rb, uint32_t jb, unsigned char *w,
-                                       uint32_t &scnt, int lkeep, float (&tauv)[NB])
+// Staging of a PAIR of row-blocks' hits (topk_lists.h: one record of 8 scores per hitting lane), with WAVE-UNIFORM control
+// flow: the record count lives in a scalar register, the only per-lane code is the record write.  The usual episode has
+// room for every hitting lane of both row-blocks: one room test, no loop.  Otherwise (cstage_full) lanes that do not fit
+// wait for a drain and then look again at the threshold it left (NREC may be smaller than a wave: up to 64 lanes hit at
+// once).  A drain does NOT touch the register copies of the thresholds here: the kernel reloads them once, after the
+// tile's episodes (`drained`) -- refreshed inside, hipcc copied all of them out and back in around every episode's join
+// with this rare path (twelve moves and a wait for the staging writes per episode).  Until then they are stale, i.e. too
+// large, which only stages a few scores that the next drain drops.
+template <typename C, int NREC>
+__device__ __forceinline__ void cstage_full(bool h, const f32x4 &lo, const f32x4 &hi, float m, uint32_t row, uint32_t jb,
+                                            unsigned char *w, uint32_t &scnt, int lkeep, bool &drained)
 {
     uint64_t b = __builtin_amdgcn_ballot_w64(h);
     while (b != 0) {
         const uint32_t room = (uint32_t)NREC - scnt;
         if (room == 0) {
-            lists_drain<C, NB>(w, scnt, lkeep, tauv);
+            lists_drain_only<C>(w, scnt, lkeep);
             scnt = 0;
-            h = h && (m < tauv[rb]);
+            drained = true;
+            h = h && (m < C::tauL(w)[row]);
             b = __builtin_amdgcn_ballot_w64(h);
             continue;
         }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
         const bool take = h && rank < room;
         if (take) {
-            const uint32_t p = scnt + rank;
-            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + p * C::RS);
+            const uint32_t q = scnt + rank;
+            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + q * C::RS);
             rp[0] = lo;
             rp[1] = hi;
-            C::shdr(w)[p] = make_uint2((uint32_t)(rb * C::RPB + (lane_id() & (C::RPB - 1))), jb);
+            C::shdr(w)[q] = make_uint2(row, jb);
         }
         const uint32_t n = (uint32_t)__builtin_popcountll(b);
         scnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(scnt + (n < room ? n : room)));
         h = h && !take;
         b = __builtin_amdgcn_ballot_w64(h);
     }
+}
+
+template <typename C, int NB, int NREC>
+__device__ __forceinline__ void cstage2(const cacc &acc, const cmins &m, int p, uint32_t jb, unsigned char *w, uint32_t &scnt,
+                                        int lkeep, const float (&tauv)[NB], bool &drained)
+{
+    const bool h0 = m.m0 < tauv[2 * p], h1 = m.m1 < tauv[2 * p + 1];
+    const uint64_t b0 = __builtin_amdgcn_ballot_w64(h0), b1 = __builtin_amdgcn_ballot_w64(h1);
+    const uint32_t n0 = (uint32_t)__builtin_popcountll(b0), n = n0 + (uint32_t)__builtin_popcountll(b1);
+    const uint32_t row = (uint32_t)(2 * p * C::RPB + (lane_id() & (C::RPB - 1)));
+    if (__builtin_expect(scnt + n <= (uint32_t)NREC, 1)) {
+        if (h0) {
+            const uint32_t q = scnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + q * C::RS);
+            rp[0] = acc.v[0][0];
+            rp[1] = acc.v[0][1];
+            C::shdr(w)[q] = make_uint2(row, jb);
+        }
+        if (h1) {
+            const uint32_t q = scnt + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+            f32x4 *rp = reinterpret_cast<f32x4 *>(C::srec(w) + q * C::RS);
+            rp[0] = acc.v[1][0];
+            rp[1] = acc.v[1][1];
+            C::shdr(w)[q] = make_uint2(row + (uint32_t)C::RPB, jb);
+        }
+        scnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(scnt + n));
+        return;
+    }
+    cstage_full<C, NREC>(h0, acc.v[0][0], acc.v[0][1], m.m0, row, jb, w, scnt, lkeep, drained);
+    // (the first row-block's drain may have brought the second one's threshold down; stale is safe, fresh stages less)
+    cstage_full<C, NREC>(h1, acc.v[1][0], acc.v[1][1], m.m1, row + (uint32_t)C::RPB, jb, w, scnt, lkeep, drained);
 }
 
 // Grid: x = target super-blocks (4 waves x 128 rows), y = reference splits.
@@ -403,15 +440,19 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             // the staging wave goes AHEAD of the SIMD's other wave (s_setprio; two waves per SIMD): it is back in its MFMA
             // loop sooner -- 0.6 ms of 102 at 1M x 1M; the other way round (the MFMA loop ahead) costs 1.5 ms
             __builtin_amdgcn_s_setprio(3);
+            bool drained = false;
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 if (hit[p] != 0) {
                     NABO_PROF_T0();
-                    cstage<C, NB, NREC>(mm[p].m0 < tauv[2 * p], old[p].v[0][0], old[p].v[0][1], mm[p].m0, 2 * p, jb, wl, scnt, lkeep, tauv);
-                    cstage<C, NB, NREC>(mm[p].m1 < tauv[2 * p + 1], old[p].v[1][0], old[p].v[1][1], mm[p].m1, 2 * p + 1, jb, wl, scnt, lkeep, tauv);
+                    cstage2<C, NB, NREC>(old[p], mm[p], p, jb, wl, scnt, lkeep, tauv, drained);
                     NABO_PROF_ADD(wl, 0, 1);
                     NABO_PROF_ADD(wl, 1, NABO_PROF_DT() >> 4);
                 }
+            }
+            if (drained) {
+#pragma unroll
+                for (int rb = 0; rb < NB; ++rb) tauv[rb] = C::tauL(wl)[rb * C::RPB + (lane & (C::RPB - 1))];
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -441,8 +482,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const cmins m = cmin8x2(accO[p]);
-            cstage<C, NB, NREC>(m.m0 < tauv[2 * p], accO[p].v[0][0], accO[p].v[0][1], m.m0, 2 * p, jb, wl, scnt, lkeep, tauv);
-            cstage<C, NB, NREC>(m.m1 < tauv[2 * p + 1], accO[p].v[1][0], accO[p].v[1][1], m.m1, 2 * p + 1, jb, wl, scnt, lkeep, tauv);
+            bool drained = false;
+            cstage2<C, NB, NREC>(accO[p], m, p, jb, wl, scnt, lkeep, tauv, drained);
         }
     }
 

@@ -92,9 +92,11 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
 {
     const int lane = lane_id();
     uint2 *rows = C::rows(w);
-    for (int e = lane; e < C::NROWS * lkeep; e += 64) {
-        const int r = e / lkeep, s = e - r * lkeep;
-        rows[r * C::ROW + s] = make_uint2(__float_as_uint(__builtin_inff()), 0xFFFFFFFFu);
+    // slots past lkeep (ROW >= lkeep) hold -inf: never the maximum, never evicted, never emitted -- the rescan walks
+    // whole compile-time batches without a bounds test per key
+    for (int e = lane; e < C::NROWS * C::ROW; e += 64) {
+        const int s = e % C::ROW;
+        rows[e] = make_uint2(__float_as_uint(s < lkeep ? __builtin_inff() : -__builtin_inff()), 0xFFFFFFFFu);
     }
     for (int r = lane; r < C::NROWS; r += 64) {
         C::tauL(w)[r] = tau0;
@@ -109,10 +111,46 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
 #ifndef NABO_RESCAN
 #define NABO_RESCAN 12
 #endif
+// New maximum (t) and its position (p) of a row's kept keys from slot I0 on, NABO_RESCAN keys per LDS round trip (a
+// one-key-at-a-time scan is a chain of lkeep dependent LDS latencies).  Batches are compile-time pieces of the row's
+// ROW slots -- the last one ends with the row -- and run while they begin below lkeep (wave-uniform): what a batch reads
+// past lkeep is -inf (lists_init), so no key needs a bounds test.  Two interleaved maximum chains (even / odd slots):
+// three instructions per key (compare, maximum, select) and no wait states between a compare and the select reading it.
+template <typename C, int I0>
+__device__ __forceinline__ void lists_rescan(const uint2 *kept, int lkeep, float &t, uint32_t &p)
+{
+    if constexpr (I0 < C::ROW) {
+        if (I0 < lkeep) {
+            constexpr int LEN = C::ROW - I0 < NABO_RESCAN ? C::ROW - I0 : NABO_RESCAN;
+            float kq[LEN];
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) kq[j] = __uint_as_float(kept[I0 + j].x);
+            float ta = t, tb = -__builtin_inff();
+            uint32_t pa = 0xFFFFFFFFu, pb = 0xFFFFFFFFu;          // position inside the batch, if the maximum moved into it
+#pragma unroll
+            for (int j = 0; j < LEN; ++j) {
+                if (j & 1) {
+                    const bool gt = kq[j] > tb;
+                    tb = fmaxf(kq[j], tb);
+                    pb = gt ? (uint32_t)j : pb;
+                } else {
+                    const bool gt = kq[j] > ta;
+                    ta = fmaxf(kq[j], ta);
+                    pa = gt ? (uint32_t)j : pa;
+                }
+            }
+            const bool gb = tb > ta;
+            t = gb ? tb : ta;
+            const uint32_t pj = gb ? pb : pa;
+            p = pj != 0xFFFFFFFFu ? (uint32_t)I0 + pj : p;
+            lists_rescan<C, I0 + LEN>(kept, lkeep, t, p);
+        }
+    }
+}
+
 template <typename C>
 __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt, int lkeep)
 {
-    constexpr int RESCAN = NABO_RESCAN;
     const int lane = lane_id();
     // volatile: lanes of one wave hand rows over to each other through these words.  The arbitration stores the lane
     // id and reads the word back to learn WHICH lane's store the LDS kept -- without volatile hipcc forwards the stored
@@ -165,37 +203,9 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
                 }
             }
             if (__builtin_amdgcn_ballot_w64(repl) != 0) {       // new maximum of the rows that changed
-                // RESCAN keys per round trip: a one-key-at-a-time scan is a chain of lkeep dependent LDS latencies;
-                // reads past lkeep (the next row, the header area) are masked
                 float t = -__builtin_inff();
                 uint32_t p = 0;
-                int i0 = 0;
-                // whole batches need no bounds test (three instructions per key: compare, two selects) ...
-                for (; i0 + RESCAN <= lkeep; i0 += RESCAN) {
-                    float kq[RESCAN];
-#pragma unroll
-                    for (int j = 0; j < RESCAN; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
-                    uint32_t pj = 0xFFFFFFFFu;                      // position inside the batch, if the maximum moved into it
-#pragma unroll
-                    for (int j = 0; j < RESCAN; ++j) {
-                        const bool gt = kq[j] > t;
-                        t = gt ? kq[j] : t;
-                        pj = gt ? (uint32_t)j : pj;
-                    }
-                    p = pj != 0xFFFFFFFFu ? (uint32_t)i0 + pj : p;
-                }
-                // ... the last, partial one masks what lies past lkeep
-                if (i0 < lkeep) {
-                    float kq[RESCAN];
-#pragma unroll
-                    for (int j = 0; j < RESCAN; ++j) kq[j] = __uint_as_float(kept[i0 + j].x);
-#pragma unroll
-                    for (int j = 0; j < RESCAN; ++j) {
-                        const bool gt = (i0 + j < lkeep) && (kq[j] > t);
-                        t = gt ? kq[j] : t;
-                        p = gt ? (uint32_t)(i0 + j) : p;
-                    }
-                }
+                lists_rescan<C, 0>(kept, lkeep, t, p);
                 tau = repl ? t : tau;
                 pm = repl ? p : pm;
             }
@@ -216,6 +226,21 @@ template <typename C>
 __device__ __noinline__ void lists_drain_fn(uint32_t w_off, uint32_t scnt, int lkeep)
 {
     lists_drain_body<C>((unsigned char *)(lds_byte *)(uintptr_t)w_off, scnt, lkeep);
+}
+
+// the drain alone (l2c_topk.hip refreshes its register copies of the thresholds once per tile, not per drain)
+template <typename C>
+__device__ __forceinline__ void lists_drain_only(unsigned char *w, uint32_t scnt, int lkeep)
+{
+    NABO_PROF_T0();
+#ifdef NABO_DRAIN_CALL
+    lists_drain_fn<C>((uint32_t)(uintptr_t)w, scnt, lkeep);
+#else
+    lists_drain_body<C>(w, scnt, lkeep);
+#endif
+    NABO_PROF_ADD(w, 2, 1);
+    NABO_PROF_ADD(w, 3, NABO_PROF_DT() >> 4);
+    NABO_PROF_ADD(w, 6, scnt);
 }
 
 // drain + refresh of the register copies of the thresholds (lane = row of its row-block)
