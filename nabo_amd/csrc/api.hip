@@ -904,6 +904,13 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (S > 1024 / L) S = 1024 / L;                     // refine merges at most 1024 candidates per row (32 or 16 lists)
         if (S < 1) S = 1;
         if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
+        {   // a list entry holds 25 bits of offset into its split (topk_lists.h): very large sets take more splits
+            const int64_t split_tiles = (NABO_LIST_SPLIT_REFS - 1) / 32;
+            const int64_t s_min = (ix->ref_tiles + split_tiles - 1) / split_tiles;
+            if (s_min > 1024 / L) return fail(NABO_E_INVALID, "more than 2^25 x (1024 / list length) reference cells in one index");
+            if (S < s_min) S = (int)s_min;
+            if (gx_tail > 0 && S2 < s_min) S2 = (int)s_min;
+        }
         const int64_t tps = (ix->ref_tiles + S - 1) / S;
         const int64_t tps2 = (ix->ref_tiles + S2 - 1) / S2;
         if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)

@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+// topk_lists.h: references one reference split (grid.y) may stream at most -- a list entry holds a 25-bit offset into its
+// split, all ones = "no reference"; api.hip raises the split count of larger sets
+#define NABO_LIST_SPLIT_REFS (((int64_t)1 << 25) - 1)
+
 namespace nabo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

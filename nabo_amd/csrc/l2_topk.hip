@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, (R * KSTEPS <= 25 && EPL == 1 ? 3 : R * KSTEPS
 #pragma unroll
     for (int rb = 0; rb < R; ++rb) tauv[rb] = tau0;
     uint32_t scnt = 0;
-    lists_init<C>(wl, lkeep, tau0);
+    lists_init<C>(wl, lkeep, tau0, (uint32_t)split * (uint32_t)tiles_per_split * 32u);
 
     // tile counters are 32-bit (n_ref < 2^32 - 16 => < 2^27 tiles): the loop test stays on the scalar unit
     const int t_begin = split * tiles_per_split;
@@ -273,6 +273,7 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st)
 {
+    if ((int64_t)tiles_per_split * 32 >= NABO_LIST_SPLIT_REFS) return hipErrorInvalidValue;   // topk_lists.h: 25 bits of offset per entry
 #define NABO_CASE(KS)                                                                                                 \
     case KS:                                                                                                          \
         if (epl == -1)                                                                                                \

@@ -271,6 +271,10 @@ __device__ __forceinline__ void cstage2(const cacc &acc, const cmins &m, int p, 
         scnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(scnt + n));
         return;
     }
+    // (the drain is a call: hipcc moves live registers around it, accumulators of the tile in flight included, and it does
+    // not know the inline-assembly MFMAs' latency.  At least 16 instructions lie between the tile's last MFMA and this
+    // point -- the 12 wait states an 8-pass MFMA's result needs; the pad makes it independent of that count)
+    asm volatile("s_nop 15" ::: "memory");
     cstage_full<C, NREC>(h0, acc.v[0][0], acc.v[0][1], m.m0, row, jb, w, scnt, lkeep, drained);
     // (the first row-block's drain may have brought the second one's threshold down; stale is safe, fresh stages less)
     cstage_full<C, NREC>(h1, acc.v[1][0], acc.v[1][1], m.m1, row + (uint32_t)C::RPB, jb, w, scnt, lkeep, drained);
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
         tauv[rb] = r < rows_valid ? ((tau_init && !(dbg & 1)) ? tau_init[r] : tau0) : -__builtin_inff();
     }
     uint32_t scnt = 0;
-    lists_init<C>(wl, lkeep, tau0);
+    lists_init<C>(wl, lkeep, tau0, (uint32_t)split * (uint32_t)tiles_per_split * 32u);
     {
         const int64_t nv = rows_valid - row0;            // valid rows of this wave
         if (nv < C::NROWS)
@@ -349,7 +353,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             uint2 *rows = C::rows(wl);
             for (int e = lane; e < C::NROWS * lkeep; e += 64) {
                 const int r = e / lkeep, sl = e - r * lkeep;
-                if (r < nv) rows[r * C::ROW + sl].x = __float_as_uint(tau_init[row0 + r]);
+                if (r < nv) rows[r * C::ROW + sl].y = __float_as_uint(tau_init[row0 + r]);
             }
             for (int r = lane; r < C::NROWS; r += 64)
                 if (r < nv) C::tauL(wl)[r] = tau_init[row0 + r];
@@ -569,6 +573,7 @@ hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsi
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
+    if ((int64_t)tiles_per_split * 32 >= NABO_LIST_SPLIT_REFS) return hipErrorInvalidValue;   // topk_lists.h: 25 bits of offset per entry
     if (geo < 0 || geo > 2 || (geo == 1 && (kc > 4 || lkeep > L2C_ROW_B)) || (geo == 0 && lkeep > 32) || lkeep > 64)
         return hipErrorInvalidValue;
     switch (kc) {

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void l2q_topk_kernel(const unsigned char *_
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) tauv[rb] = tau0;
     uint32_t scnt = 0;
-    lists_init<C>(wl, lkeep, tau0);
+    lists_init<C>(wl, lkeep, tau0, (uint32_t)split * (uint32_t)tiles_per_split * 32u);
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
@@ -316,6 +316,7 @@ hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, const int32_t *wave_start)
 {
+    if ((int64_t)tiles_per_split * 32 >= NABO_LIST_SPLIT_REFS) return hipErrorInvalidValue;   // topk_lists.h: 25 bits of offset per entry
 #define NABO_Q(KCV) case KCV: return qlaunch_one<KCV, 1, L2Q_ROW>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, wave_start);
     switch (kc) {
         NABO_Q(2) NABO_Q(4) NABO_Q(6) NABO_Q(8) NABO_Q(10) NABO_Q(12)

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, 1) void l2s_topk_kernel(const unsigned char *_
 #pragma unroll
     for (int rb = 0; rb < R; ++rb) tauv[rb] = tau0;
     uint32_t scnt = 0;
-    lists_init<C>(wl, lkeep, tau0);
+    lists_init<C>(wl, lkeep, tau0, (uint32_t)split * (uint32_t)tiles_per_split * 32u);
 
     const int t_begin = split * tiles_per_split;
     const int t_end = t_begin + tiles_per_split;
@@ -450,6 +450,7 @@ void l2s_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 hipError_t l2s_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st)
 {
+    if ((int64_t)tiles_per_split * 32 >= NABO_LIST_SPLIT_REFS) return hipErrorInvalidValue;   // topk_lists.h: 25 bits of offset per entry
     switch (kc) {
     case 2: return slaunch_one<2>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);
     case 4: return slaunch_one<4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, st);

@@ -22,9 +22,16 @@
 // The VGPR copy of a threshold is refreshed after every drain; between drains it is stale (too large), which only
 // stages a few scores that the drain then drops.  Thresholds are exact after every drain (no pending lists whose
 // entries do not count yet), so fewer scores are staged than with deferred compaction.
-// Kept lists start as lkeep sentinel entries (+inf, 0xFFFFFFFF): no "kept count"; a row that never sees lkeep real
+// Kept lists start as lkeep sentinel entries (+inf, no index): no "kept count"; a row that never sees lkeep real
 // candidates ends with threshold +inf (= nothing was dropped).  Lists are emitted unsorted: refine.hip orders the
 // candidates by their exact float64 distances anyway.
+// AN ENTRY IS A DOUBLE.  Its high word is the fp32 key, its low word (slot << 25) | (reference - first reference of the
+// split): as IEEE doubles such words order exactly as their fp32 keys do (sign-magnitude, the low word only breaks ties;
+// +-inf keys are finite doubles, NaN keys never get in), so the rescan after a replacement -- new maximum AND its
+// slot -- is ONE v_max_f64 per entry and one ds_read2_b64 per two, where key / position pairs took a compare, a
+// maximum and a select per key plus the wait states between them (~40 instead of ~105 instructions per rescan; the
+// rescans are most of what a drain costs).  25 bits of index: a split streams fewer than 2^25 - 1 references
+// (api.hip raises the split count for larger sets); the split's first reference is added back when lists are emitted.
 #pragma once
 #include "knn_common.h"
 
@@ -46,20 +53,25 @@ struct ListCfg {
     static_assert(ROW % 2 == 1, "odd row stride: lane-per-row walks spread over the LDS banks");
     static_assert(NREC <= 64 && NREC % 2 == 0, "one lane per staged record");
     // per-wave LDS block (16-byte aligned; BYTES is a multiple of 16):
-    //   srec [NREC][RS] f32 | rows [NROWS][ROW] uint2 | shdr [NREC] uint2 | tauL [NROWS] f32 | pmax [NROWS] u32 |
-    //   owner [NROWS] u32
+    //   srec [NREC][RS] f32 | rows [NROWS][ROW] uint2 (x = slot | offset, y = key) | shdr [NREC] uint2 | tauL [NROWS] f32 |
+    //   pmax [NROWS] u32 | owner [NROWS] u32 | base u32
     static constexpr int OFF_ROWS = NREC * RS * 4;
     static constexpr int OFF_SHDR = OFF_ROWS + NROWS * ROW * 8;
     static constexpr int OFF_TAU = OFF_SHDR + NREC * 8;
     static constexpr int OFF_PMAX = OFF_TAU + NROWS * 4;
     static constexpr int OFF_OWNER = OFF_PMAX + NROWS * 4;
+    static constexpr int OFF_BASE = OFF_OWNER + NROWS * 4;   // first reference of the split (entries hold offsets from it)
 #ifdef NABO_LISTS_PROF
-    static constexpr int OFF_PROF = OFF_OWNER + NROWS * 4;   // 16 u32 event counters / cycle sums (profiling builds only)
+    static constexpr int OFF_PROF = OFF_BASE + 16;           // 16 u32 event counters / cycle sums (profiling builds only)
     static constexpr int BYTES = OFF_PROF + 64;
     __device__ static uint32_t *prof(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_PROF); }
 #else
-    static constexpr int BYTES = OFF_OWNER + NROWS * 4;
+    static constexpr int BYTES = OFF_BASE + 16;
 #endif
+    static constexpr int IDX_BITS = 25;                      // entry low word: (slot << IDX_BITS) | offset of the reference
+    static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;   // (all ones: no reference -- a sentinel entry)
+    static_assert(ROWN <= 128, "seven bits of slot");
+    __device__ static uint32_t *base(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_BASE); }
     static_assert(BYTES % 16 == 0, "per-wave list block must keep 16-byte alignment");
     __device__ static float *srec(unsigned char *w) { return reinterpret_cast<float *>(w); }
     __device__ static uint2 *rows(unsigned char *w) { return reinterpret_cast<uint2 *>(w + OFF_ROWS); }
@@ -88,7 +100,7 @@ static __device__ unsigned long long nabo_lists_prof[8];
 
 // Sentinel kept lists, thresholds +inf (tau0 = -inf: "no hits" timing experiments).
 template <typename C>
-__device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float tau0)
+__device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float tau0, uint32_t idx_base)
 {
     const int lane = lane_id();
     uint2 *rows = C::rows(w);
@@ -96,8 +108,9 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
     // whole compile-time batches without a bounds test per key
     for (int e = lane; e < C::NROWS * C::ROW; e += 64) {
         const int s = e % C::ROW;
-        rows[e] = make_uint2(__float_as_uint(s < lkeep ? __builtin_inff() : -__builtin_inff()), 0xFFFFFFFFu);
+        rows[e] = make_uint2(((uint32_t)s << C::IDX_BITS) | C::IDX_MASK, __float_as_uint(s < lkeep ? __builtin_inff() : -__builtin_inff()));
     }
+    if (lane == 0) C::base(w)[0] = idx_base;
     for (int r = lane; r < C::NROWS; r += 64) {
         C::tauL(w)[r] = tau0;
         C::pmax(w)[r] = 0u;
@@ -111,39 +124,27 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
 #ifndef NABO_RESCAN
 #define NABO_RESCAN 12
 #endif
-// New maximum (t) and its position (p) of a row's kept keys from slot I0 on, NABO_RESCAN keys per LDS round trip (a
-// one-key-at-a-time scan is a chain of lkeep dependent LDS latencies).  Batches are compile-time pieces of the row's
-// ROW slots -- the last one ends with the row -- and run while they begin below lkeep (wave-uniform): what a batch reads
-// past lkeep is -inf (lists_init), so no key needs a bounds test.  Two interleaved maximum chains (even / odd slots):
-// three instructions per key (compare, maximum, select) and no wait states between a compare and the select reading it.
+// Largest entry of a row (as a double: the header comment) from slot I0 on, NABO_RESCAN entries per LDS round trip (a
+// one-at-a-time scan is a chain of lkeep dependent LDS latencies).  Batches are compile-time pieces of the row's ROW
+// slots -- the last one ends with the row -- and run while they begin below lkeep (wave-uniform): what a batch reads
+// past lkeep has a -inf key (lists_init), so nothing needs a bounds test.
 template <typename C, int I0>
-__device__ __forceinline__ void lists_rescan(const uint2 *kept, int lkeep, float &t, uint32_t &p)
+__device__ __forceinline__ void lists_rescan(const uint2 *kept, int lkeep, double &best)
 {
     if constexpr (I0 < C::ROW) {
         if (I0 < lkeep) {
             constexpr int LEN = C::ROW - I0 < NABO_RESCAN ? C::ROW - I0 : NABO_RESCAN;
-            float kq[LEN];
+            double e[LEN];
 #pragma unroll
-            for (int j = 0; j < LEN; ++j) kq[j] = __uint_as_float(kept[I0 + j].x);
-            float ta = t, tb = -__builtin_inff();
-            uint32_t pa = 0xFFFFFFFFu, pb = 0xFFFFFFFFu;          // position inside the batch, if the maximum moved into it
+            for (int j = 0; j < LEN; ++j) e[j] = reinterpret_cast<const double *>(kept)[I0 + j];
+            double other = e[LEN - 1];                        // two chains: a v_max_f64 need not wait for the one before it
 #pragma unroll
-            for (int j = 0; j < LEN; ++j) {
-                if (j & 1) {
-                    const bool gt = kq[j] > tb;
-                    tb = fmaxf(kq[j], tb);
-                    pb = gt ? (uint32_t)j : pb;
-                } else {
-                    const bool gt = kq[j] > ta;
-                    ta = fmaxf(kq[j], ta);
-                    pa = gt ? (uint32_t)j : pa;
-                }
+            for (int j = 0; j + 1 < LEN; ++j) {
+                if (j & 1) other = __builtin_fmax(other, e[j]);
+                else best = __builtin_fmax(best, e[j]);
             }
-            const bool gb = tb > ta;
-            t = gb ? tb : ta;
-            const uint32_t pj = gb ? pb : pa;
-            p = pj != 0xFFFFFFFFu ? (uint32_t)I0 + pj : p;
-            lists_rescan<C, I0 + LEN>(kept, lkeep, t, p);
+            best = __builtin_fmax(best, other);
+            lists_rescan<C, I0 + LEN>(kept, lkeep, best);
         }
     }
 }
@@ -170,7 +171,7 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
     if (mine) {
         const uint2 h = C::shdr(w)[lane];
         row = h.x;
-        jb = h.y;
+        jb = h.y - C::base(w)[0];                            // entries hold offsets from the split's first reference
         const float t = tauL[row];                           // which scores are below the row's threshold right now
 #pragma unroll
         for (int q4 = C::RS / 4 - 1; q4 >= 0; --q4) {
@@ -196,18 +197,19 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
                 const float key = rf[i];
                 repl = key < tau;
                 if (repl) {
-                    kept[pm] = make_uint2(__float_as_uint(key), jb + (uint32_t)((i & 3) + C::JSTRIDE * (i >> 2)));     // evict the largest kept entry
+                    // evict the largest kept entry
+                    kept[pm] = make_uint2((pm << C::IDX_BITS) | (jb + (uint32_t)((i & 3) + C::JSTRIDE * (i >> 2))), __float_as_uint(key));
 #ifdef NABO_LISTS_PROF
                     atomicAdd(&C::prof(w)[7], 1u);
 #endif
                 }
             }
             if (__builtin_amdgcn_ballot_w64(repl) != 0) {       // new maximum of the rows that changed
-                float t = -__builtin_inff();
-                uint32_t p = 0;
-                lists_rescan<C, 0>(kept, lkeep, t, p);
-                tau = repl ? t : tau;
-                pm = repl ? p : pm;
+                double best = __builtin_bit_cast(double, (uint64_t)0xFF800000u << 32);       // key -inf
+                lists_rescan<C, 0>(kept, lkeep, best);
+                const uint64_t bb = __builtin_bit_cast(uint64_t, best);
+                tau = repl ? __uint_as_float((uint32_t)(bb >> 32)) : tau;
+                pm = repl ? (uint32_t)bb >> C::IDX_BITS : pm;
             }
         }
         if (go) {
@@ -386,6 +388,7 @@ __device__ __forceinline__ void lists_flush(unsigned char *w, uint32_t scnt, int
                                             float (&tauv)[NB], uint32_t *__restrict__ cand_idx,
                                             float *__restrict__ cand_key, float *__restrict__ cand_tau)
 {
+    const uint32_t idx_base = C::base(w)[0];
     constexpr int LMAX = C::LMAX;
     const int lane = lane_id();
     if (scnt > 0) lists_drain<C, NB>(w, scnt, lkeep, tauv);
@@ -400,10 +403,11 @@ __device__ __forceinline__ void lists_flush(unsigned char *w, uint32_t scnt, int
         for (int r = 0; r < EPL; ++r) {
             const uint32_t e = (uint32_t)(r * 64 + lane);
             if (e < (uint32_t)LMAX) {
-                uint2 v = make_uint2(__float_as_uint(__builtin_inff()), 0xFFFFFFFFu);
+                uint2 v = make_uint2(C::IDX_MASK, __float_as_uint(__builtin_inff()));
                 if (e < (uint32_t)lkeep) v = rows[row * C::ROW + e];
-                cand_idx[o + e] = v.y;
-                if (cand_key) cand_key[o + e] = __uint_as_float(v.x);
+                const uint32_t off = v.x & C::IDX_MASK;
+                cand_idx[o + e] = off == C::IDX_MASK ? 0xFFFFFFFFu : idx_base + off;
+                if (cand_key) cand_key[o + e] = __uint_as_float(v.y);
             }
         }
         if (lane == 0) cand_tau[(lrow0 + row) * S + split] = C::tauL(w)[row];

@@ -92,7 +92,10 @@ def test_inline_assembly_mfma_kernels_keep_accumulators_out_of_agprs():
     their latency nor pads their hazards, so it must never touch an accumulator right behind them -- which it does as soon as
     it parks accumulators in AGPRs (v_accvgpr_write / _read copies; seen at two waves per SIMD with the B operands pinned in
     AGPRs: wrong neighbours).  Compile the file to assembly and require that the hand-scheduled kernels (two and four steps
-    of 32 slots, every geometry) contain no AGPR copy at all and spill nothing."""
+    of 32 slots, every geometry) spill nothing and contain no AGPR copy in any basic block that issues an MFMA nor within 16
+    instructions behind one -- AGPR parking around the drain CALL of the rare staging path (live registers moved out of the
+    callee's way, at one wave per SIMD where all 256 arch VGPRs are live) is fine: at least 16 instructions and an
+    explicit s_nop 15 lie between the tile's last MFMA and that path."""
     import re
     import subprocess
     from nabo_amd import _build
@@ -106,7 +109,23 @@ def test_inline_assembly_mfma_kernels_keep_accumulators_out_of_agprs():
         name, body = m.group(1), m.group(3)
         seen += 1
         assert body.count("v_mfma_f32_16x16x32_f16") >= 48, name
-        assert "v_accvgpr" not in body, name
+        since_mfma, block_has_mfma, block_has_acc = 10 ** 9, False, False
+        for line in body.split("\n"):
+            t = line.strip()
+            if not t or t.startswith(";"):
+                continue
+            if re.match(r"^\.?\w+:", t):                      # a label: a new basic block
+                assert not (block_has_mfma and block_has_acc), name
+                block_has_mfma = block_has_acc = False
+                continue
+            if t.startswith("v_mfma"):
+                since_mfma, block_has_mfma = 0, True
+                continue
+            since_mfma += 16 if t.startswith("s_nop 15") else 1
+            if t.startswith("v_accvgpr"):
+                block_has_acc = True
+                assert since_mfma > 16, (name, t)
+        assert not (block_has_mfma and block_has_acc), name
         assert "scratch_" not in body, name
     assert seen == 5, seen        # two steps: geometries A, B, C; four steps: A, C
     for m in re.finditer(r"\.name:\s+(_ZN4nabo15l2c_topk_kernel\w+)\n(?:.*\n){1,12}?\s+\.vgpr_spill_count:\s+(\d+)", asm):
