@@ -905,7 +905,10 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (S < 1) S = 1;
         if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
         {   // a list entry holds 25 bits of offset into its split (topk_lists.h): very large sets take more splits
-            const int64_t split_tiles = (NABO_LIST_SPLIT_REFS - 1) / 32;
+            // (NABO_SPLIT_REFS_MAX: tests lower the bound to see the rule at ordinary sizes)
+            int64_t split_refs = env_int("NABO_SPLIT_REFS_MAX", 0);
+            if (split_refs < 64 || split_refs > NABO_LIST_SPLIT_REFS) split_refs = NABO_LIST_SPLIT_REFS;
+            const int64_t split_tiles = (split_refs - 1) / 32;
             const int64_t s_min = (ix->ref_tiles + split_tiles - 1) / split_tiles;
             if (s_min > 1024 / L) return fail(NABO_E_INVALID, "more than 2^25 x (1024 / list length) reference cells in one index");
             if (S < s_min) S = (int)s_min;

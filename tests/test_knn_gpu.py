@@ -979,6 +979,30 @@ def test_small_query_pads_cost_no_list_work(gpu_lib):
     assert best1 < 0.6 * t512, (best1, t512)
 
 
+@pytest.mark.parametrize("m,mode", [(300, ""), (70000, ""), (300, "f16x3"), (300, "f32")])
+def test_large_reference_sets_take_more_splits(gpu_lib, monkeypatch, m, mode):
+    """A list entry holds the reference as a 25-bit offset into its split (topk_lists.h: the entry is a double -- key,
+    slot | offset -- so that a rescan is one v_max_f64 per entry); api.hip raises the split count of larger sets.  With the
+    bound lowered to 5000 references per split, 60 000 references need 13 splits where the planner would take fewer (one
+    for 70 000 rows, main and tail launch): same neighbours, same distances, and entries of every split carry the split's
+    first reference back (indices beyond 2^25 / 5000 come out right)."""
+    n, g, k = 60000, 50, 15
+    Y = pca_like(n, g, seed=91)
+    X = pca_like(m, g, seed=92)
+    rows = np.arange(m) if m <= 2000 else np.random.default_rng(3).choice(m, 600, replace=False)
+    oi, od = oracle.knn(X[rows], Y, k, 0, nthreads=8)
+    monkeypatch.setenv("NABO_SPLIT_REFS_MAX", "5000")
+    if mode:
+        monkeypatch.setenv("NABO_L2_MODE", mode)
+    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, k)
+    st = ix.last_stats()
+    ix.close()
+    assert st["splits"] >= 13, st
+    _check(gi[rows], gd[rows], oi, od)
+    assert st["fallback_rows"] == 0, st
+
+
 @pytest.mark.parametrize("m,n,g,k,drop,metric", [
     (3000, 40000, 100, 50, False, 2),        # BASELINE configs[4]'s metric / shape: cosine, d = 100, k = 50 -> four steps, 64-entry lists
     (2000, 30000, 100, 50, True, 0),
