@@ -226,6 +226,21 @@ int nabo_sharded_last_stats(const nabo_comm *c, double ms[8], int64_t counters[4
 int nabo_snn_counts(int32_t device, const int64_t *t_idx, int64_t m,
                     const int64_t *r_idx, int64_t n, int32_t k, int32_t *out_snn);
 
+/* ---- host-side graph assembly (consumers of the top-k; plain C++ on the caller's cores, no GPU needed) ------------
+ * nabo_pyset_order: rows [n,k] int64 of DISTINCT non-negative ints (HOST) -> perm [n,k] int32: the column order in which
+ * CPython iterates set(row).  nabo/_mapping.py:190-191 walks a cell's neighbours in that order and networkx keeps
+ * insertion order, so it is the row order of every node's dataset in the `<uid>_graph` groups (nabo/_mapping.py:252-273). */
+int nabo_pyset_order(const int64_t *rows, int64_t n, int32_t k, int32_t *perm);
+/* Connected components of an undirected edge list a[e] -- b[e] over nodes 0..n-1 (nabo/_mapping.py:203-214:
+ * nx.connected_components): labels[i] = smallest node index of i's component.  HOST pointers. */
+int nabo_component_labels(int64_t n, const int64_t *a, const int64_t *b, int64_t n_edges, int64_t *labels);
+/* Adjacency rows per node from (node, neighbour, weight) rows in insertion order, as networkx's dict-of-dicts keeps them
+ * and nabo/_mapping.py:252-273 dumps them: a node's neighbours in the order they were first added, a repeated (node,
+ * neighbour) pair keeps its first position and takes its LAST weight.  starts [n_nodes+1], nbr_out / w_out [n_rows]
+ * (the first starts[n_nodes] entries are used).  HOST pointers; node in [0, n_nodes), neighbour >= 0. */
+int nabo_group_edges(int64_t n_nodes, int64_t n_rows, const int64_t *node, const int64_t *nbr, const double *w,
+                     int64_t *starts, int64_t *nbr_out, double *w_out);
+
 /* ---- permutation null for mapping scores (EXTENSION: BASELINE.json configs[4]; the reference has the
  * score, Graph.get_mapping_score nabo/_graph.py:555-697, but no permutation test) -------------------------
  * Bipartite target->reference edges in CSR by reference node: row_ptr [n_ref+1], edge_t [E] (pooled target

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnabo_knn.so")
-SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "l2s_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "order.hip"]
+SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "l2s_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "order.hip", "host_graph.hip"]
 # per-file extra flags: -fno-honor-nans for the fp32 score kernel (scores are finite or +inf by construction; without it
 # every fminf tree starts with two v_max canonicalisations, and on gfx950 the fp32 MFMA cannot overlap vector-ALU work);
 # (NOT for l2h_topk.hip: its masked / padding cells carry an inf - inf = NaN low part, and the filter relies on NaN

@@ -22,7 +22,7 @@ SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
     "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
     "nabo_index_query_candidates",
-    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_merge_topk", "nabo_snn_counts", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
+    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_merge_topk", "nabo_snn_counts", "nabo_pyset_order", "nabo_component_labels", "nabo_group_edges", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
     "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
     "nabo_comm_rank", "nabo_comm_world", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",

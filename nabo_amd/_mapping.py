@@ -16,13 +16,14 @@ class stores exactly those: `<uid>_sortedDist/<cell>` holds the first k order en
 `<uid>_dist/<cell>` their distances (same positions), per cell like the reference, or as
 two [N,k] arrays with `layout='columnar'`.
 """
+import ctypes as C
 import os
 import random
 import string
 
 import numpy as np
 
-from . import _knn
+from . import _knn, _lib
 from ._lib import EUCLIDEAN, MOD_CANBERRA, COSINE
 
 __all__ = ["Mapping", "write_dense_pca"]
@@ -140,63 +141,18 @@ def pyset_iteration_order(rows):
     """For every row of DISTINCT non-negative ints: the permutation of its columns in which CPython iterates
     `set(row)` -- the order in which the reference's `for j in a` (nabo/_mapping.py:190-191) visits a cell's
     neighbours, hence the order of every node's rows in the `<uid>_graph` datasets (networkx keeps insertion
-    order).  Restates CPython's open-addressing set (Objects/setobject.c: 8-slot table, hash(int) = int,
-    9 linear probes, perturb shift 5, growth to the first power of two > 4*used once fill*5 >= mask*3; the
-    same in 3.7 .. 3.12), vectorised over the rows.  Pinned against the interpreter's own `set` by
+    order).  `nabo_pyset_order` (csrc/host_graph.hip) restates CPython's open-addressing set (Objects/setobject.c:
+    8-slot table, hash(int) = int, 9 linear probes, perturb shift 5, growth to the first power of two > 4*used once
+    fill*5 >= mask*3; the same in 3.7 .. 3.12) on the host's cores.  Pinned against the interpreter's own `set` by
     tests/test_host_logic.py and against the reference's files by the `*_graph_dst` goldens."""
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     n, k = rows.shape
+    perm = np.zeros((n, k), dtype=np.int32)
     if n == 0 or k == 0:
-        return np.zeros((n, k), dtype=np.int64)
-    if rows.min() < 0:
-        raise ValueError("ERROR: neighbour indices must be non-negative")
-
-    def place(table, rsel, cols, vals, mask):
-        """One insertion per selected row: column id cols[q] (hash vals[q]) into row rsel[q] of `table`
-        [n, mask+1] (-1 = empty): set_add_entry / set_insert_clean without the equality tests (keys differ)."""
-        i = vals & mask
-        perturb = vals.copy()
-        live = np.arange(rsel.size)
-        while live.size:
-            r, ii = rsel[live], i[live]
-            free = table[r, ii] < 0
-            table[r[free], ii[free]] = cols[live[free]]
-            live, r, ii = live[~free], r[~free], ii[~free]
-            if not live.size:
-                break
-            placed = np.zeros(live.size, dtype=bool)
-            lin = ii + 9 <= mask
-            for j in range(1, 10):
-                cand = np.nonzero(lin & ~placed)[0]
-                if not cand.size:
-                    break
-                fr = table[r[cand], ii[cand] + j] < 0
-                hit = cand[fr]
-                table[r[hit], ii[hit] + j] = cols[live[hit]]
-                placed[hit] = True
-            live, ii = live[~placed], ii[~placed]
-            perturb[live] >>= 5
-            i[live] = (ii * 5 + 1 + perturb[live]) & mask
-
-    mask = 7
-    table = np.full((n, mask + 1), -1, dtype=np.int64)
-    every = np.arange(n)
-    for c in range(k):
-        place(table, every, np.full(n, c, dtype=np.int64), rows[:, c].copy(), mask)
-        fill = c + 1
-        if fill * 5 >= mask * 3:                               # set_table_resize(used > 50000 ? used*2 : used*4)
-            minused = fill * 2 if fill > 50000 else fill * 4
-            newsize = 8
-            while newsize <= minused:
-                newsize <<= 1
-            old, mask = table, newsize - 1
-            table = np.full((n, newsize), -1, dtype=np.int64)
-            for s_ in range(old.shape[1]):                      # old entries re-inserted in table order
-                sub = np.nonzero(old[:, s_] >= 0)[0]
-                if sub.size:
-                    cc = old[sub, s_]
-                    place(table, sub, cc, rows[sub, cc].copy(), mask)
-    return table[table >= 0].reshape(n, k)                      # occupied slots of every row, left to right
+        return perm.astype(np.int64)
+    _lib.check(_lib.lib().nabo_pyset_order(rows.ctypes.data_as(C.c_void_p), C.c_int64(n), C.c_int32(k),
+                                           perm.ctypes.data_as(C.c_void_p)))
+    return perm.astype(np.int64)
 
 
 def snn_edges_from_counts(t_idx, cnt, k):
@@ -223,32 +179,34 @@ def snn_edges(t_idx, r_idx, k, device=0):
 
 
 def _component_labels(n, a, b):
-    """Connected-component label (= smallest member index) of every node of an undirected edge
-    list: label hooking + pointer jumping, vectorised.  Labels are member indices and never increase,
-    the smallest member keeps its own, so the fixed point is the component minimum."""
-    lab = np.arange(n, dtype=np.int64)
-    a = np.asarray(a, dtype=np.int64)
-    b = np.asarray(b, dtype=np.int64)
-    if a.size == 0:
-        return lab
-    while True:
-        la, lb = lab[a], lab[b]
-        lo, hi = np.minimum(la, lb), np.maximum(la, lb)
-        cut = hi != lo
-        if not cut.any():
-            return lab
-        a, b = a[cut], b[cut]                # edges inside one component stay there: drop them
-        new = lab.copy()
-        new[hi[cut]] = lo[cut]               # hook the larger root under the smaller one: every write is a
-                                             # strict decrease, so whichever of several writers wins is fine
-        while True:                          # flatten
-            nn = new[new]
-            if np.array_equal(nn, new):
-                break
-            new = nn
-        if np.array_equal(new, lab):
-            return lab
-        lab = new
+    """Connected-component label (= smallest member index) of every node of an undirected edge list
+    (`nabo_component_labels`, csrc/host_graph.hip: union-find, the larger root hooked under the smaller)."""
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    lab = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.lib().nabo_component_labels(C.c_int64(n), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p),
+                                                C.c_int64(a.shape[0]), lab.ctypes.data_as(C.c_void_p)))
+    return lab
+
+
+def group_edges(n_nodes, node, nb, w):
+    """(node, neighbour, weight) rows in insertion order -> (starts [n_nodes+1], neighbours, weights) grouped by node: a
+    node's neighbours in the order they were first added, a repeated pair keeps its first position and takes its last
+    weight -- what networkx's adjacency holds when the reference dumps it (nabo/_mapping.py:252-273).
+    `nabo_group_edges` (csrc/host_graph.hip): a stable counting sort by node + a per-node pass over the repeats."""
+    node = np.ascontiguousarray(node, dtype=np.int64)
+    nb = np.ascontiguousarray(nb, dtype=np.int64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    rows = node.shape[0]
+    starts = np.zeros(n_nodes + 1, dtype=np.int64)
+    nb_out = np.empty(rows, dtype=np.int64)
+    w_out = np.empty(rows, dtype=np.float64)
+    _lib.check(_lib.lib().nabo_group_edges(C.c_int64(n_nodes), C.c_int64(rows), node.ctypes.data_as(C.c_void_p),
+                                           nb.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                           starts.ctypes.data_as(C.c_void_p), nb_out.ctypes.data_as(C.c_void_p),
+                                           w_out.ctypes.data_as(C.c_void_p)))
+    kept = int(starts[-1])
+    return starts, nb_out[:kept], w_out[:kept]
 
 
 # ---- columnar graph layout (opt-in extension; the reference's per-node layout is the default) ---------------------
@@ -680,29 +638,10 @@ class Mapping:
             w = np.concatenate([np.repeat(ew, 2), np.repeat(xw, 2)])
         else:
             node, nb, w = et, ej, ew
-        # group by node, keep insertion order inside a node, drop repeated (node, neighbour) pairs:
-        # a dict keeps the first position and the last value, as networkx's adjacency does
-        # (ONE stable sort of the composite key node << 32 | neighbour is np.lexsort((position, neighbour, node)) at a third
-        # of its time on 30M rows: node and neighbour are cell positions < 2^32)
-        if node.shape[0] and (int(node.max()) >> 32 or int(nb.max()) >> 32 or int(node.min()) < 0 or int(nb.min()) < 0):
-            raise ValueError("cell positions must fit 32 bits")
-        o = np.argsort((node.astype(np.uint64) << np.uint64(32)) | nb.astype(np.uint64), kind="stable")
-        node_o, nb_o = node[o], nb[o]
-        first = np.ones(o.shape[0], dtype=bool)
-        first[1:] = (node_o[1:] != node_o[:-1]) | (nb_o[1:] != nb_o[:-1])
-        grp_id = np.cumsum(first) - 1
-        last_of = np.zeros(int(first.sum()), dtype=np.int64)
-        last_of[grp_id] = np.arange(o.shape[0])                 # last duplicate of every pair (ascending writes)
-        keep_first = o[first]
-        w_keep = w[o[last_of]]
-        node_k, nb_k = node[keep_first], nb[keep_first]
-        # by node, then insertion order (the keys are unique: the first positions are; < 2^32 rows)
-        if keep_first.shape[0] and int(keep_first.max()) >> 32:
-            raise ValueError("more than 2^32 edge rows")
-        o2 = np.argsort((node_k.astype(np.uint64) << np.uint64(32)) | keep_first.astype(np.uint64))
-        node_k, nb_k, w_keep = node_k[o2], nb_k[o2], w_keep[o2]
-        counts = np.bincount(node_k, minlength=n_t)
-        starts = np.concatenate([[0], np.cumsum(counts)])
+        # group by node, keep insertion order inside a node, drop repeated (node, neighbour) pairs: a dict keeps the
+        # first position and the last value, as networkx's adjacency does (group_edges)
+        starts, nb_k, w_keep = group_edges(n_t, node, nb, w)
+        counts = np.diff(starts)
         if self._graphLayout == "columnar":
             with h5py.File(self._h5Fn, mode="a") as h5:
                 if out_grp in h5:
@@ -713,8 +652,8 @@ class Mapping:
         uw, winv = np.unique(w_keep, return_inverse=True)
         wtxt = np.array([repr(float(x)).encode("ascii") for x in uw]) if len(uw) else np.empty(0, dtype="S1")
         width = max(32, ref_nodes.dtype.itemsize if n_r else 1)
-        rows = np.empty((node_k.shape[0], 2), dtype="S%d" % width)
-        if node_k.shape[0]:
+        rows = np.empty((nb_k.shape[0], 2), dtype="S%d" % width)
+        if nb_k.shape[0]:
             rows[:, 0] = ref_nodes[nb_k]
             rows[:, 1] = wtxt[winv]
         name_len = np.char.str_len(ref_nodes) if n_r else np.zeros(0, dtype=np.int64)

@@ -38,3 +38,32 @@ def test_snn_edges_from_counts_weights_and_order():
         assert tab[s] == round(s / (2 * (k - 1) - s), 2)
     with pytest.raises(ZeroDivisionError):              # k = 2, snn = 2: the reference divides by zero (:194)
         snn_edges_from_counts(np.array([[0, 1]]), np.array([[2, 1]], dtype=np.int32), 2)
+
+
+def test_native_host_helpers_equal_their_numpy_restatements():
+    """csrc/host_graph.hip against tests/_host_numpy.py (the forms the product used before): the set order on many rows
+    (threads), component labels of random forests + cycles, edge grouping with repeated pairs (first position, last weight)."""
+    from nabo_amd._mapping import _component_labels, group_edges
+    from tests._host_numpy import component_labels_numpy, group_edges_numpy, pyset_iteration_order_numpy
+    rng = np.random.default_rng(5)
+    for n, k, hi in ((20000, 15, 1000000), (5000, 50, 300), (9000, 23, 1 << 40)):
+        rows = np.argsort(rng.random((n, min(hi, 4 * k))), axis=1)[:, :k].astype(np.int64)
+        if hi > 4 * k:
+            rows = rows * (hi // (4 * k)) + rng.integers(0, hi // (4 * k), (n, 1))
+        assert np.array_equal(pyset_iteration_order(rows), pyset_iteration_order_numpy(rows))
+    for n, e in ((1, 0), (50, 0), (1000, 300), (20000, 15000), (20000, 90000)):
+        a, b = rng.integers(0, n, e), rng.integers(0, n, e)
+        lab = _component_labels(n, a, b)
+        assert np.array_equal(lab, component_labels_numpy(n, a, b))
+        assert (lab <= np.arange(n)).all() and np.array_equal(lab[lab], lab)
+    for n_nodes, rows_n, span in ((1, 0, 1), (7, 40, 5), (3000, 60000, 40), (50000, 400000, 100000)):
+        node = rng.integers(0, n_nodes, rows_n)
+        nb = rng.integers(0, span, rows_n)
+        w = np.round(rng.random(rows_n), 2)
+        s1, n1, w1 = group_edges(n_nodes, node, nb, w)
+        s2, n2, w2 = group_edges_numpy(n_nodes, node, nb, w)
+        assert np.array_equal(s1, s2) and np.array_equal(n1, n2) and np.array_equal(w1, w2)
+    with pytest.raises(ValueError):
+        group_edges(3, np.array([0, 3]), np.array([1, 1]), np.array([0.5, 0.5]))
+    with pytest.raises(ValueError):
+        _component_labels(3, np.array([0]), np.array([5]))
