@@ -67,3 +67,24 @@ def test_native_host_helpers_equal_their_numpy_restatements():
         group_edges(3, np.array([0, 3]), np.array([1, 1]), np.array([0.5, 0.5]))
     with pytest.raises(ValueError):
         _component_labels(3, np.array([0]), np.array([5]))
+
+
+def test_list_entries_order_as_doubles_like_their_fp32_keys():
+    """topk_lists.h keeps a list entry as ONE double -- high word the fp32 key, low word slot | offset -- and finds the
+    largest entry with v_max_f64.  The property it rests on, checked here on the host: for non-NaN keys (finite, +-inf,
+    zeros, denormals) the order of such doubles refines the order of the keys; none of them is a NaN or an infinity."""
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, 1e-45, -1e-45, 1.17549435e-38, -1.17549435e-38, 3.4028235e38, -3.4028235e38,
+                        1.0, -1.0], dtype=np.float32)
+    keys = np.concatenate([special, rng.standard_normal(4000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 4000).astype(np.float32),
+                           rng.integers(0, 1 << 32, 4000, dtype=np.uint64).astype(np.uint32).view(np.float32)])
+    keys = keys[~np.isnan(keys)]
+    lo = rng.integers(0, 1 << 32, keys.shape[0], dtype=np.uint64)
+    ent = ((keys.view(np.uint32).astype(np.uint64) << np.uint64(32)) | lo).view(np.float64)
+    assert np.isfinite(ent).all()
+    a, b = rng.integers(0, keys.shape[0], 200000), rng.integers(0, keys.shape[0], 200000)
+    lt = keys[a] < keys[b]
+    assert (ent[a][lt] < ent[b][lt]).all()                      # strictly smaller key => strictly smaller entry
+    m = np.maximum(ent[a], ent[b])                               # the maximum's key is the larger key
+    assert np.array_equal((m.view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32) >= np.maximum(keys[a], keys[b]),
+                          np.ones(a.shape[0], dtype=bool))
