@@ -521,21 +521,22 @@ class Mapping:
             return []
         ref = self._ref_matrix()
         size_of_node = sizes[inv]
-        order = np.argsort(inv, kind="stable")                     # members of every component, ascending index
-        starts = np.concatenate([[0], np.cumsum(sizes)])
-        new = []
         smax = sizes.max()
-        for ci in range(len(comps)):
-            sz = sizes[ci]
+        # components of one size share their mask (allowed = cells of strictly larger components): one mask upload and
+        # one query per DISTINCT size serve all of them; a component's edge is its best row by (distance, member, neighbour)
+        best_of = {}
+        for sz in np.unique(sizes):
             if sz == smax:                                          # no strictly larger component
                 continue
-            members = order[starts[ci]:starts[ci + 1]]
-            mask = (size_of_node <= sz).astype(np.uint8)            # allowed = cells of strictly larger components
-            index.set_mask(mask)
+            members = np.nonzero(size_of_node == sz)[0]             # ascending cell index
+            index.set_mask((size_of_node <= sz).astype(np.uint8))
             idx, dist = index.query(ref[members], 1)
-            best = int(np.lexsort((idx[:, 0], members, dist[:, 0]))[0])
-            new.append((int(members[best]), int(idx[best, 0]), weight))
-        return new
+            ci = inv[members]
+            o = np.lexsort((idx[:, 0], members, dist[:, 0], ci))
+            firsts = o[np.concatenate([[True], ci[o][1:] != ci[o][:-1]])]
+            for f in firsts:
+                best_of[int(ci[f])] = (int(members[f]), int(idx[f, 0]), weight)
+        return [best_of[c] for c in sorted(best_of)]               # in component order, as the reference adds them
 
     @staticmethod
     def _merge_labels(lab, new_edges):
