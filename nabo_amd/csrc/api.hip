@@ -972,7 +972,10 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
             // the l2q kernel on the one-product operands: A/B runs, and the locality-ordered stream (its home pre-pass)
             const bool coarse_on_q = !on_l2c;
-            seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0;
+            // (a seeded pass keeps at most L entries: where the first pass already does -- k' >= 50 on the 64-entry lists --
+            // it cannot certify what the first could not, and the rows go straight to the pass behind it)
+            seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0 &&
+                       (ix->pass_level != 0 || lkeep + 4 <= L);
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             if (use_1 && !coarse_on_q) {
                 if (gx_main > 0)
