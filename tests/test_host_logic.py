@@ -44,7 +44,7 @@ def test_native_host_helpers_equal_their_numpy_restatements():
     """csrc/host_graph.hip against tests/_host_numpy.py (the forms the product used before): the set order on many rows
     (threads), component labels of random forests + cycles, edge grouping with repeated pairs (first position, last weight)."""
     from nabo_amd._mapping import _component_labels, group_edges
-    from tests._host_numpy import component_labels_numpy, group_edges_numpy, pyset_iteration_order_numpy
+    from _host_numpy import component_labels_numpy, group_edges_numpy, pyset_iteration_order_numpy
     rng = np.random.default_rng(5)
     for n, k, hi in ((20000, 15, 1000000), (5000, 50, 300), (9000, 23, 1 << 40)):
         rows = np.argsort(rng.random((n, min(hi, 4 * k))), axis=1)[:, :k].astype(np.int64)
