@@ -904,6 +904,13 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         if (S > 1024 / L) S = 1024 / L;                     // refine merges at most 1024 candidates per row (32 or 16 lists)
         if (S < 1) S = 1;
         if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
+        // A seeded pass keeps at most L entries per list: where the first pass already kept (nearly) as many -- k' >= 43 on the
+        // 64-entry lists: cosine d = 100, k = 50 -- one list per row certifies nothing the first pass could not.  Four
+        // reference splits give a row four lists: the references below its seed (a few more than 64) spread over them.
+        if (use_1 && ix->pass_level == 1 && !forced && kk + 8 + slack1 + 8 > L) {
+            if (S < 4) S = 4;
+            if (gx_tail > 0 && S2 < 4) S2 = 4;
+        }
         {   // a list entry holds 25 bits of offset into its split (topk_lists.h): very large sets take more splits
             // (NABO_SPLIT_REFS_MAX: tests lower the bound to see the rule at ordinary sizes)
             int64_t split_refs = env_int("NABO_SPLIT_REFS_MAX", 0);
@@ -972,10 +979,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
             // the l2q kernel on the one-product operands: A/B runs, and the locality-ordered stream (its home pre-pass)
             const bool coarse_on_q = !on_l2c;
-            // (a seeded pass keeps at most L entries: where the first pass already does -- k' >= 50 on the 64-entry lists --
-            // it cannot certify what the first could not, and the rows go straight to the pass behind it)
-            seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0 &&
-                       (ix->pass_level != 0 || lkeep + 4 <= L);
+            seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0;
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             if (use_1 && !coarse_on_q) {
                 if (gx_main > 0)
