@@ -461,6 +461,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             __builtin_amdgcn_s_setprio(0);
         }
     };
+    // Every load of the preamble lands HERE (s_waitcnt vmcnt(0), once per wave).  hipcc's scheduler is free to reorder the
+    // preamble's tile loads, and its wait-count pass merges the preamble's pending loads with the loop's at the loop
+    // header: with the first tile's loads issued last, the FIRST step of every round waited for all but the newest tile
+    // (vmcnt(8) where 24 loads may be in flight) -- a ring of four that emptied once per round.  Seen in the product build of
+    // every ring-of-four geometry, not in the experiment builds (whose extra branches happened to keep the order):
+    // cosine 1M x 1M, d = 100, k = 50: kernel 425 -> 318 ms.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     int t = t_begin;
     if (RING == 4) {
         for (; t < t_end; t += 4) {
