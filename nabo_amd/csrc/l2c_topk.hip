@@ -290,12 +290,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
                                                           float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg,
                                                           int64_t rows_valid, const float *__restrict__ tau_init)
 {
+    // dbg: timing ablations of the experiment builds (knn_common.h: debug_ablate; the shipped library always passes 0).
+    // The four-step kernel on the 64-entry lists keeps it a RUN-TIME value in the product build too: with the ablation
+    // selects compiled in -- a few scalar instructions and never-taken branches per tile, same loads, same waits, same
+    // MFMA statements -- that one instantiation runs 16 % faster than with them folded away (cosine 1M x 1M, d = 100,
+    // k = 50, same box: 308 against 365 ms; no such effect, or 1-4 % the other way, in the other instantiations:
+    // profiles/r3_coarse_experiments.txt item 13).  Not understood; measured.
 #ifdef NABO_EXPERIMENTS
-    const int dbg = dbg_arg;                           // timing ablations (knn_common.h: debug_ablate)
+    constexpr bool DBG_RT = true;
 #else
-    constexpr int dbg = 0;
-    (void)dbg_arg;
+    constexpr bool DBG_RT = KS == 4 && EPL == 2;
 #endif
+    const int dbg = DBG_RT ? dbg_arg : 0;
     constexpr int NB = NBv;                            // row-blocks of 16 targets per wave
     constexpr int NP = NB / 2;                         // pairs
     constexpr int NREC = NRECv;
