@@ -305,7 +305,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
     constexpr int NB = NBv;                            // row-blocks of 16 targets per wave
     constexpr int NP = NB / 2;                         // pairs
     constexpr int NREC = NRECv;
-    using C = ListCfg<EPL, ROWN, NB, NREC, 16>;
+    using C = ListCfg<EPL, ROWN, NB, NREC, 16, (ROWN >= 64)>;
     constexpr int TB = 2 * KS * 1024;                  // bytes per packed 32-cell tile (targets and references alike)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -363,6 +363,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             }
             for (int r = lane; r < C::NROWS; r += 64)
                 if (r < nv) C::tauL(wl)[r] = tau_init[row0 + r];
+            if constexpr (C::GRP) {
+                for (int e = lane; e < C::NROWS * C::NGRP; e += 64) {
+                    const int r = e / C::NGRP, g = e % C::NGRP;
+                    if (r < nv && 8 * g < lkeep) reinterpret_cast<uint2 *>(C::gmax(wl))[e].y = __float_as_uint(tau_init[row0 + r]);
+                }
+            }
         }
     }
 
@@ -513,7 +519,7 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
                               int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
 {
     const int dbg = debug_ablate();
-    constexpr size_t lds = (size_t)WAVES * ListCfg<EPL, ROWN, NBv, NRECv, 16>::BYTES;
+    constexpr size_t lds = (size_t)WAVES * ListCfg<EPL, ROWN, NBv, NRECv, 16, (ROWN >= 64)>::BYTES;
     static_assert(lds <= 163840, "LDS budget");
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

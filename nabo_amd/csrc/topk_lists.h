@@ -41,7 +41,10 @@ namespace nabo {
 // wave; NREC: staging records per wave (<= 64: one lane per record); RPBv: target rows per row-block -- 32 for the
 // 32x32 MFMA shapes (a lane holds 16 scores of row l & 31, references jb + (i & 3) + 8 (i >> 2)), 16 for 16x16x32
 // (l2q_topk.hip: 8 scores of row l & 15, references jb + (i & 3) + 16 (i >> 2)).
-template <int EPL, int ROWN, int NB, int NREC, int RPBv = 32>
+// GRPv (l2c_topk.hip on its 64-entry lists): per-row GROUP maxima -- eight groups of eight slots, gmax[row][g] = the largest
+// entry of slots 8 g .. 8 g + 7 (a double like the entries).  A replacement rescans its own group and the eight group
+// maxima, 16 entries instead of 64: on these lists the rescans were most of a kernel that spent half its time on hits.
+template <int EPL, int ROWN, int NB, int NREC, int RPBv = 32, bool GRPv = false>
 struct ListCfg {
     static constexpr int LMAX = 32 * EPL;                // stride of the emitted candidate lists
     static constexpr int ROW = ROWN;
@@ -61,12 +64,18 @@ struct ListCfg {
     static constexpr int OFF_PMAX = OFF_TAU + NROWS * 4;
     static constexpr int OFF_OWNER = OFF_PMAX + NROWS * 4;
     static constexpr int OFF_BASE = OFF_OWNER + NROWS * 4;   // first reference of the split (entries hold offsets from it)
+    static constexpr bool GRP = GRPv;
+    static constexpr int NGRP = 8;                           // groups of eight slots: rows of up to 64 kept entries
+    static_assert(!GRPv || (ROWN >= 64 && ROWN <= 65), "group maxima: 64 kept entries in eight groups of eight");
+    static constexpr int OFF_GMAX = OFF_BASE + 16;           // gmax [NROWS][NGRP] doubles (GRP only)
+    static constexpr int GMAX_BYTES = GRPv ? NROWS * NGRP * 8 : 0;
+    __device__ static double *gmax(unsigned char *w) { return reinterpret_cast<double *>(w + OFF_GMAX); }
 #ifdef NABO_LISTS_PROF
-    static constexpr int OFF_PROF = OFF_BASE + 16;           // 16 u32 event counters / cycle sums (profiling builds only)
+    static constexpr int OFF_PROF = OFF_BASE + 16 + GMAX_BYTES;   // 16 u32 event counters / cycle sums (profiling builds only)
     static constexpr int BYTES = OFF_PROF + 64;
     __device__ static uint32_t *prof(unsigned char *w) { return reinterpret_cast<uint32_t *>(w + OFF_PROF); }
 #else
-    static constexpr int BYTES = OFF_BASE + 16;
+    static constexpr int BYTES = OFF_BASE + 16 + GMAX_BYTES;
 #endif
     static constexpr int IDX_BITS = 25;                      // entry low word: (slot << IDX_BITS) | offset of the reference
     static constexpr uint32_t IDX_MASK = (1u << IDX_BITS) - 1u;   // (all ones: no reference -- a sentinel entry)
@@ -111,6 +120,17 @@ __device__ __forceinline__ void lists_init(unsigned char *w, int lkeep, float ta
         rows[e] = make_uint2(((uint32_t)s << C::IDX_BITS) | C::IDX_MASK, __float_as_uint(s < lkeep ? __builtin_inff() : -__builtin_inff()));
     }
     if (lane == 0) C::base(w)[0] = idx_base;
+    if constexpr (C::GRP) {
+        // a group's largest initial entry: its highest sentinel slot below lkeep (key +inf), or slot 8 g (key -inf) past it
+        for (int e = lane; e < C::NROWS * C::NGRP; e += 64) {
+            const int g = e % C::NGRP;
+            const int top = lkeep - 1 < 8 * g + 7 ? lkeep - 1 : 8 * g + 7;
+            const bool live = 8 * g < lkeep;
+            const uint32_t slot = (uint32_t)(live ? top : 8 * g);
+            const uint2 v = make_uint2((slot << C::IDX_BITS) | C::IDX_MASK, __float_as_uint(live ? __builtin_inff() : -__builtin_inff()));
+            reinterpret_cast<uint2 *>(C::gmax(w))[e] = v;
+        }
+    }
     for (int r = lane; r < C::NROWS; r += 64) {
         C::tauL(w)[r] = tau0;
         C::pmax(w)[r] = 0u;
@@ -206,7 +226,26 @@ __device__ __forceinline__ void lists_drain_body(unsigned char *w, uint32_t scnt
             }
             if (__builtin_amdgcn_ballot_w64(repl) != 0) {       // new maximum of the rows that changed
                 double best = __builtin_bit_cast(double, (uint64_t)0xFF800000u << 32);       // key -inf
-                lists_rescan<C, 0>(kept, lkeep, best);
+                if constexpr (C::GRP) {
+                    // the replaced slot's group, then the eight group maxima (lanes without a replacement walk along on
+                    // their stale position: harmless reads, their results are dropped below)
+                    const uint32_t g = pm >> 3;
+                    const double *ge = reinterpret_cast<const double *>(kept) + 8 * g;
+                    double e8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e8[j] = ge[j];
+                    double gm = __builtin_fmax(__builtin_fmax(__builtin_fmax(e8[0], e8[1]), __builtin_fmax(e8[2], e8[3])),
+                                               __builtin_fmax(__builtin_fmax(e8[4], e8[5]), __builtin_fmax(e8[6], e8[7])));
+                    double *gmx = C::gmax(w) + row * C::NGRP;
+                    if (repl) gmx[g] = gm;
+                    double m8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m8[j] = gmx[j];
+                    best = __builtin_fmax(__builtin_fmax(__builtin_fmax(m8[0], m8[1]), __builtin_fmax(m8[2], m8[3])),
+                                          __builtin_fmax(__builtin_fmax(m8[4], m8[5]), __builtin_fmax(m8[6], m8[7])));
+                } else {
+                    lists_rescan<C, 0>(kept, lkeep, best);
+                }
                 const uint64_t bb = __builtin_bit_cast(uint64_t, best);
                 tau = repl ? __uint_as_float((uint32_t)(bb >> 32)) : tau;
                 pm = repl ? (uint32_t)bb >> C::IDX_BITS : pm;
