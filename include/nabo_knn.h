@@ -136,6 +136,16 @@ int nabo_index_last_kernel(const nabo_index *ix, char *buf, size_t n);
  * NABO_L2_MODE=f16x3 makes the f16x3 filter the first pass.  Results are the same bits whichever pass answers a row
  * (the reference has one float64 path: nabo/_mapping.py:16-26). */
 int nabo_index_last_passes(const nabo_index *ix, int64_t rows[3]);
+/* WHICH pass answered each of the m rows of the LAST nabo_index_query on this index (out [m] bytes, host; m must be that
+ * query's row count): a test can then compare exactly the rows that took an unusual route with the reference's
+ * nabo/_mapping.py:139-145, instead of hoping that a uniform sample contains some. */
+#define NABO_PASS_ONE_PRODUCT 0   /* the one-product f16 filter, lists built from +inf (the default first pass)      */
+#define NABO_PASS_SEEDED      1   /* the same filter, seeded with the threshold the row's failed certificate implies */
+#define NABO_PASS_SECOND      2   /* the f16x3 split or the fp32-MFMA filter (first pass under NABO_L2_MODE=f16x3|f32) */
+#define NABO_PASS_WIDE        3   /* the 64-entry lists (second chance of rows the 32-entry lists could not certify)  */
+#define NABO_PASS_EXACT       4   /* the exact float64 kernels (brute force)                                          */
+#define NABO_PASS_CANBERRA    5   /* the modified-Canberra filter (count + fp32 lower bound + float64 refine)         */
+int nabo_index_last_row_pass(const nabo_index *ix, uint8_t *out, int64_t m);
 
 /* ---- shard merge (reference rows sharded over GPUs) ---------------
  * parts_idx / parts_dist: [n_parts, m, kp] DEVICE arrays, each row sorted by the canonical
@@ -271,6 +281,8 @@ int nabo_dev_free(int32_t device, void *ptr);
 int nabo_memcpy_h2d(int32_t device, void *dst, const void *src, size_t bytes);
 int nabo_memcpy_d2h(int32_t device, void *dst, const void *src, size_t bytes);
 int nabo_dev_synchronize(int32_t device);
+/* free / total bytes of the device's memory (hipMemGetInfo): what a long-running host watches for leaks */
+int nabo_dev_mem_info(int32_t device, size_t *free_bytes, size_t *total_bytes);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,14 @@ class KnnIndex:
                 "fallback_rows": int(cn[0]), "splits": int(cn[1]), "list_len": int(cn[2]), "workgroups": int(cn[3]),
                 "seeded_pass_rows": int(ps[0]), "second_pass_rows": int(ps[1]), "wide_list_rows": int(ps[2])}
 
+    PASS_NAMES = ("one_product", "seeded", "second_filter", "wide_lists", "exact", "canberra_filter")
+
+    def last_row_pass(self, m):
+        """uint8 [m]: which pass answered each row of the last query of m rows (include/nabo_knn.h: NABO_PASS_*)"""
+        out = np.empty(int(m), dtype=np.uint8)
+        _lib.check(_lib.lib().nabo_index_last_row_pass(self._h, out.ctypes.data, int(m)))
+        return out
+
     def last_kernel(self):
         """name of the dominant kernel the last query ran (which filter the launch logic picked)"""
         buf = C.create_string_buffer(192)

@@ -22,8 +22,8 @@ SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
     "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
     "nabo_index_query_candidates",
-    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_merge_topk", "nabo_snn_counts", "nabo_pyset_order", "nabo_component_labels", "nabo_group_edges", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
-    "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize",
+    "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_index_last_row_pass", "nabo_merge_topk", "nabo_snn_counts", "nabo_pyset_order", "nabo_component_labels", "nabo_group_edges", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
+    "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize", "nabo_dev_mem_info",
     "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
     "nabo_comm_rank", "nabo_comm_world", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
     "nabo_sharded_query", "nabo_sharded_last_stats",
@@ -58,6 +58,7 @@ def lib():
     L.nabo_index_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.nabo_index_last_kernel.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.nabo_index_last_passes.argtypes = [vp, C.POINTER(i64)]
+    L.nabo_index_last_row_pass.argtypes = [vp, vp, i64]
     L.nabo_merge_topk.argtypes = [i32, vp, vp, i32, i64, i32, i32, i32, vp, vp]
     L.nabo_snn_counts.argtypes = [i32, vp, i64, vp, i64, i32, vp]
     L.nabo_dev_malloc.argtypes = [i32, C.POINTER(vp), C.c_size_t]
@@ -65,6 +66,7 @@ def lib():
     L.nabo_memcpy_h2d.argtypes = [i32, vp, vp, C.c_size_t]
     L.nabo_memcpy_d2h.argtypes = [i32, vp, vp, C.c_size_t]
     L.nabo_dev_synchronize.argtypes = [i32]
+    L.nabo_dev_mem_info.argtypes = [i32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.nabo_comm_unique_id.argtypes = [vp]
     L.nabo_comm_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
     L.nabo_comm_create_all.argtypes = [C.POINTER(vp), C.POINTER(i32), i32]
@@ -134,3 +136,10 @@ def check(rc):
 
 def device_count():
     return int(lib().nabo_device_count())
+
+
+def mem_info(device=0):
+    """(free, total) bytes of the device's memory"""
+    f, t = C.c_size_t(), C.c_size_t()
+    check(lib().nabo_dev_mem_info(int(device), C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)

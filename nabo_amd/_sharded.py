@@ -213,6 +213,9 @@ class ShardedIndex:
                 "protocol": {1: "global", 2: "local"}.get(int(cn[3]), "?")}
 
 
+_LEAKED = []          # handles of ranks whose thread never came back (ShardedGroup.close)
+
+
 class ShardedGroup:
     """One process, several ranks: rank i = (device[i], shard i of the references), each driven by its own host thread
     (the C calls release the GIL; the collectives inside nabo_sharded_query rendezvous the threads).
@@ -257,20 +260,25 @@ class ShardedGroup:
         # one persistent host thread per rank (a step of bench.py must not pay for thread creation)
         self._jobs = [queue.Queue() for _ in range(N)]
         self._done = queue.Queue()
-        self._threads = [threading.Thread(target=self._worker, args=(r,), daemon=True) for r in range(N)]
+        # (the threads hold the two queues, not `self`: a group that is dropped without close() is still collected, and
+        # __del__ then shuts the threads down and frees the GPU memory and the communicators)
+        self._threads = [threading.Thread(target=ShardedGroup._worker, args=(self._jobs[r], self._done, r), daemon=True)
+                         for r in range(N)]
         for t in self._threads:
             t.start()
 
-    def _worker(self, r):
+    @staticmethod
+    def _worker(jobs, done, r):
         while True:
-            fn = self._jobs[r].get()
+            fn = jobs.get()
             if fn is None:
                 return
             try:
                 fn(r)
-                self._done.put((r, None))
+                done.put((r, None))
             except BaseException as e:      # noqa: BLE001
-                self._done.put((r, e))
+                done.put((r, e))
+            del fn                          # (the job closes over the group: do not keep it alive while idle)
 
     def _each(self, fn):
         """fn(r) on every rank's thread.  If a rank has not come back after `timeout` (+ the C side's own deadline for
@@ -340,17 +348,38 @@ class ShardedGroup:
         return self.shards[r].last_stats()
 
     def close(self):
+        """Stop the rank threads, then free every rank's index, reference rows and communicator.  A rank whose thread is
+        still inside a HIP / RCCL call (after an aborted or timed-out collective) keeps its handles: destroying them under
+        a running call would be a use-after-free -- they are leaked and reported instead."""
+        threads = getattr(self, "_threads", [])
         for q in getattr(self, "_jobs", []):
             q.put(None)
-        for t in getattr(self, "_threads", []):
+        for t in threads:
             t.join(timeout=5.0)
+        stuck = [r for r, t in enumerate(threads) if t.is_alive()]
+        if stuck:
+            for c in getattr(self, "comms", []):
+                c.abort()                                      # releases ranks blocked in a collective
+            for r in stuck:
+                threads[r].join(timeout=30.0)
+            stuck = [r for r in stuck if threads[r].is_alive()]
         self._jobs, self._threads = [], []
-        for ix in self.indices:
-            ix.close()
-        for y in self._Y:
-            y.free()
-        for c in self.comms:
-            c.close()
+        for r, ix in enumerate(getattr(self, "indices", [])):
+            if r not in stuck:
+                ix.close()
+        for r, y in enumerate(getattr(self, "_Y", [])):
+            if r not in stuck:
+                y.free()
+        for r, c in enumerate(getattr(self, "comms", [])):
+            if r not in stuck:
+                c.close()
+        if stuck:
+            import warnings
+            for r in stuck:                                    # keep the objects alive: their __del__ would free them
+                _LEAKED.append((self.indices[r], self._Y[r], self.comms[r]))
+            warnings.warn("ShardedGroup.close: rank thread(s) %s still inside a device call; their index, reference rows and "
+                          "communicator were NOT destroyed (leaked)" % stuck, ResourceWarning)
+        self.indices, self._Y, self.comms = [], [], []
 
     def __del__(self):
         try:

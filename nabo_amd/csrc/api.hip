@@ -42,7 +42,13 @@ int l2q_pick_kc1(int g);
 // the one-product first pass (l2c_topk.hip; operands packed with layout16, nseg = 1)
 hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init);
+                           int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride = 0,
+                           int64_t tau_row0 = 0);
+// tournament seeds for the one-product pass (l2c_topk.hip: l2c_pre_kernel)
+void l2c_pre_plan(int kc, int lkeep, int tiles_per_split, int scale_pct, int *pre_tiles, int *gt);
+hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                          int64_t rows, int64_t tile_off, int pre_tiles, int gt, int64_t pad_tile, hipStream_t st,
+                          int64_t rows_valid, float *tau_out);
 int l2c_pick_kc(int g);
 int l2c_geometry(int kc, int lkeep_want);
 void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
@@ -171,10 +177,14 @@ int use_device(int device)
     return NABO_OK;
 }
 
-// grow-only device buffer
+// grow-only device buffer; owns its allocation (freed by release() or with the object: `delete ix` cannot miss a member)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return NABO_OK;
@@ -281,8 +291,16 @@ struct nabo_index {
     // query workspace
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
     DevBuf xfailp[2], tmpip[2], tmpdp[2], failsp[2], seedp[2], failseed;      // the same for passes 1 and 2 (the passes nest)
+    DevBuf taupre, taupre2;                   // tournament seeds of the main / tail launch of the one-product pass [rows][S]
+    int64_t pre_tiles_last = 0;               // reference tiles per split the last query's tournament looked at (0: none)
     int cand_slack = 3;                       // candidate mode on the one-product pass: kept entries beyond the emitted ones
     int64_t pass_rows[3] = {0, 0, 0};         // rows of the last query sent to the seeded pass / the f16x3 pass / the 64-entry lists
+    // Which pass ANSWERED each row of the last top-level query (nabo_index_last_row_pass; NABO_PASS_* of nabo_knn.h): the
+    // first filter's code for every row, overwritten as fail lists go down the chain.  row_map: rows of the batch a nested
+    // query_impl works on -> rows of the top-level query (null at the top); depth: nesting level of query_impl.
+    std::vector<uint8_t> row_pass;
+    const std::vector<uint32_t> *row_map = nullptr;
+    int depth = 0;
     float ms_keep[3] = {0, 0, 0};
     double ms_inner = 0.0;         // total of the most recent query_impl (read by the outer call of a retry)
     bool ms_keep_valid = false;
@@ -319,6 +337,21 @@ void index_set_cand_slack(nabo_index *ix, int s) { ix->cand_slack = s < 0 ? 0 : 
 // that: its masked references would enter the global merge as if they were neighbours (found by the randomised
 // sweep: 40-reference shards, 60 % masked) -- there the tail is left absent (index -1), which the merge skips.
 static int tail_len(const nabo_index *ix) { return ix->shard_mode ? 0 : ix->n_masked_list; }
+
+// The rows of the current batch listed in `d_rows` (device, nf entries) go on to the pass `code`: note it per top-level row and
+// return their top-level row numbers in `map` (the inner query_impl's row_map).  The stream is synchronised.
+static int note_row_pass(nabo_index *ix, const uint32_t *d_rows, int64_t nf, uint8_t code, std::vector<uint32_t> &map)
+{
+    map.resize((size_t)nf);
+    if (nf == 0) return NABO_OK;
+    HIP_TRY(hipMemcpyAsync(map.data(), d_rows, (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    for (int64_t i = 0; i < nf; ++i) {
+        if (ix->row_map) map[(size_t)i] = map[(size_t)i] < ix->row_map->size() ? (*ix->row_map)[map[(size_t)i]] : 0xFFFFFFFFu;
+        if (map[(size_t)i] < ix->row_pass.size()) ix->row_pass[map[(size_t)i]] = code;
+    }
+    return NABO_OK;
+}
 
 // Locality order of `n` rows of V (order.hip): sorted keys and the permutation, on the index's stream.
 static int order_rows(nabo_index *ix, const double *V, int64_t n, DevBuf &keys, DevBuf &perm)
@@ -525,18 +558,13 @@ int nabo_index_destroy(nabo_index *ix)
     if (!ix) return NABO_OK;
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-    DevBuf *bufs[] = {&ix->ybuf, &ix->ynbuf, &ix->xnbuf, &ix->maskbuf, &ix->mlistbuf, &ix->centre, &ix->ypk, &ix->ycpk, &ix->normmax, &ix->yt, &ix->ycf, &ix->yrow, &ix->cbflag, &ix->ych, &ix->cbscale, &ix->xh, &ix->xfail, &ix->tmpi, &ix->tmpd, &ix->exact_d, &ix->fails2,
-                      &ix->xbuf, &ix->xpk, &ix->xnorm, &ix->cand_idx, &ix->cand_tau, &ix->cand_idx2, &ix->cand_tau2, &ix->cand_d, &ix->fails,
-                      &ix->failcnt, &ix->oidx, &ix->odist, &ix->nfound, &ix->rkeys, &ix->rperm, &ix->tkeys, &ix->tperm, &ix->wstart, &ix->okeys,
-                      &ix->opos, &ix->otemp, &ix->cbedges, &ix->cbtab, &ix->cbvalid, &ix->cbrow};
-    for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 6; ++i)
         if (ix->ev[i]) (void)hipEventDestroy(ix->ev[i]);
     if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
     if (ix->ev_main) (void)hipEventDestroy(ix->ev_main);
     if (ix->ev_ref) (void)hipEventDestroy(ix->ev_ref);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
-    delete ix;
+    delete ix;                       // every DevBuf member frees its allocation (the device is current)
     return NABO_OK;
 }
 
@@ -690,7 +718,24 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
 
 // cand_mode: shard mode of nabo_index_query_candidates -- k is the number of candidates per row to emit,
 // out_bound [m] receives the squared-distance bound of everything not emitted; no local certification.
+static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k, int32_t drop_first,
+                      int64_t *out_idx, double *out_dist, int32_t out_on_device, bool cand_mode, double *out_bound);
+
 static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k, int32_t drop_first,
+                      int64_t *out_idx, double *out_dist, int32_t out_on_device, bool cand_mode, double *out_bound)
+{
+    if (!ix) return fail(NABO_E_INVALID, "NULL argument");
+    if (ix->depth == 0) {                            // a top-level query: the per-row record starts over
+        ix->row_pass.clear();
+        ix->row_map = nullptr;
+    }
+    ++ix->depth;
+    const int rc = query_body(ix, X, x_on_device, m, k, drop_first, out_idx, out_dist, out_on_device, cand_mode, out_bound);
+    --ix->depth;
+    return rc;
+}
+
+static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k, int32_t drop_first,
                       int64_t *out_idx, double *out_dist, int32_t out_on_device, bool cand_mode, double *out_bound)
 {
     if (!ix || !X || !out_idx || !out_dist) return fail(NABO_E_INVALID, "NULL argument");
@@ -738,8 +783,11 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
     int S = 1;
     int64_t n_wg = 0;
     HIP_TRY(hipEventRecord(ix->ev[0], st));
+    const bool top = ix->depth == 1 && !cand_mode;   // this call owns the per-row pass record
+    std::vector<uint32_t> pass_map;                  // top-level rows of the batch an inner call works on
 
     if (exact_route) {
+        if (top) ix->row_pass.assign((size_t)m, (uint8_t)NABO_PASS_EXACT);
         uint64_t d_rows = (1ull << 30) / ((uint64_t)ix->n * sizeof(double));
         if (d_rows < 1) d_rows = 1;
         if (d_rows > (uint64_t)m) d_rows = (uint64_t)m;
@@ -840,6 +888,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                           r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 33 : 65);
         }
         if ((rc = ensure_packed(ix, use_1 ? 2 : use_h ? 1 : 0))) return rc;
+        if (top) ix->row_pass.assign((size_t)m, (uint8_t)(use_1 ? NABO_PASS_ONE_PRODUCT : NABO_PASS_SECOND));
         const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
         const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
         const int64_t rows_pad = gx * rows_per_wg;
@@ -982,10 +1031,37 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0;
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             if (use_1 && !coarse_on_q) {
+                // Tournament seeds (l2c_topk.hip: l2c_pre_kernel): every (row, split) list starts from an upper bound of its
+                // lkeep-th smallest score among the split's first references instead of +inf -- not for a pass that has its
+                // seeds already.  NABO_PREPASS: 0 off, otherwise percent of the planned length (A/B runs; same bits always).
+                const int pre_pct = seeds ? 0 : env_int("NABO_PREPASS", 100);
+                const float *seeds_main = seeds, *seeds_tail = seeds;
+                int stride_main = 0, stride_tail = 0;
+                if (ix->pass_level == 0 && !ix->wide_retry) ix->pre_tiles_last = 0;
+                if (pre_pct > 0) {
+                    int pt = 0, gt = 2;
+                    nabo::l2c_pre_plan(kcq, lkeep, (int)tps, pre_pct, &pt, &gt);
+                    if (pt > 0 && gx_main > 0) {
+                        if ((rc = ix->taupre.reserve((size_t)rows_main * S * sizeof(float)))) return rc;
+                        HIP_TRY(nabo::l2c_pre_launch(kcq, lkeep, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, rows_main, 0, pt, gt,
+                                                     ix->ref_tiles_alloc - 1, st, m, ix->taupre.as<float>()));
+                        seeds_main = ix->taupre.as<float>();
+                        stride_main = S;
+                        if (ix->pass_level == 0 && !ix->wide_retry) ix->pre_tiles_last = pt;
+                    }
+                    nabo::l2c_pre_plan(kcq, lkeep, (int)tps2, pre_pct, &pt, &gt);
+                    if (pt > 0 && gx_tail > 0) {
+                        if ((rc = ix->taupre2.reserve((size_t)rows_tail * S2 * sizeof(float)))) return rc;
+                        HIP_TRY(nabo::l2c_pre_launch(kcq, lkeep, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, rows_tail,
+                                                     rows_main / 32, pt, gt, ix->ref_tiles_alloc - 1, st, m, ix->taupre2.as<float>()));
+                        seeds_tail = ix->taupre2.as<float>();
+                        stride_tail = S2;
+                    }
+                }
                 if (gx_main > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
                                                   ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
-                                                  ix->ref_tiles_alloc - 1, st, m, seeds));
+                                                  ix->ref_tiles_alloc - 1, st, m, seeds_main, stride_main, 0));
                 // the tail launch (a fraction of a round, reference splits) leaves most CUs idle: the refine of the main
                 // launch's rows (an HBM gather) runs beside it on the second stream
                 if (gx_main > 0 && gx_tail > 0 && !cand_mode && env_int("NABO_REFINE_OVERLAP", 1) != 0) {
@@ -995,7 +1071,8 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 if (gx_tail > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
                                                   rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
-                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m, seeds));
+                                                  ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m, seeds_tail, stride_tail,
+                                                  rows_main));
             } else {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2q_topk_launch(kcq, ix->xpk.as<unsigned char>(), ytiles,
@@ -1124,14 +1201,18 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 HIP_TRY(hipMemcpyAsync(ix->seedp[b].p, fail_seed, (size_t)nf * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
             HIP_TRY(nabo::gather_rows_launch(dX, ix->failsp[b].as<uint32_t>(), nf, g, ix->xfailp[b].as<double>(), st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if ((rc = note_row_pass(ix, ix->failsp[b].as<uint32_t>(), nf, (uint8_t)(next == 1 ? NABO_PASS_SEEDED : NABO_PASS_SECOND), pass_map)))
+                return rc;                                   // (synchronises the stream)
             const float *seed_saved = ix->seed_tau;
+            const std::vector<uint32_t> *map_saved = ix->row_map;
             ix->pass_level = next;
             ix->seed_tau = next == 1 ? ix->seedp[b].as<float>() : nullptr;
+            ix->row_map = &pass_map;
             rc = query_impl(ix, ix->xfailp[b].as<double>(), 1, nf, k, drop_first, ix->tmpip[b].as<int64_t>(),
                             ix->tmpdp[b].as<double>(), 1, false, nullptr);
             ix->pass_level = here;
             ix->seed_tau = seed_saved;
+            ix->row_map = map_saved;
             if (rc) return rc;
             ix->pass_rows[next - 1] = nf;
             if (here == 0 && m >= 1024 && ix->pass_rows[1] > m / 4) ix->coarse_weak = true;
@@ -1153,11 +1234,14 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if ((rc = ix->tmpd.reserve((size_t)nf * k * sizeof(double)))) return rc;
             HIP_TRY(hipMemcpyAsync(ix->fails2.p, ix->fails.p, (size_t)nf * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
             HIP_TRY(nabo::gather_rows_launch(dX, ix->fails2.as<uint32_t>(), nf, g, ix->xfail.as<double>(), st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if ((rc = note_row_pass(ix, ix->fails2.as<uint32_t>(), nf, (uint8_t)NABO_PASS_WIDE, pass_map))) return rc;      // (synchronises)
+            const std::vector<uint32_t> *map_saved = ix->row_map;
             ix->wide_retry = true;
+            ix->row_map = &pass_map;
             rc = query_impl(ix, ix->xfail.as<double>(), 1, nf, k, drop_first, ix->tmpi.as<int64_t>(), ix->tmpd.as<double>(), 1,
                             false, nullptr);
             ix->wide_retry = false;
+            ix->row_map = map_saved;
             if (rc) return rc;
             ix->pass_rows[2] = nf;
             n_fail = (unsigned int)ix->counters[0];          // rows that still needed the exact kernels
@@ -1172,6 +1256,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             if (d_rows > n_fail) d_rows = n_fail;
             if (d_rows > 65535) d_rows = 65535;
             if ((rc = ix->exact_d.reserve((size_t)d_rows * ix->n * sizeof(double)))) return rc;
+            if ((rc = note_row_pass(ix, ix->fails.as<uint32_t>(), n_fail, (uint8_t)NABO_PASS_EXACT, pass_map))) return rc;
             HIP_TRY(nabo::exact_rows_launch(dX, ix->dY, ix->n, g, ix->metric, ix->f, ix->dmask, ix->fails.as<uint32_t>(),
                                             n_fail, k, drop, ix->base, ix->mlistbuf.as<uint32_t>(), tail_len(ix),
                                             d_oidx, d_odist, ix->exact_d.as<double>(), (unsigned int)d_rows, st));
@@ -1196,6 +1281,7 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
         bool done = false;
         const int S_exact = S;
         snprintf(ix->kernel, sizeof(ix->kernel), "canberra_topk_kernel (float64)");
+        if (top) ix->row_pass.assign((size_t)m, (uint8_t)NABO_PASS_EXACT);
         if (ix->cb_f32 && n_valid >= kk) {
             // fp32 lower-bound filter -> float64 refine + certification -> exact re-solve of uncertified rows
             float slack, plateau;
@@ -1315,6 +1401,10 @@ static int query_impl(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(hipStreamSynchronize(st));
             if (hf[0] == 0) {                    // targets fit fp32: results stand, re-solve uncertified rows
                 n_fail = hf[1];
+                if (top) {
+                    ix->row_pass.assign((size_t)m, (uint8_t)NABO_PASS_CANBERRA);
+                    if ((rc = note_row_pass(ix, ix->fails.as<uint32_t>(), n_fail, (uint8_t)NABO_PASS_EXACT, pass_map))) return rc;
+                }
                 if (n_fail > 0) {
                     const int64_t nf = n_fail;
                     int S3 = 1;
@@ -1417,6 +1507,16 @@ int nabo_index_last_passes(const nabo_index *ix, int64_t rows[3])
     rows[0] = ix->pass_rows[0];
     rows[1] = ix->pass_rows[1];
     rows[2] = ix->pass_rows[2];
+    return NABO_OK;
+}
+
+int nabo_index_last_row_pass(const nabo_index *ix, uint8_t *out, int64_t m)
+{
+    if (!ix || !out) return fail(NABO_E_INVALID, "NULL argument");
+    if ((int64_t)ix->row_pass.size() != m)
+        return fail(NABO_E_INVALID, "the last nabo_index_query on this index had %lld rows, not %lld (candidate queries keep no record)",
+                    (long long)ix->row_pass.size(), (long long)m);
+    if (m > 0) memcpy(out, ix->row_pass.data(), (size_t)m);
     return NABO_OK;
 }
 
@@ -1694,6 +1794,15 @@ int nabo_memcpy_d2h(int32_t device, void *dst, const void *src, size_t bytes)
     int rc = use_device(device);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return NABO_OK;
+}
+
+int nabo_dev_mem_info(int32_t device, size_t *free_bytes, size_t *total_bytes)
+{
+    if (!free_bytes || !total_bytes) return fail(NABO_E_INVALID, "NULL argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
     return NABO_OK;
 }
 

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <system_error>
 #include <thread>
@@ -24,6 +25,10 @@ int api_fail(int code, const char *fmt, ...);
 
 namespace {
 
+// Rows [0, n) in chunks on the caller's cores.  Nothing escapes a worker thread: an exception thrown inside one (bad_alloc
+// from a per-thread table) is kept, every thread is joined, and the FIRST exception is rethrown on the calling thread, where
+// the extern "C" entry points turn it into a status code; if a thread cannot be started (system_error) the threads already
+// running are joined first and the rest of the rows is done by the caller.
 template <typename F>
 void parallel_rows(int64_t n, int64_t grain, F &&f)
 {
@@ -34,13 +39,31 @@ void parallel_rows(int64_t n, int64_t grain, F &&f)
     if (nt > (n + grain - 1) / grain) nt = (n + grain - 1) / grain;
     if (nt <= 1) { f(0, n); return; }
     std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err((size_t)nt);
     const int64_t per = (n + nt - 1) / nt;
-    for (int64_t t = 0; t < nt; ++t) {
-        const int64_t a = t * per, b = std::min(n, a + per);
-        if (a >= b) break;
-        th.emplace_back([&f, a, b]() { f(a, b); });
+    int64_t done_to = 0;                                     // rows [0, done_to) have a thread
+    try {
+        th.reserve((size_t)nt);
+        for (int64_t t = 0; t < nt; ++t) {
+            const int64_t a = t * per, b = std::min(n, a + per);
+            if (a >= b) break;
+            std::exception_ptr *slot = &err[(size_t)t];
+            th.emplace_back([&f, a, b, slot]() {
+                try { f(a, b); } catch (...) { *slot = std::current_exception(); }
+            });
+            done_to = b;
+        }
+    } catch (...) {                                          // thread creation failed: the caller's thread takes the rest
+        done_to = th.empty() ? 0 : std::min(n, (int64_t)th.size() * per);
+    }
+    std::exception_ptr mine;
+    if (done_to < n) {
+        try { f(done_to, n); } catch (...) { mine = std::current_exception(); }
     }
     for (auto &x : th) x.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+    if (mine) std::rethrow_exception(mine);
 }
 
 // CPython's set of small non-negative ints (Objects/setobject.c, 3.7 .. 3.12): open addressing, hash(int) = int, a table

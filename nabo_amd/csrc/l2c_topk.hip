@@ -288,7 +288,8 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
                                                           uint32_t *__restrict__ cand_idx,
                                                           float *__restrict__ cand_key,
                                                           float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg,
-                                                          int64_t rows_valid, const float *__restrict__ tau_init)
+                                                          int64_t rows_valid, const float *__restrict__ tau_init,
+                                                          int tau_stride, int64_t tau_row0)
 {
     // dbg: timing ablations of the experiment builds (knn_common.h: debug_ablate; the shipped library always passes 0).
     // The four-step kernel on the 64-entry lists keeps it a RUN-TIME value in the product build too: with the ablation
@@ -343,10 +344,16 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
     // lkeep entries (tau_init, no index): its maximum IS the threshold until every one of them has been replaced, and from
     // then on the list behaves like any other (a row with more than lkeep references below its seed loses its
     // certificate again and goes on to the f16x3 pass).
+    // The same start serves the TOURNAMENT seeds of l2c_pre_kernel (below): one value per row AND reference split
+    // (tau_stride = the launch's split count, tau_row0 = its first row), an upper bound of the row's lkeep-th smallest
+    // score among the split's first references -- the list warm-up from +inf, half of all list updates, is skipped.
+    auto seed_of = [&](int64_t r) -> float {
+        return tau_stride ? tau_init[(r - tau_row0) * tau_stride + split] : tau_init[r];
+    };
 #pragma unroll
     for (int rb = 0; rb < NB; ++rb) {
         const int64_t r = row0 + rb * 16 + (lane & 15);
-        tauv[rb] = r < rows_valid ? ((tau_init && !(dbg & 1)) ? tau_init[r] : tau0) : -__builtin_inff();
+        tauv[rb] = r < rows_valid ? ((tau_init && !(dbg & 1)) ? seed_of(r) : tau0) : -__builtin_inff();
     }
     uint32_t scnt = 0;
     lists_init<C>(wl, lkeep, tau0, (uint32_t)split * (uint32_t)tiles_per_split * 32u);
@@ -359,14 +366,14 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             uint2 *rows = C::rows(wl);
             for (int e = lane; e < C::NROWS * lkeep; e += 64) {
                 const int r = e / lkeep, sl = e - r * lkeep;
-                if (r < nv) rows[r * C::ROW + sl].y = __float_as_uint(tau_init[row0 + r]);
+                if (r < nv) rows[r * C::ROW + sl].y = __float_as_uint(seed_of(row0 + r));
             }
             for (int r = lane; r < C::NROWS; r += 64)
-                if (r < nv) C::tauL(wl)[r] = tau_init[row0 + r];
+                if (r < nv) C::tauL(wl)[r] = seed_of(row0 + r);
             if constexpr (C::GRP) {
                 for (int e = lane; e < C::NROWS * C::NGRP; e += 64) {
                     const int r = e / C::NGRP, g = e % C::NGRP;
-                    if (r < nv && 8 * g < lkeep) reinterpret_cast<uint2 *>(C::gmax(wl))[e].y = __float_as_uint(tau_init[row0 + r]);
+                    if (r < nv && 8 * g < lkeep) reinterpret_cast<uint2 *>(C::gmax(wl))[e].y = __float_as_uint(seed_of(row0 + r));
                 }
             }
         }
@@ -513,10 +520,159 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
     lists_flush<C, EPL, NB>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }
 
+// ---- tournament seeds: a START THRESHOLD per (row, reference split) without any list work ---------------------------------
+// A streamed top-L makes L (1 + ln(n / L)) list updates per row and half of them fall into the first few thousand references
+// of the stream, while the threshold is still far above where it ends (a shard of 125k references pays them as the whole
+// set does: the reason one rank of eight costs far more than an eighth).  This kernel looks at the first `pre_tiles` tiles of
+// every split BEFORE the filter does and hands it an upper bound tau0 of the row's lkeep-th smallest score among them:
+//   * a lane (row-block rb, row l & 15, quarter lq = l >> 4) sees 8 scores of its row per tile; the minimum over `gt`
+//     consecutive tiles is a GROUP minimum -- one distinct reference per group, groups of different lanes and steps are
+//     disjoint;
+//   * each lane keeps its q = ceil(lkeep / 4) smallest group minima (a bubble through q sorted registers per group);
+//   * tau0 = the largest of the four lanes' q-th values: 4 q >= lkeep distinct references score <= tau0.
+// The filter then starts the row's list as lkeep entries (tau0, no index) -- the seeded start of tau_init above -- and
+// collects the ~1.4 lkeep references below tau0 instead of climbing down from +inf through lkeep (1 + ln(T / lkeep))
+// updates.  Any tau0 gives a correct certificate (refine.hip bounds the non-candidates by the FINAL threshold <= tau0); a
+// tau0 that is too low only leaves the list short and sends the row to the next pass, so nothing here needs to be exact --
+// it is, though: the same operands through the same MFMA chain as the filter's.  Cost: pre_tiles of the stream's MFMA
+// work and ~16 vector instructions per pair of row-blocks and tile, no LDS, no branches.
+template <int KS, int NB, int QM>
+__global__ __launch_bounds__(256) void l2c_pre_kernel(const unsigned char *__restrict__ Xpk, const unsigned char *__restrict__ Ypk,
+                                                      int tiles_per_split, int64_t tile_off, int64_t rows, int pre_tiles, int gt,
+                                                      int q, int64_t pad_tile, int64_t rows_valid, float *__restrict__ tau_out)
+{
+    constexpr int NP = NB / 2;
+    constexpr int TB = 2 * KS * 1024;
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int split = blockIdx.y, S = gridDim.y;
+    const int64_t ltile0 = ((int64_t)blockIdx.x * 4 + wave) * NP;            // in 32-row tiles, local to the launch
+    const int64_t ttile0 = tile_off + ltile0;
+    // (wave-uniform: a wave beyond the launch's rows -- the filter's workgroups are whole multiples of a wave's rows -- or
+    // with nothing but padding rows)
+    if (ltile0 * 32 >= rows || ttile0 * 32 >= rows_valid) return;
+    f16x8 xb[NB][KS];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(Xpk + (ttile0 + (rb >> 1)) * TB);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xb[rb][s] = p[((rb & 1) * KS + s) * 64 + lane];
+    }
+    float srt[NB][QM];
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb)
+#pragma unroll
+        for (int j = 0; j < QM; ++j) srt[rb][j] = __builtin_inff();
+    const int t_begin = split * tiles_per_split, t_end = t_begin + tiles_per_split;
+    auto tile_load = [&](f16x8(&a)[2][KS], int ts) {
+        const f16x8 *p = reinterpret_cast<const f16x8 *>(Ypk + (ts < t_end ? (int64_t)ts : pad_tile) * TB);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[h][s] = p[(h * KS + s) * 64 + lane];
+    };
+    float gm[NB];
+    auto tile_mins = [&](const f16x8(&a)[2][KS]) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const cacc acc = cchain<KS>(a, xb[2 * p], xb[2 * p + 1]);
+            const cmins mm = cmin8x2(acc);
+            gm[2 * p] = fminf(gm[2 * p], mm.m0);
+            gm[2 * p + 1] = fminf(gm[2 * p + 1], mm.m1);
+        }
+    };
+    f16x8 a0[2][KS], a1[2][KS];
+    tile_load(a0, t_begin);
+    const int t_stop = t_begin + pre_tiles;                                  // (gt even, pre_tiles a multiple of gt: the caller's)
+    for (int t = t_begin; t < t_stop;) {
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) gm[rb] = __builtin_inff();
+        for (int u = 0; u < gt; u += 2) {
+            tile_load(a1, t + 1);
+            tile_mins(a0);
+            tile_load(a0, t + 2);
+            tile_mins(a1);
+            t += 2;
+        }
+#pragma unroll
+        for (int rb = 0; rb < NB; ++rb) {                                    // the group minimum bubbles into the sorted registers
+            float x = gm[rb];
+#pragma unroll
+            for (int j = 0; j < QM; ++j) {
+                const float lo = fminf(srt[rb][j], x);
+                x = fmaxf(srt[rb][j], x);
+                srt[rb][j] = lo;
+            }
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < NB; ++rb) {
+        float v = srt[rb][0];
+#pragma unroll
+        for (int j = 1; j < QM; ++j) v = (j == q - 1) ? srt[rb][j] : v;
+        v = fmaxf(v, __shfl_xor(v, 16, 64));
+        v = fmaxf(v, __shfl_xor(v, 32, 64));
+        const int64_t lrow = ltile0 * 32 + rb * 16 + (lane & 15);
+        if (lane < 16 && tile_off * 32 + lrow < rows_valid) tau_out[lrow * S + split] = v;
+    }
+}
+
+template <int KS, int NB, int QM>
+static hipError_t cpre_launch(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int64_t rows,
+                              int64_t tile_off, int pre_tiles, int gt, int q, int64_t pad_tile, hipStream_t st,
+                              int64_t rows_valid, float *tau_out)
+{
+    const int64_t gx = (rows + 4 * NB * 16 - 1) / (4 * NB * 16);
+    hipLaunchKernelGGL((l2c_pre_kernel<KS, NB, QM>), dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, Xpk, Ypk, tiles_per_split,
+                       tile_off, rows, pre_tiles, gt, q, pad_tile, rows_valid, tau_out);
+    return hipGetLastError();
+}
+
+// How much of a split's stream the tournament looks at, for lists of lkeep entries over splits of tiles_per_split tiles:
+// *pre_tiles (0: not worth it), *gt tiles per group.  The optimum does not depend on the stream's length: a tile of the
+// tournament costs a row ~2 SIMD cycles per step of 32 slots (kc / 2 steps), a list update ~120 (1M x 1M: 14 ms of hits for
+// 269 updates per row), and a tournament over T tiles saves lkeep (ln(32 T / lkeep) - 0.4) updates: d/dT = 0 at
+// T = 120 lkeep / kc tiles (690 at lkeep = 23, two steps) -- capped at a quarter of the stream; scale_pct: A/B runs.
+void l2c_pre_plan(int kc, int lkeep, int tiles_per_split, int scale_pct, int *pre_tiles, int *gt)
+{
+    const int q = (lkeep + 3) / 4;
+    int want = (int)((int64_t)120 * lkeep * scale_pct / 100 / (kc > 0 ? kc : 2));
+    if (want > tiles_per_split / 4) want = tiles_per_split / 4;
+    *pre_tiles = 0;
+    *gt = 2;
+    if (want < 6 * q) return;                         // fewer than 3 q groups of two tiles: the bound would be loose
+    int g2 = want / (8 * q);                          // >= 8 q groups when the budget allows, in groups of 2, 4, .. tiles
+    g2 = g2 < 2 ? 2 : (g2 > 8 ? 8 : g2 & ~1);
+    *gt = g2;
+    *pre_tiles = want / g2 * g2;
+}
+
+// tau_out [rows][S] (rows local to this launch: row tile_off * 32 of the query is row 0), rows_valid as in l2c_topk_launch
+hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                          int64_t rows, int64_t tile_off, int pre_tiles, int gt, int64_t pad_tile, hipStream_t st,
+                          int64_t rows_valid, float *tau_out)
+{
+    const int q = (lkeep + 3) / 4;
+    if (pre_tiles <= 0 || gt < 2 || (gt & 1) || pre_tiles % gt || pre_tiles > tiles_per_split || q < 1 || q > 16 || rows <= 0)
+        return hipErrorInvalidValue;
+#define NABO_PRE(KSV)                                                                                                               \
+    case 2 * KSV:                                                                                                                   \
+        return q <= 8 ? cpre_launch<KSV, (KSV <= 2 ? 8 : 4), 8>(Xpk, Ypk, tiles_per_split, S, rows, tile_off, pre_tiles, gt, q, pad_tile, \
+                                                              st, rows_valid, tau_out)                                             \
+                      : cpre_launch<KSV, 4, 16>(Xpk, Ypk, tiles_per_split, S, rows, tile_off, pre_tiles, gt, q, pad_tile, st,     \
+                                                rows_valid, tau_out);
+    switch (kc) {
+        NABO_PRE(1) NABO_PRE(2) NABO_PRE(3) NABO_PRE(4)
+    default: return hipErrorInvalidValue;
+    }
+#undef NABO_PRE
+}
+
 template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES>
 static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
+                              int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
+                              int64_t tau_row0)
 {
     const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)WAVES * ListCfg<EPL, ROWN, NBv, NRECv, 16, (ROWN >= 64)>::BYTES;
@@ -526,7 +682,7 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(64 * WAVES);
     hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
-                       cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init);
+                       cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride, tau_row0);
 #ifdef NABO_LISTS_PROF
     {
         unsigned long long h[8];
@@ -542,18 +698,19 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
 template <int KS>
 static hipError_t claunch_one(int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                              int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
+                              int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
+                              int64_t tau_row0)
 {
     if constexpr (KS <= 2) {
         if (geo == 1)
             return claunch_geo<KS, 1, L2C_ROW_B, 6, L2C_NREC_B, 8>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx,
-                                                                  cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+                                                                  cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
     }
     if (geo == 2)
         return claunch_geo<KS, 2, L2C_ROW_C, 4, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
-                                                            cand_tau, pad_tile, st, rows_valid, tau_init);
+                                                            cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
     return claunch_geo<KS, 1, L2C_ROW, 8, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau,
-                                                      pad_tile, st, rows_valid, tau_init);
+                                                      pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
 }
 
 // Which geometry serves lists of `lkeep_want` kept entries: 1 = B (two waves per SIMD) up to 23 entries and KS <= 2 (its
@@ -590,16 +747,17 @@ int l2c_pick_kc(int g)
 // caller's padding tile, never past the allocation.  geo: what l2c_geometry said when the caller sized its grid.
 hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init)
+                           int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
+                           int64_t tau_row0)
 {
     if ((int64_t)tiles_per_split * 32 >= NABO_LIST_SPLIT_REFS) return hipErrorInvalidValue;   // topk_lists.h: 25 bits of offset per entry
     if (geo < 0 || geo > 2 || (geo == 1 && (kc > 4 || lkeep > L2C_ROW_B)) || (geo == 0 && lkeep > 32) || lkeep > 64)
         return hipErrorInvalidValue;
     switch (kc) {
-    case 2: return claunch_one<1>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
-    case 4: return claunch_one<2>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
-    case 6: return claunch_one<3>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
-    case 8: return claunch_one<4>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init);
+    case 2: return claunch_one<1>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+    case 4: return claunch_one<2>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+    case 6: return claunch_one<3>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+    case 8: return claunch_one<4>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
     default: return hipErrorInvalidValue;
     }
 }

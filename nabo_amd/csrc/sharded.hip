@@ -49,6 +49,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -171,6 +172,10 @@ struct LoopHub {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return NABO_OK;
@@ -215,7 +220,12 @@ struct nabo_comm {
     // r % ref_shards and answers for target slice r / ref_shards; 0 = world (every rank its own piece: the 1-D form)
     int ref_shards = 0;
     double timeout_s = 600.0;        // deadline of every wait on a peer
-    volatile bool aborted = false;   // set once; every later call on this communicator fails with NABO_E_COMM
+    std::atomic<bool> aborted{false};   // set once (exchange: one thread wins); every later call fails with NABO_E_COMM
+    // nabo_comm_abort may come from ANY thread while the rank's own thread polls the handle: ncclCommAbort frees it, so the
+    // handle is only touched under this lock and never again once nccl_dead is set (the pointer itself stays until destroy)
+    pthread_mutex_t nccl_lock = PTHREAD_MUTEX_INITIALIZER;
+    bool nccl_dead = false;
+    bool group_open = false;         // the rank's thread has an RCCL group open (closed BEFORE an abort: see rccl_failed)
     bool agreed = false;             // the error being returned was agreed on by all ranks (no abort needed)
 };
 
@@ -225,10 +235,11 @@ namespace {
 // error, our own stream is released); loopback: the hub's flag + a broadcast.  Idempotent; callable from any thread.
 void comm_abort(nabo_comm *c)
 {
-    if (!c || c->aborted) return;
-    c->aborted = true;
+    if (!c || c->aborted.exchange(true)) return;             // one caller aborts, every other one returns
     if (c->kind == 0) {
-        if (c->nccl && g_rccl.CommAbort) { (void)g_rccl.CommAbort(c->nccl); c->nccl = nullptr; }
+        pthread_mutex_lock(&c->nccl_lock);
+        if (c->nccl && !c->nccl_dead && g_rccl.CommAbort) { (void)g_rccl.CommAbort(c->nccl); c->nccl_dead = true; }
+        pthread_mutex_unlock(&c->nccl_lock);
     } else if (c->hub) {
         pthread_mutex_lock(&c->hub->lock);
         c->hub->aborted = true;
@@ -242,12 +253,24 @@ int comm_dead(nabo_comm *c)
     return api_fail(NABO_E_COMM, "rank %d: the communicator was aborted (an earlier collective failed or timed out)", c->rank);
 }
 
+// An RCCL call of the rank's own thread failed: an open group is closed FIRST (ncclGroupEnd on operations of a freed
+// communicator is undefined), then the communicator is aborted.
+void rccl_failed(nabo_comm *c)
+{
+    if (c->group_open) {
+        c->group_open = false;
+        (void)g_rccl.GroupEnd();
+    }
+    comm_abort(c);
+}
+
 #define RCCL_TRY(expr)                                                                                  \
     do {                                                                                                \
+        if (c->aborted.load()) return comm_dead(c);      /* the handle may be gone: never enqueue on it */ \
         ncclResult_t r__ = (expr);                                                                      \
         if (r__ != ncclSuccess) {                                                                       \
             const int rc__ = api_fail(NABO_E_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(r__)); \
-            comm_abort(c);                                                                              \
+            rccl_failed(c);                                                                             \
             return rc__;                                                                                \
         }                                                                                               \
     } while (0)
@@ -261,7 +284,7 @@ struct Group {
     {
         if (c->kind == 0) {
             RCCL_TRY(g_rccl.GroupStart());
-            open = true;
+            open = c->group_open = true;
         }
         return NABO_OK;
     }
@@ -269,13 +292,24 @@ struct Group {
     {
         if (open) {
             open = false;
-            RCCL_TRY(g_rccl.GroupEnd());
+            if (!c->group_open) return comm_dead(c);          // rccl_failed closed it on the way out of a failed call
+            c->group_open = false;
+            ncclResult_t r = g_rccl.GroupEnd();
+            if (r != ncclSuccess) {
+                const int rc = api_fail(NABO_E_COMM, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(r));
+                comm_abort(c);
+                return rc;
+            }
         }
         return NABO_OK;
     }
     ~Group()
     {
-        if (open) (void)g_rccl.GroupEnd();
+        // (an error return between begin and end: the thread's group state must not leak into its next RCCL call)
+        if (open && c->group_open) {
+            c->group_open = false;
+            (void)g_rccl.GroupEnd();
+        }
     }
 };
 
@@ -288,6 +322,7 @@ int stream_wait(nabo_comm *c)
         HIP_TRY(hipStreamSynchronize(c->stream));
         return NABO_OK;
     }
+    if (c->aborted.load()) return comm_dead(c);
     const double t0 = now_s();
     for (unsigned spins = 1;; ++spins) {
         const hipError_t e = hipStreamQuery(c->stream);
@@ -299,7 +334,13 @@ int stream_wait(nabo_comm *c)
         }
         if ((spins & 255) == 0) {
             ncclResult_t ar = ncclSuccess;
-            if (g_rccl.CommGetAsyncError(c->nccl, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+            bool dead;
+            pthread_mutex_lock(&c->nccl_lock);                // (an abort from another thread frees the handle)
+            dead = c->nccl_dead;
+            const bool have = !dead && g_rccl.CommGetAsyncError(c->nccl, &ar) == ncclSuccess;
+            pthread_mutex_unlock(&c->nccl_lock);
+            if (dead) return comm_dead(c);
+            if (have && ar != ncclSuccess && ar != ncclInProgress) {
                 const int rc = api_fail(NABO_E_COMM, "rank %d: RCCL reported an asynchronous error: %s", c->rank, g_rccl.GetErrorString(ar));
                 comm_abort(c);
                 return rc;
@@ -345,7 +386,7 @@ int hub_wait(nabo_comm *c)
     }
     pthread_mutex_unlock(&h->lock);
     if (rc) {
-        c->aborted = true;
+        c->aborted.store(true);
         return api_fail(NABO_E_COMM, "rank %d: the loopback group was aborted (a peer failed, or did not arrive within %.0f s)", c->rank, c->timeout_s);
     }
     return NABO_OK;
@@ -666,7 +707,7 @@ int nabo_comm_destroy(nabo_comm *c)
 {
     if (!c) return NABO_OK;
     (void)hipSetDevice(c->device);
-    if (c->nccl && g_rccl.CommDestroy) {
+    if (c->nccl && !c->nccl_dead && g_rccl.CommDestroy) {
         // a stream that still waits for a peer must not block the teardown
         if (c->stream && hipStreamQuery(c->stream) == hipErrorNotReady && g_rccl.CommAbort) (void)g_rccl.CommAbort(c->nccl);
         else (void)g_rccl.CommDestroy(c->nccl);
@@ -683,10 +724,6 @@ int nabo_comm_destroy(nabo_comm *c)
         pthread_mutex_unlock(&c->hub->lock);
         if (left == 0) delete c->hub;
     }
-    DevBuf *bufs[] = {&c->ci, &c->cd, &c->cb, &c->ri, &c->rd, &c->rb, &c->mi, &c->md, &c->oi, &c->od, &c->fulli, &c->fulld, &c->cnt,
-                      &c->bad, &c->ids, &c->allids, &c->sel, &c->xb, &c->bi, &c->bd, &c->gi, &c->gd, &c->fi, &c->fd, &c->scratch,
-                      &c->agree, &c->pi, &c->pd};
-    for (DevBuf *b : bufs) b->release();
     for (int i = 0; i < 8; ++i)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -6,72 +6,21 @@ certificate, second round, gather) runs with 8 loopback ranks on the one GPU, in
 and every rank's result must equal the unsharded index on ALL rows bit for bit and the oracle on a row sample.
 
 configs[4]: 5M ref x 5M target, d=100, k=50, cosine + 1000-permutation null (both EXTENSIONS: the reference has
-neither, parity is pinned by this build's own oracle only).  One rank's share at full size (625k references x
-5M targets, 24 candidates per shard), the whole 8-shard protocol on a row sample against the unsharded index over
-all 5M references and the oracle, and the permutation null at 15M edges x 1000 permutations against the oracle on
-a sampled sub-graph.
+neither, parity is pinned by this build's own oracle only).  Run WHOLE on the one GPU (tools/config4_one_gpu.py): all
+5M x 5M pairs on one unsharded index, all of them again with the references sharded 8 ways (loopback ranks, every
+rank's copy of every row compared), the reference graph, the SNN weights and the permutation null on the resulting
+~250M-edge graph; the oracle re-solves stratified row samples and a sub-graph.  The 15M-edge null test keeps the
+1000-permutation comparison with the oracle.
 """
 import numpy as np
 import pytest
 
 import oracle
 from nabo_amd import _knn
-from nabo_amd._sharded import shard_bounds, candidates_per_shard
-from nabo_amd._synth import pca_like, pca_like_big
+from nabo_amd._sharded import candidates_per_shard
+from nabo_amd._synth import pca_like
 
 pytestmark = pytest.mark.gpu
-
-
-def _protocol_one_gpu(gpu_lib, X, Y, k, N, metric, Ls, rows_chunk=None):
-    """Every shard's candidate query, the merge and the owner's certificate, as tests/_dist_spec.py and nabo_sharded_query sequence them
-    (exchange = host stack).  Returns merged idx/dist [m,k], certified flags [m] and per-shard stats."""
-    m, n = X.shape[0], Y.shape[0]
-    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
-    pi = np.empty((N, m, Ls), dtype=np.int64)
-    pd = np.empty((N, m, Ls), dtype=np.float64)
-    pb = np.empty((N, m), dtype=np.float64)
-    stats = []
-    for r in range(N):
-        lo, hi = shard_bounds(n, N, r)
-        sx = gpu_lib.KnnIndex(hi - lo, Y.shape[1], metric=metric, ref_index_base=lo).set_ref(Y[lo:hi])
-        di, dd, db = _knn.DeviceBuffer(m * Ls * 8), _knn.DeviceBuffer(m * Ls * 8), _knn.DeviceBuffer(m * 8)
-        sx.query_candidates_device(dx.ptr, m, Ls, di.ptr, dd.ptr, db.ptr)
-        stats.append(sx.last_stats())
-        pi[r], pd[r], pb[r] = di.download((m, Ls), np.int64), dd.download((m, Ls), np.float64), db.download((m,), np.float64)
-        sx.close()
-        for b in (di, dd, db):
-            b.free()
-    dx.free()
-    dpi, dpd = _knn.DeviceBuffer(pi.nbytes).upload(pi), _knn.DeviceBuffer(pd.nbytes).upload(pd)
-    doi, dod = _knn.DeviceBuffer(m * k * 8), _knn.DeviceBuffer(m * k * 8)
-    _knn.merge_topk_device(dpi.ptr, dpd.ptr, N, m, Ls, k, False, doi.ptr, dod.ptr)
-    mi, md = doi.download((m, k), np.int64), dod.download((m, k), np.float64)
-    for b in (dpi, dpd, doi, dod):
-        b.free()
-    dk = md[:, k - 1]
-    ok = (mi[:, k - 1] >= 0) & (dk * dk * (1 + 1e-12) < pb.min(axis=0))          # the owner certificate (sharded.hip certify_kernel)
-    return mi, md, ok, stats, (pi, pd, pb)
-
-
-def _second_round(gpu_lib, X, Y, k, N, metric, bad, mi, md):
-    """rows the owner could not certify: exact local top-k of just those rows on every shard, merged"""
-    if bad.size == 0:
-        return
-    Xb = np.ascontiguousarray(X[bad])
-    n = Y.shape[0]
-    pi = np.empty((N, bad.size, k), dtype=np.int64)
-    pd = np.empty((N, bad.size, k), dtype=np.float64)
-    for r in range(N):
-        lo, hi = shard_bounds(n, N, r)
-        sx = gpu_lib.KnnIndex(hi - lo, Y.shape[1], metric=metric, ref_index_base=lo).set_ref(Y[lo:hi])
-        pi[r], pd[r] = sx.query(Xb, k)
-        sx.close()
-    dpi, dpd = _knn.DeviceBuffer(pi.nbytes).upload(pi), _knn.DeviceBuffer(pd.nbytes).upload(pd)
-    doi, dod = _knn.DeviceBuffer(bad.size * k * 8), _knn.DeviceBuffer(bad.size * k * 8)
-    _knn.merge_topk_device(dpi.ptr, dpd.ptr, N, bad.size, k, k, False, doi.ptr, dod.ptr)
-    mi[bad], md[bad] = doi.download((bad.size, k), np.int64), dod.download((bad.size, k), np.float64)
-    for b in (dpi, dpd, doi, dod):
-        b.free()
 
 
 def _loopback_all_ranks(N, R, X, Y, k, metric=0, drop=False):
@@ -136,59 +85,75 @@ def test_baseline_configs3_sorted_references_take_the_second_round(gpu_lib):
         assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
 
 
-def test_baseline_configs4_one_ranks_share_and_protocol_sample(gpu_lib):
-    """BASELINE configs[4] (EXTENSION metric, parity vs this build's oracle): rank 0's share at full size --
-    625k references x 5M targets, d=100, k=50, cosine, 24 candidates per shard -- then the 8-shard protocol on a
-    row sample against the unsharded index over all 5M references and against the oracle."""
+def test_baseline_configs4_whole_on_one_gpu(gpu_lib):
+    """BASELINE configs[4] run WHOLE on one MI355X (EXTENSION metric + EXTENSION null: parity vs this build's oracle only):
+    5M x 5M, d=100, k=50, cosine -- ALL 5M target rows on one unsharded index, ALL of them again through
+    nabo_sharded_query with the reference rows sharded 8 ways (loopback ranks: every rank's copy of every row must equal
+    the unsharded result), the reference <-> reference graph, the SNN weights, and nabo_score_null_edges on the resulting
+    ~250M-edge graph with 1000 permutations (tools/config4_one_gpu.py).  Oracle: >= 256 target rows stratified by the
+    pass that answered them + reference rows (order rows as nabo/_mapping.py:139-145 defines them, cosine expression of
+    oracle/nabo_oracle.c), the SNN counts of a row sample, the mapping score (nabo/_graph.py:644-653) and the null on
+    the sub-graph of 150 reference nodes."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "config4_one_gpu", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "config4_one_gpu.py"))
+    c4 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(c4)
     n = m = 5000000
-    d, k, N = 100, 50, 8
-    MET = gpu_lib.COSINE
-    Y = pca_like_big(n, d, seed=1004)
-    X = pca_like_big(m, d, seed=2004)
-    Ls = candidates_per_shard(k, N, m)
-    assert Ls == 24
-    lo, hi = shard_bounds(n, N, 0)
-    sx = gpu_lib.KnnIndex(hi - lo, d, metric=MET, ref_index_base=lo).set_ref(Y[lo:hi])
-    batch = 1000000
-    di, dd, db = _knn.DeviceBuffer(batch * Ls * 8), _knn.DeviceBuffer(batch * Ls * 8), _knn.DeviceBuffer(batch * 8)
-    dx = _knn.DeviceBuffer(batch * d * 8)
+    d, k, N, P = 100, 50, 8, 1000
+    rep, A = c4.run(n, m, d, k, ranks=N, perms=P, keep=True)
+    X, Y, ti, td, ri, rd = A["X"], A["Y"], A["ti"], A["td"], A["ri"], A["rd"]
+    # ---- all rows: size-independent properties ----------------------------------------------------------------------
+    for gi, gd in ((ti, td), (ri, rd)):
+        assert gi.min() >= 0 and gi.max() < n
+        assert (np.diff(gd, axis=1) >= 0).all() and (gd >= -1e-15).all() and (gd <= 2.0 + 1e-12).all()
+        srt = np.sort(gi, axis=1)
+        assert (np.diff(srt, axis=1) > 0).all()                               # no repeated neighbour in any row
+    assert not (ri == np.arange(n)[:, None]).any()                            # positional self-drop (no exact twins in this data)
+    assert rep["sharded_loopback"]["all_rows_of_all_ranks_equal_unsharded"]
+    assert rep["sharded_loopback"]["candidates_per_shard"] == candidates_per_shard(k, N, 1000000) == 23
+    assert rep["sharded_loopback"]["second_round_rows_max"] < 100
+    assert "l2c_topk_kernel<4," in rep["target_knn"]["kernel"], rep["target_knn"]["kernel"]
+    assert rep["target_knn"]["rows_by_pass"]["exact"] < 1000
+    # ---- >= 256 target rows + 64 reference rows against the oracle, stratified by the pass that answered them ------------
     rng = np.random.default_rng(9)
-    ms = 0.0
-    for b0 in range(0, m, batch):
-        xb = np.ascontiguousarray(X[b0:b0 + batch])
-        dx.upload(xb)
-        sx.query_candidates_device(dx.ptr, batch, Ls, di.ptr, dd.ptr, db.ptr)
-        ms += sx.last_stats()["ms_total"]
-        ci, cd, cb = di.download((batch, Ls), np.int64), dd.download((batch, Ls), np.float64), db.download((batch,), np.float64)
-        # all rows: global indices of THIS shard, no repeats, ascending distances, a usable bound
-        assert ci.min() >= lo and ci.max() < hi
-        assert (np.diff(np.sort(ci, axis=1), axis=1) > 0).all()
-        assert (np.diff(cd, axis=1) >= 0).all() and (cd >= -1e-15).all() and (cd <= 2.0 + 1e-12).all()
-        assert np.isfinite(cb).all() and (cb > 0).all()
-        # sampled rows: the list is the oracle's order row of the shard, and the bound really bounds the rest
-        rows = rng.choice(batch, 6, replace=False)
-        oi, od = oracle.knn(xb[rows], Y[lo:hi], Ls + 1, oracle.COSINE, nthreads=8)
-        assert np.array_equal(ci[rows], oi[:, :Ls] + lo) and np.array_equal(cd[rows], od[:, :Ls])
-        assert (cb[rows] <= od[:, Ls] ** 2 * (1 + 1e-12)).all()
-    sx.close()
-    for b in (di, dd, db, dx):
-        b.free()
-    assert ms < 20000, "rank share took %.0f ms" % ms          # 4.9 s in round 1; a gross regression guard only
-    # the whole protocol for a sample of targets
-    sample = 20000
-    rows = np.sort(rng.choice(m, sample, replace=False))
-    Xs = np.ascontiguousarray(X[rows])
-    del X
-    ix = gpu_lib.KnnIndex(n, d, metric=MET).set_ref(Y)
-    ri, rd = ix.query(Xs, k)
-    ix.close()
-    mi, md, ok, _, _ = _protocol_one_gpu(gpu_lib, Xs, Y, k, N, MET, Ls)
-    bad = np.nonzero(~ok)[0]
-    assert bad.size < 20
-    _second_round(gpu_lib, Xs, Y, k, N, MET, bad, mi, md)
-    assert np.array_equal(mi, ri) and np.array_equal(md, rd)
-    oi, od = oracle.knn(Xs[:16], Y, k, oracle.COSINE, nthreads=8)
-    assert np.array_equal(mi[:16], oi) and np.array_equal(md[:16], od)
+    rp = A["rp_t"]
+    rare = np.nonzero(rp >= 1)[0]
+    rows = np.unique(np.concatenate([rng.choice(rare, min(rare.size, 128), replace=False),
+                                     np.nonzero(rp >= 2)[0][:64], rng.choice(m, 160, replace=False)]))
+    assert rows.size >= 256
+    oi, od = oracle.knn(X[rows], Y, k, oracle.COSINE, nthreads=16)
+    assert np.array_equal(ti[rows], oi) and np.array_equal(td[rows], od)
+    rrows = np.unique(np.concatenate([np.nonzero(A["rp_r"] >= 1)[0][:32], rng.choice(n, 32, replace=False)]))
+    oi, od = oracle.knn(Y[rrows], Y, k, oracle.COSINE, drop_first=True, nthreads=16)
+    assert np.array_equal(ri[rrows], oi) and np.array_equal(rd[rrows], od)
+    # ---- SNN counts of a row sample (nabo/_mapping.py:186-198) -------------------------------------------------------------
+    srows = rng.choice(m, 2000, replace=False)
+    for t in srows[:200]:
+        st = set(ti[t].tolist())
+        want = [len(st & set(ri[j].tolist())) for j in ti[t]]
+        assert A["snn"][t].tolist() == want
+    assert rep["edges"] == int((A["snn"] > 0).sum()) and rep["edges"] > 100000000
+    # ---- the null: observed score == the reference's mapping score; oracle on a sub-graph, first 48 permutations ----------
+    e_t, e_r, w, group, null = A["e_t"], A["e_r"], A["w"], A["group"], A["null"]
+    keep = group[e_t] != 0
+    sc = gpu_lib.mapping_score_from_edges(n, e_r[keep], w[keep], int(group.sum()))
+    assert np.allclose(null["obs"], sc, rtol=1e-12, atol=0)
+    assert (null["sizes"] == int(group.sum())).all() and ((null["n_ge"] >= 0) & (null["n_ge"] <= P)).all()
+    deg = np.bincount(e_r, minlength=n)
+    hot = np.sort(rng.choice(np.nonzero(deg > 0)[0], 150, replace=False))
+    sel = np.isin(e_r, hot)
+    P2 = 48                                                                    # (the oracle labels all 5M pooled cells per permutation)
+    small = gpu_lib.mapping_score_null(e_t[sel], np.searchsorted(hot, e_r[sel]), w[sel], group, hot.size, n_perm=P2, seed=3)
+    o = oracle.score_null(e_t[sel], np.searchsorted(hot, e_r[sel]), w[sel], group, hot.size, P2, seed=3)
+    for key in ("obs", "n_ge", "sizes"):
+        assert np.array_equal(small[key], o[key]), key
+    assert np.allclose(small["null_mean"], o["null_mean"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(small["null_sd"], o["null_sd"], rtol=1e-9, atol=1e-9)
+    # the whole-graph run and the sub-graph run agree where they overlap (same permutations: a prefix of the 1000)
+    assert np.array_equal(null["obs"][hot], small["obs"])
+    assert (null["n_ge"][hot] >= small["n_ge"]).all()
 
 
 def test_baseline_configs4_permutation_null_15M_edges_1000_permutations(gpu_lib):

@@ -297,23 +297,45 @@ def test_config2_100k_sampled_rows(gpu_lib):
     assert st["fallback_rows"] < n // 100
 
 
+def _stratified_rows(rp, n_total, n_rare, seed):
+    """>= n_total rows for the oracle: EVERY row a pass behind the seeded one answered, up to n_rare (at least) of the rows
+    the seeded pass answered, the rest uniform over the rows of the first pass (nabo_index_last_row_pass)."""
+    rng = np.random.default_rng(seed)
+    beyond = np.nonzero(rp >= 2)[0]
+    seeded = np.nonzero(rp == 1)[0]
+    take = [beyond[:2048], rng.choice(seeded, min(seeded.size, n_rare), replace=False)]
+    first = np.nonzero(rp == 0)[0]
+    left = max(n_total - sum(t.size for t in take), 256)
+    take.append(rng.choice(first, min(first.size, left), replace=False))
+    return np.unique(np.concatenate(take))
+
+
 def test_config3_full_size_1M_properties(gpu_lib):
     """BASELINE configs[2] at FULL size (1M x 1M, d=50, k=15, the bench workload) through the resident-index
-    entry points: size-independent properties on all rows, a row sample re-solved by the oracle, and the
-    reference-vs-itself form (positional self-drop) on a slice."""
+    entry points: size-independent properties on all rows; >= 1024 rows re-solved by the oracle, STRATIFIED by the pass
+    that answered them (nabo_index_last_row_pass): at least 256 of the ~0.7 % of rows the seeded pass answered, every
+    row a pass behind it answered, the rest uniform (the order rows must equal nabo/_mapping.py:139-145 whichever
+    pass produced them); and the reference-vs-itself form (positional self-drop) on a slice."""
     n = 1000000
     Y = pca_like(n, 50, seed=1003)
     X = pca_like(n, 50, seed=2003)
     ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
     gi, gd = ix.query(X, 15)
     st = ix.last_stats()
+    rp = ix.last_row_pass(n)
     assert st["fallback_rows"] < 1000
+    # the per-row record agrees with the per-pass counters
+    assert int((rp >= 1).sum()) == st["seeded_pass_rows"]
+    assert int((rp >= 2).sum()) == st["second_pass_rows"] and int((rp >= 3).sum()) >= st["wide_list_rows"]
+    assert int((rp == 4).sum()) == st["fallback_rows"]
+    assert "l2c_topk_kernel" in ix.last_kernel() and st["seeded_pass_rows"] >= 256, "the default chain: one-product pass, then seeded"
     assert (np.diff(gd, axis=1) >= 0).all()                       # sorted rows
     assert gi.min() >= 0 and gi.max() < n
     s = np.sort(gi, axis=1)
     assert (np.diff(s, axis=1) > 0).all()                         # no repeated neighbour in any row
-    rows = np.random.default_rng(5).choice(n, 48, replace=False)
-    oi, od = oracle.knn(X[rows], Y, 15, 0, nthreads=8)
+    rows = _stratified_rows(rp, 1024, 384, seed=5)
+    assert rows.size >= 1024 and int((rp[rows] == 1).sum()) >= 256 and set(np.nonzero(rp >= 2)[0][:2048]) <= set(rows)
+    oi, od = oracle.knn(X[rows], Y, 15, 0, nthreads=16)
     _check(gi[rows], gd[rows], oi, od)
     # every returned distance is the reference formula at the returned index (checksum over a sample of rows)
     rs = rows[:16]
@@ -326,6 +348,37 @@ def test_config3_full_size_1M_properties(gpu_lib):
     assert (gd2[:, 0] > 0).all()
     o2i, o2d = oracle.knn(Y[rows[:8] % 20000], Y, 15, 0, drop_first=True, nthreads=8)
     _check(gi2[rows[:8] % 20000], gd2[rows[:8] % 20000], o2i, o2d)
+
+
+def test_config3_full_size_1M_every_filter_gives_the_same_bits_on_all_rows(gpu_lib, monkeypatch):
+    """ALL 1M rows of BASELINE configs[2] through three different first filters -- the default chain (one-product pass,
+    seeded pass, ...), the f16x3 split first (NABO_L2_MODE=f16x3) and the fp32-MFMA filter (NABO_L2_MODE=f32: no f16
+    arithmetic anywhere) -- must agree bit for bit, indices and distances: the all-rows cross-check of bench.py's alt
+    blocks as a test.  (They share refine_kernel's float64 evaluation; the filters, their error budgets and the rows
+    that leave the first pass differ: the 0.7 % of rows the seeded pass answers in the default chain are certified by
+    the first pass in the other two.)"""
+    n = 1000000
+    Y = pca_like(n, 50, seed=1003)
+    X = pca_like(n, 50, seed=2003)
+    res = {}
+    for mode in ("", "f16x3", "f32"):
+        if mode:
+            monkeypatch.setenv("NABO_L2_MODE", mode)
+        else:
+            monkeypatch.delenv("NABO_L2_MODE", raising=False)
+        ix = gpu_lib.KnnIndex(n, 50, metric=0).set_ref(Y)
+        gi, gd = ix.query(X, 15)
+        res[mode] = (gi, gd, ix.last_kernel(), ix.last_row_pass(n), ix.last_stats())
+        ix.close()
+    monkeypatch.delenv("NABO_L2_MODE", raising=False)
+    assert "l2c_topk_kernel" in res[""][2] and "l2q_topk_kernel" in res["f16x3"][2] and "f32_32x32x2" in res["f32"][2]
+    for mode in ("f16x3", "f32"):
+        assert np.array_equal(res[mode][0], res[""][0]), mode
+        assert np.array_equal(res[mode][1], res[""][1]), mode
+        assert (res[mode][3] >= 2).all()                          # these chains start at the "second" filter
+    # the rows the default chain could not certify in its first pass were certified by the first pass of the others
+    seeded = res[""][3] == 1
+    assert seeded.sum() >= 256 and (res["f32"][3][seeded] == 2).mean() > 0.99
 
 
 def test_canberra_tail_round_rows_are_exact(gpu_lib):
@@ -1058,3 +1111,92 @@ def test_weak_one_product_bound_is_remembered_until_the_references_change(gpu_li
     assert kernels[0].startswith("l2c_topk") and second[0] > m // 4, (kernels, second)
     assert kernels[1].startswith("l2q_topk") and second[1] == 0, (kernels, second)
     assert kernels[2].startswith("l2c_topk"), kernels
+
+
+def test_create_and_destroy_many_indices_returns_the_device_memory(gpu_lib):
+    """nabo_index_destroy frees EVERY buffer of an index (round-3 advisory: the release list missed the one-product tiles,
+    128 MB at 1M references -- every one-shot nabo_knn call, Mapping call and bench layout leaked them): free device memory
+    after 24 create / set_ref / query / destroy cycles over all three metrics (and every pass of the Euclidean chain: the
+    tight far-away cluster sends rows through the seeded pass and the pass behind it) is back at the baseline."""
+    from nabo_amd import _lib
+    rng = np.random.default_rng(77)
+    Y = pca_like(60000, 50, seed=31)
+    Y[:20000] = 400.0 + 1e-3 * rng.standard_normal((20000, 50))       # weak one-product bound: later passes allocate too
+    X = np.concatenate([pca_like(3000, 50, seed=32), Y[:3000] + 1e-4])
+    ix = gpu_lib.KnnIndex(60000, 50, metric=0).set_ref(Y)              # warm-up: code objects, allocator pools
+    ix.query(X, 15)
+    ix.close()
+    _lib.check(_lib.lib().nabo_dev_synchronize(0))
+    free0, total = _lib.mem_info(0)
+    for it in range(24):
+        metric = it % 3
+        ix = gpu_lib.KnnIndex(60000, 50, metric=metric, dist_factor=0.25).set_ref(Y)
+        ix.query(X, 15)
+        ix.close()
+        gpu_lib.knn(X[:64], Y, 5, metric=metric)                       # the one-shot entry point creates and destroys its own
+    _lib.check(_lib.lib().nabo_dev_synchronize(0))
+    free1, _ = _lib.mem_info(0)
+    assert free0 - free1 < 32 << 20, "device memory not returned: %.1f MB gone after 24 cycles" % ((free0 - free1) / 2 ** 20)
+
+
+def test_row_pass_record_names_the_pass_that_answered_each_row(gpu_lib, monkeypatch):
+    """nabo_index_last_row_pass: the chain test's data (a tight cluster far from the centre: the one-product bound fails
+    there) -- the record's counts equal nabo_index_last_passes, every pass of the chain occurs, all rows equal the oracle;
+    pinning the f16x3 filter as the first pass renames every row; the Canberra record separates filter and exact rows."""
+    rng = np.random.default_rng(5)
+    n, g, k = 40000, 50, 15
+    Y = pca_like(n, g, seed=41)
+    Y[:8000] = 300.0 + 2e-3 * rng.standard_normal((8000, g))
+    X = np.concatenate([pca_like(1500, g, seed=42), Y[:1500] + 1e-5 * rng.standard_normal((1500, g))])
+    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    gi, gd = ix.query(X, k)
+    st, rp = ix.last_stats(), ix.last_row_pass(X.shape[0])
+    with pytest.raises(ValueError):
+        ix.last_row_pass(X.shape[0] + 1)
+    ix.close()
+    oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
+    _check(gi, gd, oi, od)
+    assert int((rp >= 1).sum()) == st["seeded_pass_rows"] > 0 and int((rp >= 2).sum()) == st["second_pass_rows"]
+    assert int((rp == 4).sum()) == st["fallback_rows"] and (rp[:1500] == 0).mean() > 0.9
+    monkeypatch.setenv("NABO_L2_MODE", "f16x3")
+    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    monkeypatch.delenv("NABO_L2_MODE")
+    hi, hd = ix.query(X, k)
+    rp2 = ix.last_row_pass(X.shape[0])
+    ix.close()
+    assert np.array_equal(hi, gi) and np.array_equal(hd, gd) and (rp2 >= 2).all()
+    # modified Canberra: duplicated references make exact ties the filter cannot certify
+    Yc = pca_like(3000, 20, seed=43)
+    Yc[1500:1540] = Yc[100]
+    Xc = np.concatenate([pca_like(200, 20, seed=44), Yc[100:101]])
+    ix = gpu_lib.KnnIndex(3000, 20, metric=1, dist_factor=0.25).set_ref(Yc)
+    ci, cd = ix.query(Xc, 11)
+    st, rpc = ix.last_stats(), ix.last_row_pass(Xc.shape[0])
+    ix.close()
+    oi, od = oracle.knn(Xc, Yc, 11, 1, 0.25, nthreads=8)
+    _check(ci, cd, oi, od)
+    assert set(np.unique(rpc)) <= {4, 5} and int((rpc == 4).sum()) == st["fallback_rows"]
+
+
+@pytest.mark.parametrize("m,n,g,k,drop,metric,splits", [(3000, 60000, 50, 15, 0, 0, "0"), (700, 200000, 50, 15, 0, 0, "0"),
+                                                       (2500, 90000, 30, 40, 1, 0, "0"), (1500, 70000, 100, 50, 0, 2, "0"),
+                                                       (900, 50000, 50, 15, 0, 0, "3"), (1200, 40000, 80, 11, 1, 2, "2")])
+def test_tournament_seeds_change_no_result(gpu_lib, monkeypatch, m, n, g, k, drop, metric, splits):
+    """l2c_pre_kernel (the one-product pass starts every list from an upper bound of its lkeep-th smallest score among the
+    split's first references instead of +inf): results with it, with four times the planned tournament and without it are
+    the same bits as the oracle's -- all three geometries, one to four operand steps, reference splits, the tail launch,
+    cosine.  With seeds the first pass must not certify fewer rows than the margin its shorter warm-up can explain."""
+    Y = pca_like(n, g, seed=51)
+    X = pca_like(m, g, seed=52) if not drop else Y[:m]
+    oi, od = oracle.knn(X, Y, k, metric, drop_first=bool(drop), nthreads=16)
+    monkeypatch.setenv("NABO_SPLITS", splits)
+    res = {}
+    for pre in ("100", "400", "0"):
+        monkeypatch.setenv("NABO_PREPASS", pre)
+        ix = gpu_lib.KnnIndex(n, g, metric=metric).set_ref(Y)
+        gi, gd = ix.query(X, k, drop_first=bool(drop))
+        res[pre] = ix.last_stats()
+        assert "l2c_topk_kernel" in ix.last_kernel()
+        ix.close()
+        _check(gi, gd, oi, od)
+    assert res["100"]["seeded_pass_rows"] <= res["0"]["seeded_pass_rows"] + max(8, m // 50)
