@@ -420,7 +420,10 @@ def main():
             line["roofline"] = canberra_roofline(pmc_record("canberra", workload, dig), t_kernel, kern, dig)
         if kind != "single":
             hx = [s for s in per_rank if "sharded" in s]
-            line["sharded"] = {"world": ranks if kind != "loopback" else 1, "rccl_world": ranks if kind in ("launcher", "threads") else None,
+            # (what the TRANSPORT reports, not what was asked for: ncclCommCount of this rank's communicator)
+            tr = (comm.transport_ranks() if comm is not None else lay.group.comms[0].transport_ranks() if lay.group is not None else None)
+            line["sharded"] = {"world": ranks if kind != "loopback" else 1, "rccl_world": tr if kind in ("launcher", "threads") else None,
+                               "ranks_requested": ranks,
                                "loopback_ranks": ranks if kind == "loopback" else None,
                                "layout": {"ref_shards": shards, "target_slices": slices},
                                "candidates_per_shard": head["candidates"], "second_round_rows": head["second_round_rows"],

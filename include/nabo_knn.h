@@ -181,6 +181,9 @@ int nabo_comm_create_loopback(nabo_comm **comms /* [n] */, const int32_t *device
 int nabo_comm_destroy(nabo_comm *c);
 int nabo_comm_rank(const nabo_comm *c);
 int nabo_comm_world(const nabo_comm *c);
+/* How many ranks the TRANSPORT itself says the communicator has -- ncclCommCount for RCCL, the rendezvous' size for the
+ * loopback transport -- as opposed to what the caller asked for (nabo_comm_world): a benchmark line reports this one. */
+int nabo_comm_transport_ranks(nabo_comm *c);
 /* Give up on a communicator from ANY thread: every rank blocked in one of its collectives (and every later call on
  * it) returns NABO_E_COMM -- ncclCommAbort for RCCL, the rendezvous' abort flag for the loopback transport.  The
  * handle must still be destroyed.  nabo_comm_set_timeout: how long a rank waits for its peers inside a collective

@@ -31,7 +31,7 @@ FILE_FLAGS = {"l2_topk.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-na
 HEADERS = [os.path.join(CSRC, "knn_common.h"), os.path.join(CSRC, "topk_lists.h"), os.path.join(HERE, "..", "include", "nabo_knn.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 
 
 def hipcc():

@@ -25,7 +25,7 @@ SYMBOLS = [
     "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_index_last_row_pass", "nabo_merge_topk", "nabo_snn_counts", "nabo_pyset_order", "nabo_component_labels", "nabo_group_edges", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize", "nabo_dev_mem_info",
     "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
-    "nabo_comm_rank", "nabo_comm_world", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
+    "nabo_comm_rank", "nabo_comm_world", "nabo_comm_transport_ranks", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
     "nabo_sharded_query", "nabo_sharded_last_stats",
 ]
 
@@ -74,6 +74,7 @@ def lib():
     L.nabo_comm_destroy.argtypes = [vp]
     L.nabo_comm_rank.argtypes = [vp]
     L.nabo_comm_world.argtypes = [vp]
+    L.nabo_comm_transport_ranks.argtypes = [vp]
     L.nabo_comm_set_ref_shards.argtypes = [vp, i32]
     L.nabo_comm_abort.argtypes = [vp]
     L.nabo_comm_set_timeout.argtypes = [vp, dbl]

@@ -168,6 +168,13 @@ class Comm:
         if self._h is not None and self._h.value:
             _lib.lib().nabo_comm_abort(self._h)
 
+    def transport_ranks(self):
+        """ranks the transport itself reports (ncclCommCount / the loopback rendezvous' size)"""
+        n = _lib.lib().nabo_comm_transport_ranks(self._h)
+        if n < 0:
+            _lib.check(n)
+        return int(n)
+
     def barrier(self):
         _lib.check(_lib.lib().nabo_comm_barrier(self._h))
 

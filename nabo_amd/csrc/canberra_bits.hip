@@ -44,13 +44,32 @@ namespace nabo {
 #define NABO_CBB_B 64
 #endif
 constexpr int CBB_B = NABO_CBB_B;         // quantile buckets per dimension (survivors of the count: 7e-3 of the pairs at 32, 2.6e-3 at 64)
-constexpr int CBB_ROWS = CBB_B + 1;       // cumulative rows per dimension (row 0: empty set)
+constexpr int CBB_ROWS = CBB_B;           // STORED cumulative rows per dimension: rows 1 .. CBB_B (row 0, the empty set, is a zero row in LDS)
 constexpr int CBB_BLK = 2048;             // references per block: 64 lanes x 32 bits
 constexpr int CBB_T = 8;                  // target rows per wave (six count planes each, in registers: < 128 VGPRs per wave)
 #ifndef NABO_CBB_TB
 #define NABO_CBB_TB 8
 #endif
 constexpr int CBB_NW = 16;                // waves per workgroup (four per SIMD): they share the LDS copy of the table rows
+constexpr int CBB_WLN = 128;              // work-list ring of a wave (entries)
+constexpr int CBB_DIM_BYTES = CBB_ROWS * 256;                          // the rows of one dimension of one block: 16 KiB
+constexpr int CBB_PAIR_BYTES = 2 * CBB_DIM_BYTES;                      // ... of a pair of dimensions: contiguous in the table
+constexpr int CBB_PIECES = CBB_PAIR_BYTES / 1024;                      // 1-KiB LDS-DMA pieces per pair: two per wave
+constexpr int CBB_ZERO_OFF = CBB_PAIR_BYTES;                           // the zero row ("row 0") behind the pair, never overwritten
+constexpr int CBB_BUF_BYTES = CBB_PAIR_BYTES + 256;                    // a row buffer in LDS
+constexpr int CBB_BUF1 = 65536;                                        // LDS offset of the second row buffer (one address bit)
+static_assert(CBB_PAIR_BYTES % 1024 == 0 && CBB_PIECES == 2 * CBB_NW, "two whole DMA pieces per wave and pair");
+static_assert(CBB_BUF_BYTES <= CBB_BUF1 && CBB_BUF_BYTES <= 65536, "row addresses (16 bits) and the buffer bit must not overlap");
+// per-wave LDS block: ro2 [gp/2][T] uint2 | keys, idx [T][CAP] | tau, tidx, cnt, thr [T] | wl [WLN] u32 | wl_t [WLN] u8
+// (kept + pending list entries: 16 pending per 32 kept)
+constexpr int cbb_cap(int gp, int epl) { return 32 * epl + 16 * epl; }
+constexpr int cbb_wave_bytes(int gp, int epl) { return (gp / 2) * CBB_T * 8 + CBB_T * cbb_cap(gp, epl) * 8 + CBB_T * 16 + CBB_WLN * 5; }
+constexpr size_t cbb_lds_bytes(int gp, int epl)
+{
+    const int wbytes = cbb_wave_bytes(gp, epl);
+    const int na = (CBB_BUF1 - CBB_BUF_BYTES) / wbytes;
+    return (size_t)CBB_BUF1 + CBB_BUF_BYTES + (size_t)(CBB_NW > na ? CBB_NW - na : 0) * wbytes;
+}
 
 int cbb_buckets() { return CBB_B; }
 int cbb_rows_per_wg() { return CBB_T * CBB_NW; }
@@ -77,19 +96,20 @@ __device__ __forceinline__ int cbb_bucket(const double *__restrict__ edges, doub
 __global__ __launch_bounds__(64) void cbb_pack_table_kernel(const double *__restrict__ Y, int64_t n, int g,
                                                             const double *__restrict__ edges, uint32_t *__restrict__ tab)
 {
-    __shared__ uint32_t eq[CBB_ROWS][64];
+    __shared__ uint32_t eq[CBB_B][64];
     const int w = threadIdx.x, d = blockIdx.y;
     const int64_t blk = blockIdx.x;
 #pragma unroll
-    for (int r = 0; r < CBB_ROWS; ++r) eq[r][w] = 0u;
+    for (int r = 0; r < CBB_B; ++r) eq[r][w] = 0u;
     const double *ed = edges + (size_t)d * (CBB_B - 1);
     for (int r = 0; r < 32; ++r) {
         const int64_t j = blk * CBB_BLK + (int64_t)w * 32 + r;
-        if (j < n) eq[cbb_bucket(ed, Y[j * g + d]) + 1][w] |= 1u << r;         // (column w is this lane's own: no races)
+        if (j < n) eq[cbb_bucket(ed, Y[j * g + d])][w] |= 1u << r;             // (column w is this lane's own: no races)
     }
+    // stored row r - 1 = cumulative row r = buckets 0 .. r - 1 (cumulative row 0, the empty set, is not stored)
     uint32_t acc = 0u;
     uint32_t *o = tab + ((size_t)(blk * g + d) * CBB_ROWS) * 64 + w;
-    for (int r = 0; r < CBB_ROWS; ++r) {
+    for (int r = 0; r < CBB_B; ++r) {
         acc |= eq[r][w];
         o[(size_t)r * 64] = acc;
     }
@@ -153,7 +173,35 @@ __device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count,
     return __shfl(key[(L - 1) >> 6], (L - 1) & 63, 64);
 }
 
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + lane * 16 (M0 is written in the statement that
+// reads it and declared clobbered; hipcc neither counts nor drains this load -- the kernel waits for it itself: cbb_dma_wait).
+// (scalar base + 32-bit per-lane byte offset: the piece's address costs no vector instruction)
+__device__ __forceinline__ void cbb_glds16(const void *gbase /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_off), "s"(gbase), "s"(lds_dst)
+                 : "memory", "m0");
+}
+__device__ __forceinline__ void cbb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+typedef uint32_t cbb_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t cbb_u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const cbb_u32x4 cbb_lds_u4;
+typedef __attribute__((address_space(3))) const cbb_u32x2 cbb_lds_u2;
+
 // grid.x = ceil(m / (NW T)) workgroups of NW waves, grid.y = S splits of `blocks_per_split` reference blocks.
+//
+// Round 4: FOUR WORDS PER LANE.  The round-3 form (lane = one word of a row, eight targets one after another) issued 223
+// instructions per step of eight targets -- 142 vector, 45 scalar, 36 LDS -- and, every instruction of a SIMD costing its ~4
+// issue cycles whatever its kind, ran at exactly that price (4.7e11 instructions per 1M x 1M step = 0.77 s).  Now a lane holds
+// FOUR consecutive words (128 references) and a group of 16 lanes covers a table row, so ONE ds_read_b128 fetches a row
+// for FOUR targets at once (lane group q = lane >> 4 reads the row of target 4 s + q; rows are 256-byte aligned, so any
+// combination of rows is conflict-free in the b128 lane grouping), row addresses are per-lane registers built from ONE LDS
+// word per target and dimension pair (no v_readlane, no scalar unpacking), and the table rows arrive by LDS-DMA instead of
+// through registers.  The counters take four dimension pairs per carry-save cycle (weight-2 carries of two steps enter
+// plane 1 together, weight-4 carries of two such pairs enter plane 2 together, one weight-8 carry ripples on): 2.5 instead
+// of 3.5 instructions per dimension and word.  ~95 instructions per step of eight targets.
 template <int GP, int EPL>
 __global__ __launch_bounds__(64 * CBB_NW, 1)
 void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict__ rowoff, int64_t m,
@@ -161,23 +209,26 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                        int64_t n, int g, int64_t n_blocks, int64_t blocks_per_split, float slack, float plateau,
                        uint32_t *__restrict__ cand_idx, float *__restrict__ cand_tau)
 {
-    constexpr int T = CBB_T, NW = CBB_NW;
-    constexpr int TB = T < NABO_CBB_TB ? T : NABO_CBB_TB;      // targets per batch of row reads (their LDS reads fly together)
-    constexpr int L = 32 * EPL, CAP = L + 16 * EPL;      // kept + pending entries per list
-    constexpr int WLN = 256;                             // work-list ring (entries; <= 63 pending + 64 new)
-    constexpr int ROWW = CBB_ROWS * 64;                  // words of one dimension's rows
-    constexpr int WAVE_BYTES = T * GP * 2 + T * CAP * 8 + T * 16 + WLN * 5;
+    constexpr int T = CBB_T, NW = CBB_NW, TS = T / 4;   // TS target slots: slot s, lane group q -> target 4 s + q of the wave
+    constexpr int L = 32 * EPL, CAP = cbb_cap(GP, EPL);  // kept + pending entries per list
+    constexpr int WLN = CBB_WLN;                         // work-list ring (entries; <= 63 pending + 64 new)
+    constexpr int ROWW = CBB_ROWS * 64;                  // words of one dimension's rows in the table
+    constexpr int WAVE_BYTES = cbb_wave_bytes(GP, EPL);
+    constexpr int NA = (CBB_BUF1 - CBB_BUF_BYTES) / WAVE_BYTES;      // waves whose block lies between the two row buffers
     static_assert(WAVE_BYTES % 16 == 0, "wave block alignment");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    static_assert(T % 4 == 0 && TS >= 1, "targets come in fours (one per group of 16 lanes)");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_raw[];
     const int lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // shared: rows [2][2][CBB_ROWS][64] u32 (a pair of dimensions of the current block, double-buffered)
-    // per wave: ro [T][GP] u16 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
+    const int q = lane >> 4, sub = lane & 15;
+    // LDS map: [0, BUF_BYTES) row buffer 0 | blocks of waves 0 .. NA-1 | [BUF1, BUF1 + BUF_BYTES) row buffer 1 | the other
+    // waves' blocks.  A row buffer holds a PAIR of dimensions of the current block (2 x 65 rows x 256 B, padded to whole
+    // 1-KiB DMA pieces); buffer 1 starts at 2^16 so that "which buffer" is one address bit that ORs with row and lane bits.
+    // per wave: ro2 [GP/2][T] uint2 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
     //           wl [WLN] u32 | wl_t [WLN] u8
-    uint32_t *rows = reinterpret_cast<uint32_t *>(smem_raw);
-    unsigned char *wb = smem_raw + 4 * ROWW * 4 + (size_t)wave * WAVE_BYTES;
-    uint16_t *ro = reinterpret_cast<uint16_t *>(wb);
-    float *keys = reinterpret_cast<float *>(ro + T * GP);
+    unsigned char *wb = smem_raw + (wave < NA ? CBB_BUF_BYTES + wave * WAVE_BYTES : CBB_BUF1 + CBB_BUF_BYTES + (wave - NA) * WAVE_BYTES);
+    uint2 *ro2 = reinterpret_cast<uint2 *>(wb);
+    float *keys = reinterpret_cast<float *>(ro2 + (GP / 2) * T);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
     float *tau = reinterpret_cast<float *>(idxs + T * CAP);
     uint32_t *tidx = reinterpret_cast<uint32_t *>(tau + T);
@@ -185,6 +236,9 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     uint32_t *thr_l = reinterpret_cast<uint32_t *>(cnt + T);
     uint32_t *wl = thr_l + T;
     unsigned char *wl_t = reinterpret_cast<unsigned char *>(wl + WLN);
+    // LDS addresses below are byte offsets from the start of the dynamic segment, which IS LDS address 0: this kernel has no
+    // static LDS (cbb_launch_one checks hipFuncGetAttributes once) -- going through the pointer costs a v_add per row read.
+    const uint32_t ro2_off = (uint32_t)(wb - smem_raw);
 
     const int S = gridDim.y;
     const int split = blockIdx.y;
@@ -200,15 +254,29 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
         return need < 0.0f ? 0u : (uint32_t)(int)floorf(need) + 1u;
     };
     for (int e = lane; e < T; e += 64) { tau[e] = __builtin_inff(); tidx[e] = 0xFFFFFFFFu; cnt[e] = 0; thr_l[e] = 0u; }
-    for (int e = lane; e < T * GP; e += 64) {
-        const int64_t row = row0 + e / GP;
-        ro[e] = row < m ? rowoff[row * GP + e % GP] : (uint16_t)0;
+    // ro2[dp][t] = the four row ADDRESSES inside a row buffer (16 bits each) of target t in dimensions 2 dp, 2 dp + 1:
+    // x = lo | hi << 16 of the first, y of the second.  rowoff holds the cumulative row numbers b(lo) | (b(hi) + 1) << 8
+    // per dimension (0 | 0 for padding): cumulative row r >= 1 is stored row r - 1 of its dimension's half of the buffer,
+    // cumulative row 0 (the empty set) is the zero row behind the pair.
+    auto row_addr = [](uint32_t r, uint32_t half) -> uint32_t {
+        return r ? (r - 1u) * 256u + half * (uint32_t)CBB_DIM_BYTES : (uint32_t)CBB_ZERO_OFF;
+    };
+    for (int e = lane; e < (GP / 2) * T; e += 64) {
+        const int dp = e / T, t = e - dp * T;
+        const int64_t row = row0 + t;
+        uint32_t xa = 0u, xc = 0u;
+        if (row < m) { xa = rowoff[row * GP + 2 * dp]; xc = rowoff[row * GP + 2 * dp + 1]; }
+        ro2[e] = make_uint2(row_addr(xa & 0xFFu, 0u) | (row_addr(xa >> 8, 0u) << 16), row_addr(xc & 0xFFu, 1u) | (row_addr(xc >> 8, 1u) << 16));
+    }
+    if (wave == 0) {             // the zero rows of both buffers (the DMA never touches them)
+        *reinterpret_cast<uint32_t *>(smem_raw + CBB_ZERO_OFF + lane * 4) = 0u;
+        *reinterpret_cast<uint32_t *>(smem_raw + CBB_BUF1 + CBB_ZERO_OFF + lane * 4) = 0u;
     }
     const float below_plateau = __uint_as_float(__float_as_uint(plateau) - 1u);
     int wl_head = 0, wl_n = 0;                               // wave-uniform ring state
 
     // fp32 lower bound of `nb` (<= 64) work-list pairs, one per lane, then list insertion (canberra_f32.hip: drain);
-    // the target's packed (x, thr) row comes from global memory here (rare: 7e-3 of the pairs).  A list accepts
+    // the target's packed (x, thr) row comes from global memory here (rare: 3e-3 of the pairs).  A list accepts
     // (key, j) < (tau, tidx) lexicographically: arrival order does not matter (header).
     auto drain = [&](int nb) {
         const bool act = lane < nb;
@@ -234,10 +302,10 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                 const float ad = fabsf(xs_[k] - ys_[k]);
                 const float nlb = fmaxf(__builtin_fmaf(s, -2.5e-07f, ad), 0.0f);
                 const float den = __builtin_fmaf(s, 1.00000072f, 0.01000002f);
-                const float q = nlb * __builtin_amdgcn_rcpf(den);
+                const float qq = nlb * __builtin_amdgcn_rcpf(den);
                 const bool out = ad >= th_[k];
                 no_p += out ? 1 : 0;
-                lb += out ? 1.0f : q;
+                lb += out ? 1.0f : qq;
             }
         }
         const float key = (no_p == g) ? plateau : fminf(lb - slack, below_plateau);
@@ -277,145 +345,167 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     const int64_t b_begin = split * blocks_per_split;
     int64_t b_end = b_begin + blocks_per_split;
     if (b_end > n_blocks) b_end = n_blocks;
-    // The rows of dimensions 2 dp, 2 dp + 1 of block blk (a PAIR of dimensions per step: one carry-save step serves
-    // both), staged by the whole workgroup through registers into the LDS buffer the previous step has finished with:
-    // the next pair is fetched before this one is counted and written behind the count; ONE barrier per step.
-    // g odd: the last pair's second half is whatever follows in the table, with every target's rows (0, 0).
-    constexpr int PIECES = 2 * ROWW / 4;                     // sixteen-byte pieces of a pair
-    constexpr int NST = (PIECES + 64 * NW - 1) / (64 * NW);  // per thread
-    static_assert(NST <= 6, "staging registers");
-    uint4 st0, st1, st2, st3, st4, st5;                      // (scalars, not an array: an array captured by the lambdas went to scratch)
-    st0 = st1 = st2 = st3 = st4 = st5 = make_uint4(0u, 0u, 0u, 0u);
-    const int tid = (int)threadIdx.x;
+    // The rows of dimensions 2 dp, 2 dp + 1 of block blk -- contiguous in the table, 32 KiB -- go to the row buffer the
+    // previous step has finished with as 32 LDS-DMA pieces of 1 KiB (wave w issues pieces w and w + 16): requested at the top
+    // of a step, waited for (every wave for its own pieces) in front of the step's ONE barrier.
+    // g odd: the last pair's second half is whatever follows in the table, with every target's rows (0, 0): an empty mask.
+    // The fetch stream is its own little state machine in scalar registers (the pairs are visited in table order): fsrc =
+    // this wave's first piece of the next pair to fetch, fdp its pair number inside its block, fleft the pairs still to fetch.
     const int npair = (g + 1) / 2;
-    auto fetch = [&](int64_t blk, int dp) {
-        // (both dimensions of a pair are contiguous in the table; an odd g reads one dimension past the block's last --
-        // the next block's first, or the table's slack dimension behind the very last block)
-        const uint4 *src = reinterpret_cast<const uint4 *>(tab + ((size_t)blk * g + 2 * dp) * ROWW);
-        auto ld = [&](int i) { const int pc = tid + i * 64 * NW; return src[pc < PIECES ? pc : PIECES - 1]; };
-        st0 = ld(0);
-        if constexpr (NST > 1) st1 = ld(1);
-        if constexpr (NST > 2) st2 = ld(2);
-        if constexpr (NST > 3) st3 = ld(3);
-        if constexpr (NST > 4) st4 = ld(4);
-        if constexpr (NST > 5) st5 = ld(5);
+    const unsigned char *fsrc = reinterpret_cast<const unsigned char *>(tab) + ((size_t)b_begin * g * ROWW) * 4 + wave * 1024;
+    int fdp = 0;
+    int fleft = b_begin < b_end ? (int)(b_end - b_begin) * npair : 0;       // (< 2^31: a split has < 2^26 blocks of <= 32 pairs)
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto fetch = [&](int buf) {
+        if (fleft <= 0) return;
+        --fleft;
+        const uint32_t dst = ((uint32_t)buf << 16) + (uint32_t)wave * 1024u;
+        cbb_glds16(fsrc, lane_off, dst);
+        cbb_glds16(fsrc + NW * 1024, lane_off, dst + (uint32_t)NW * 1024u);
+        fsrc += CBB_PAIR_BYTES;
+        if (++fdp == npair) {                                // the next pair opens the next block: an odd g shares its last
+            fdp = 0;                                         // pair's second half with it
+            if (g & 1) fsrc -= CBB_DIM_BYTES;
+        }
     };
-    auto commit = [&](int buf) {
-        uint4 *dst = reinterpret_cast<uint4 *>(rows + buf * 2 * ROWW);
-        auto wr = [&](int i, const uint4 &v) { const int pc = tid + i * 64 * NW; if (pc < PIECES) dst[pc] = v; };
-        wr(0, st0);
-        if constexpr (NST > 1) wr(1, st1);
-        if constexpr (NST > 2) wr(2, st2);
-        if constexpr (NST > 3) wr(3, st3);
-        if constexpr (NST > 4) wr(4, st4);
-        if constexpr (NST > 5) wr(5, st5);
-    };
-    if (b_begin < b_end) {
-        fetch(b_begin, 0);
-        commit(0);
-    }
+    fetch(0);
+    cbb_dma_wait();
     __syncthreads();
     int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
-        const uint32_t vmask = vbits[blk * 64 + lane];
-        uint32_t pl[T][6];                                   // bit-sliced counters: pl[t][b] = bit b of the 32 counts
+        uint32_t pl[TS][4][6];                               // bit-sliced counters: pl[s][w][b] = bit b of the 32 counts of word w
+        uint32_t c2a[TS][4], c4a[TS][4];                     // carries waiting for their partner (weight 2, weight 4)
 #pragma unroll
-        for (int t = 0; t < T; ++t)
+        for (int s = 0; s < TS; ++s)
 #pragma unroll
-            for (int b = 0; b < 6; ++b) pl[t][b] = 0u;
-        // Steps come in twos (round 3): the carries out of the lowest plane of two consecutive steps (weight 2 each) wait in a
-        // register and enter plane 1 TOGETHER through a second 3:2 compressor, and only its carry (weight 4) ripples through
-        // planes 2..5 -- 14 instructions per two steps and target instead of 24 (MODE 1: first of two, 2: second, 0: a
-        // single step with the full ripple, the last one of an odd number).
-        // One straight-line copy of the step per role, no lambdas around the plane arrays (captured arrays went to scratch):
-        // STASH = first of two (the weight-2 carry waits in c1a), otherwise it combines (a lone last step combines with 0).
-        uint32_t c1a[T];
-#define CBB_STEP(DP, STASH)                                                                                              \
-        {                                                                                                                \
-            const int dp_ = (DP);                                                                                        \
-            const bool more = dp_ + 1 < npair || blk + 1 < b_end;                                                        \
-            if (more) fetch(dp_ + 1 < npair ? blk : blk + 1, dp_ + 1 < npair ? dp_ + 1 : 0);                             \
-            const unsigned char *rb = reinterpret_cast<const unsigned char *>(rows + buf * 2 * ROWW + lane);            \
-            const uint32_t myro = *reinterpret_cast<const uint32_t *>(ro + (lane & (T - 1)) * GP + 2 * dp_);             \
-            _Pragma("unroll") for (int t0 = 0; t0 < T; t0 += TB) {                                                       \
-                uint32_t m0[TB], m1[TB];                                                                                 \
-                _Pragma("unroll") for (int i = 0; i < TB; ++i) {                                                         \
-                    const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane((int)myro, t0 + i);                          \
-                    m0[i] = *reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFF00u))) &                                 \
-                            ~*reinterpret_cast<const uint32_t *>(rb + ((r4 & 0xFFu) << 8));                              \
-                    m1[i] = *reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 16) & 0xFF00u)) &                \
-                            ~*reinterpret_cast<const uint32_t *>(rb + ROWW * 4 + ((r4 >> 8) & 0xFF00u));                 \
-                }                                                                                                        \
-                _Pragma("unroll") for (int i = 0; i < TB; ++i) {                                                         \
-                    const int t = t0 + i;                                                                                \
-                    uint32_t c = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0xE8);                              \
-                    pl[t][0] = __builtin_amdgcn_bitop3_b32(pl[t][0], m0[i], m1[i], 0x96);                                \
-                    if (STASH) {                                                                                         \
-                        c1a[t] = c;                                                                                      \
-                    } else {                                                                                             \
-                        const uint32_t c4 = __builtin_amdgcn_bitop3_b32(pl[t][1], c1a[t], c, 0xE8);                      \
-                        pl[t][1] = __builtin_amdgcn_bitop3_b32(pl[t][1], c1a[t], c, 0x96);                               \
-                        c = c4;                                                                                          \
-                        _Pragma("unroll") for (int b = 2; b < 6; ++b) {                                                  \
-                            const uint32_t carry = pl[t][b] & c;                                                         \
-                            pl[t][b] ^= c;                                                                               \
-                            c = carry;                                                                                   \
-                        }                                                                                                \
-                    }                                                                                                    \
-                }                                                                                                        \
-            }                                                                                                            \
-            if (more) commit(buf ^ 1);                                                                                   \
-            __syncthreads();                                                                                             \
-            buf ^= 1;                                                                                                    \
-        }
-        // ONE LDS read hands the pair's row offsets of all T targets to the wave (lane t holds target t's two words;
-        // v_readlane then makes them scalars) -- a read + wait per target made the step a chain of LDS latencies; all the row
-        // reads of a batch of TB targets fly together.  (An odd g: the second half of the last pair is a padding
-        // dimension's (0, 0): the mask is x & ~x = 0.)
-        for (int dp0 = 0; dp0 < npair; dp0 += 2) {
-            const bool lone = dp0 + 1 >= npair;
-            if (!lone) CBB_STEP(dp0, true)
-            else {
+            for (int w = 0; w < 4; ++w) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) c1a[t] = 0u;
+                for (int b = 0; b < 6; ++b) pl[s][w][b] = 0u;
+                c2a[s][w] = c4a[s][w] = 0u;
             }
-            CBB_STEP(lone ? dp0 : dp0 + 1, false)
+        // One step = one pair of dimensions.  ROLE: 0 / 2 first of two (the weight-2 carry waits), 1 second of two and first
+        // of four (the weight-4 carry waits), 3 last of four (weight-8 carry ripples through planes 3..5), 5 second of two at
+        // the end of an odd number of pairs-of-steps (the weight-4 carry ripples through planes 2..5), 4 a lone last step.
+#define CBB_STEP(DP, ROLE)                                                                                                   \
+        {                                                                                                                    \
+            const int dp_ = (DP);                                                                                            \
+            fetch(buf ^ 1);                                                                                                  \
+            const uint32_t lb = (uint32_t)sub * 16u | ((uint32_t)buf << 16);      /* row | lane | buffer bits never overlap */  \
+            _Pragma("unroll") for (int s = 0; s < TS; ++s) {                                                                 \
+                const cbb_u32x2 r = *(cbb_lds_u2 *)(uintptr_t)(ro2_off + (uint32_t)((dp_ * T + 4 * s + q) * 8));                 \
+                const cbb_u32x4 lA = *(cbb_lds_u4 *)(uintptr_t)((r.x & 0xFFFFu) | lb);                                           \
+                const cbb_u32x4 hA = *(cbb_lds_u4 *)(uintptr_t)((r.x >> 16) | lb);                                               \
+                const cbb_u32x4 lB = *(cbb_lds_u4 *)(uintptr_t)((r.y & 0xFFFFu) | lb);                                           \
+                const cbb_u32x4 hB = *(cbb_lds_u4 *)(uintptr_t)((r.y >> 16) | lb);                                               \
+                const uint32_t la_[4] = {lA.x, lA.y, lA.z, lA.w}, ha_[4] = {hA.x, hA.y, hA.z, hA.w};                         \
+                const uint32_t lb_[4] = {lB.x, lB.y, lB.z, lB.w}, hb_[4] = {hB.x, hB.y, hB.z, hB.w};                         \
+                _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                              \
+                    const uint32_t m0 = ha_[w] & ~la_[w], m1 = hb_[w] & ~lb_[w];                                             \
+                    uint32_t c = __builtin_amdgcn_bitop3_b32(pl[s][w][0], m0, m1, 0xE8);                                     \
+                    pl[s][w][0] = __builtin_amdgcn_bitop3_b32(pl[s][w][0], m0, m1, 0x96);                                    \
+                    if ((ROLE) == 0 || (ROLE) == 2) {                                                                        \
+                        c2a[s][w] = c;                                                                                       \
+                    } else if ((ROLE) == 4) {                                                                                \
+                        _Pragma("unroll") for (int b = 1; b < 6; ++b) {                                                      \
+                            const uint32_t carry = pl[s][w][b] & c;                                                          \
+                            pl[s][w][b] ^= c;                                                                                \
+                            c = carry;                                                                                       \
+                        }                                                                                                    \
+                    } else {                                                                                                 \
+                        uint32_t c4 = __builtin_amdgcn_bitop3_b32(pl[s][w][1], c2a[s][w], c, 0xE8);                          \
+                        pl[s][w][1] = __builtin_amdgcn_bitop3_b32(pl[s][w][1], c2a[s][w], c, 0x96);                          \
+                        if ((ROLE) == 1) {                                                                                   \
+                            c4a[s][w] = c4;                                                                                  \
+                        } else {                                                                                             \
+                            int b0 = 2;                                                                                      \
+                            if ((ROLE) == 3) {                                                                               \
+                                const uint32_t c8 = __builtin_amdgcn_bitop3_b32(pl[s][w][2], c4a[s][w], c4, 0xE8);           \
+                                pl[s][w][2] = __builtin_amdgcn_bitop3_b32(pl[s][w][2], c4a[s][w], c4, 0x96);                 \
+                                c4 = c8;                                                                                     \
+                                b0 = 3;                                                                                      \
+                            }                                                                                                \
+                            _Pragma("unroll") for (int b = 2; b < 6; ++b) {                                                  \
+                                if (b >= b0) {                                                                               \
+                                    const uint32_t carry = pl[s][w][b] & c4;                                                 \
+                                    pl[s][w][b] ^= c4;                                                                       \
+                                    c4 = carry;                                                                              \
+                                }                                                                                            \
+                            }                                                                                                \
+                        }                                                                                                    \
+                    }                                                                                                        \
+                }                                                                                                            \
+                /* the step's results are materialised HERE: hipcc otherwise sinks the whole counter update of the first three  \
+                   steps of a cycle into the fourth (their values are only read there), holding 3 x 32 mask registers: spills */  \
+                _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                              \
+                    asm volatile("" : "+v"(pl[s][w][0]));                                                                    \
+                    if ((ROLE) == 0 || (ROLE) == 2) asm volatile("" : "+v"(c2a[s][w]));                                      \
+                    else asm volatile("" : "+v"(pl[s][w][1]));                                                               \
+                    if ((ROLE) == 1) asm volatile("" : "+v"(c4a[s][w]));                                                     \
+                    if ((ROLE) >= 3) { _Pragma("unroll") for (int b = 2; b < 6; ++b) asm volatile("" : "+v"(pl[s][w][b])); }  \
+                }                                                                                                            \
+                __builtin_amdgcn_sched_barrier(0);      /* one slot's rows at a time: 16 registers of reads in flight, not 32 */ \
+            }                                                                                                                \
+            cbb_dma_wait();                                                                                                  \
+            __syncthreads();                                                                                                 \
+            buf ^= 1;                                                                                                        \
         }
+        int dp0 = 0;
+        for (; dp0 + 4 <= npair; dp0 += 4) {
+            CBB_STEP(dp0, 0)
+            CBB_STEP(dp0 + 1, 1)
+            CBB_STEP(dp0 + 2, 2)
+            CBB_STEP(dp0 + 3, 3)
+        }
+        if (dp0 + 2 <= npair) {
+            CBB_STEP(dp0, 0)
+            CBB_STEP(dp0 + 1, 5)
+            dp0 += 2;
+        }
+        if (dp0 < npair) CBB_STEP(dp0, 4)
 #undef CBB_STEP
-        // inw >= thr ?  bit-sliced comparator per target (all T unrolled: the planes are registers), then the survivors
-        // into the ring, target by target
-        uint32_t gev[T];
+        // inw >= thr ?  bit-sliced comparator per (slot, word) -- the threshold is the lane group's target's --, then the
+        // survivors into the ring, slot by slot and word by word
+        uint32_t gev[TS][4];
+        const uint4 vmask = reinterpret_cast<const uint4 *>(vbits)[blk * 16 + sub];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const uint32_t thr_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_l[t]);
-            uint32_t gt = 0u, eq = 0xFFFFFFFFu;
+        for (int s = 0; s < TS; ++s) {
+            const uint32_t thr_in = thr_l[4 * s + q];
+            uint32_t tb[6];
 #pragma unroll
-            for (int b = 5; b >= 0; --b) {                       // (branch-free: the threshold's bit selects per plane)
-                const uint32_t tb = ((thr_in >> b) & 1u) ? 0xFFFFFFFFu : 0u;
-                gt |= eq & pl[t][b] & ~tb;
-                eq &= ~(pl[t][b] ^ tb);
-            }
-            gev[t] = thr_in < 64u ? ((gt | eq) & vmask) : 0u;
-        }
-#pragma unroll 1
-        for (int t = 0; t < t_cnt; ++t) {
-            uint32_t ge = gev[0];
+            for (int b = 0; b < 6; ++b) tb[b] = (uint32_t)__builtin_amdgcn_sbfe((int)thr_in, b, 1);       // all ones where bit b is set
+            const uint32_t vm_[4] = {vmask.x, vmask.y, vmask.z, vmask.w};
 #pragma unroll
-            for (int tt = 1; tt < T; ++tt) ge = (t == tt) ? gev[tt] : ge;
-            uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
-            while (anyb != 0) {                                  // every lane with survivors hands over its lowest one
-                const bool has = ge != 0u;
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
-                if (has) {
-                    const int r = __builtin_ctz(ge);
-                    const int slot = (wl_head + wl_n + rank) & (WLN - 1);
-                    wl[slot] = (uint32_t)(blk * CBB_BLK + lane * 32 + r);
-                    wl_t[slot] = (unsigned char)t;
-                    ge &= ge - 1u;
+            for (int w = 0; w < 4; ++w) {
+                uint32_t gt = 0u, eq = 0xFFFFFFFFu;
+#pragma unroll
+                for (int b = 5; b >= 0; --b) {
+                    gt |= eq & pl[s][w][b] & ~tb[b];
+                    eq &= ~(pl[s][w][b] ^ tb[b]);
                 }
-                wl_n += __popcll(anyb);
-                while (wl_n >= 64) drain(64);
-                anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
+                gev[s][w] = thr_in < 64u ? ((gt | eq) & vm_[w]) : 0u;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < TS; ++s) {
+            const int t_mine = 4 * s + q;                        // this lane group's target in slot s
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                uint32_t ge = t_mine < t_cnt ? gev[s][w] : 0u;
+                uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
+                while (anyb != 0) {                              // every lane with survivors hands over its lowest one
+                    const bool has = ge != 0u;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
+                    if (has) {
+                        const int r = __builtin_ctz(ge);
+                        const int slot = (wl_head + wl_n + rank) & (WLN - 1);
+                        wl[slot] = (uint32_t)(blk * CBB_BLK + sub * 128 + w * 32 + r);
+                        wl_t[slot] = (unsigned char)t_mine;
+                        ge &= ge - 1u;
+                    }
+                    wl_n += __popcll(anyb);
+                    while (wl_n >= 64) drain(64);
+                    anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
+                }
             }
         }
     }
@@ -469,16 +559,24 @@ static hipError_t cbb_launch_one(const float *xq, const uint16_t *rowoff, int64_
                                  const uint32_t *vbits, int64_t n, int g, int S, uint32_t *cand_idx, float *cand_tau,
                                  hipStream_t st)
 {
-    constexpr int L = 32 * EPL, CAP = L + 16 * EPL;
     const int64_t n_blocks = (n + CBB_BLK - 1) / CBB_BLK;
     const int64_t bps = (n_blocks + S - 1) / S;
     float slack, plateau;
     cbf_constants(g, &slack, &plateau);
-    constexpr size_t lds = (size_t)4 * CBB_ROWS * 64 * 4 + (size_t)CBB_NW * (CBB_T * GP * 2 + CBB_T * CAP * 8 + CBB_T * 16 + 256 * 5);
+    constexpr size_t lds = cbb_lds_bytes(GP, EPL);
     static_assert(lds <= 163840, "LDS budget");
     auto kern = &cbb_filter_kernel<GP, EPL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    {   // the kernel addresses its dynamic LDS segment from 0: it must not have a static one
+        static int static_lds = -1;
+        if (static_lds < 0) {
+            hipFuncAttributes fa;
+            if ((e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern))) != hipSuccess) return e;
+            static_lds = (int)fa.sharedSizeBytes;
+        }
+        if (static_lds != 0) return hipErrorInvalidConfiguration;
+    }
     const int rpw = CBB_T * CBB_NW;
     dim3 grid((unsigned)((m + rpw - 1) / rpw), S), block(64 * CBB_NW);
     hipLaunchKernelGGL(kern, grid, block, lds, st, reinterpret_cast<const float2 *>(xq), rowoff, m, yrow, tab, vbits, n, g,

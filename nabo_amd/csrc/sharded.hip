@@ -42,9 +42,15 @@
 //     (nabo_comm_set_timeout, NABO_COMM_TIMEOUT_S, default 600 s), the loopback barrier is a timed condition wait;
 //   * a shard with fewer than k' references takes part with absent entries (-1) instead of failing its local query.
 #include <dlfcn.h>
+#ifdef NABO_SHARDED_HOST
+// tests/host_shim: this file compiled with g++ against host memory, so that a box WITHOUT a GPU runs the compiled control
+// flow of the protocol below (tests/test_sharded_host.py); the product build never defines it
+#include "hip_shim.h"
+#else
 #include <hip/hip_runtime.h>
-#include <pthread.h>
 #include <rccl/rccl.h>
+#endif
+#include <pthread.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -95,6 +101,7 @@ struct Rccl {
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
@@ -132,6 +139,7 @@ int load_rccl()
         NABO_SYM(CommInitAll, "ncclCommInitAll");
         NABO_SYM(CommDestroy, "ncclCommDestroy");
         NABO_SYM(CommAbort, "ncclCommAbort");
+        NABO_SYM(CommCount, "ncclCommCount");
         NABO_SYM(CommGetAsyncError, "ncclCommGetAsyncError");
         NABO_SYM(AllReduce, "ncclAllReduce");
         NABO_SYM(AllGather, "ncclAllGather");
@@ -733,6 +741,19 @@ int nabo_comm_destroy(nabo_comm *c)
 
 int nabo_comm_rank(const nabo_comm *c) { return c ? c->rank : -1; }
 int nabo_comm_world(const nabo_comm *c) { return c ? c->world : -1; }
+
+int nabo_comm_transport_ranks(nabo_comm *c)
+{
+    if (!c) return api_fail(NABO_E_INVALID, "NULL communicator");
+    if (c->aborted.load()) return comm_dead(c);
+    if (c->kind != 0) return c->hub ? c->hub->n : 1;
+    int count = -1;
+    pthread_mutex_lock(&c->nccl_lock);
+    const ncclResult_t r = (c->nccl && !c->nccl_dead) ? g_rccl.CommCount(c->nccl, &count) : ncclSuccess;
+    pthread_mutex_unlock(&c->nccl_lock);
+    if (r != ncclSuccess || count < 0) return api_fail(NABO_E_COMM, "ncclCommCount failed");
+    return count;
+}
 
 int nabo_comm_abort(nabo_comm *c)
 {

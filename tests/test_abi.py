@@ -130,3 +130,38 @@ def test_inline_assembly_mfma_kernels_keep_accumulators_out_of_agprs():
     assert seen == 5, seen        # two steps: geometries A, B, C; four steps: A, C
     for m in re.finditer(r"\.name:\s+(_ZN4nabo15l2c_topk_kernel\w+)\n(?:.*\n){1,12}?\s+\.vgpr_spill_count:\s+(\d+)", asm):
         assert int(m.group(2)) == 0, m.group(0)
+    # ... and, register by register (round-3 advisory): hipcc brackets inline assembly with ;;#ASMSTART / ;;#ASMEND, so the
+    # destination quads of the hand-issued MFMAs are known exactly.  No instruction hipcc itself placed -- a v_mov, a spill
+    # copy, a load, anything outside an assembly statement -- may read or write one of them within 16 instruction slots of
+    # the MFMA that writes it (12 wait states for this shape; s_nop N counts N + 1).  A toolchain update that starts to
+    # touch accumulators right behind the statements fails HERE, on the CPU box, not as wrong neighbours on the GPU.
+    def regs(tok):
+        out = set()
+        for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", tok):
+            out.update(range(int(a), int(b) + 1))
+        out.update(int(a) for a in re.findall(r"\bv(\d+)\b", tok))
+        return out
+    checked = 0
+    for m in re.finditer(r"^(_ZN4nabo15l2c_topk_kernelILi([24])E\w+):[^\n]*\n(.*?)s_endpgm", asm, re.S | re.M):
+        name, body = m.group(1), m.group(3)
+        in_asm, live = False, []                              # live: [registers of an asm MFMA's destination, its age]
+        for line in body.split("\n"):
+            t = line.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not t or t.startswith(";") or re.match(r"^\.?\w+:", t):
+                continue
+            age = int(t.split()[1]) + 1 if t.startswith("s_nop") else 1
+            if not in_asm:
+                used = regs(t.split(";")[0])
+                for dst, a in live:
+                    assert not (used & dst), (name, t, sorted(dst), a)
+                checked += 1
+            live = [[d, a + age] for d, a in live if a + age <= 16]
+            if in_asm and t.startswith("v_mfma"):
+                live.append([regs(t.split(",")[0]), 0])
+    assert checked > 1000

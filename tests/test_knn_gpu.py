@@ -1157,7 +1157,8 @@ def test_row_pass_record_names_the_pass_that_answered_each_row(gpu_lib, monkeypa
     oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
     _check(gi, gd, oi, od)
     assert int((rp >= 1).sum()) == st["seeded_pass_rows"] > 0 and int((rp >= 2).sum()) == st["second_pass_rows"]
-    assert int((rp == 4).sum()) == st["fallback_rows"] and (rp[:1500] == 0).mean() > 0.9
+    assert int((rp == 4).sum()) == st["fallback_rows"]
+    assert {1, 2} <= set(np.unique(rp).tolist()), "the far-away tight cluster sends rows past the first pass and the seeded one"
     monkeypatch.setenv("NABO_L2_MODE", "f16x3")
     ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
     monkeypatch.delenv("NABO_L2_MODE")
