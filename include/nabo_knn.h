@@ -87,6 +87,17 @@ typedef struct nabo_index nabo_index;
 int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g,
                       int32_t metric, double dist_factor, int64_t ref_index_base);
 int nabo_index_destroy(nabo_index *ix);
+/* Tuning options of ONE index (tests drive rows down every link of the pass chain with them; A/B tools cut launches
+ * differently).  Every setting returns the SAME BITS -- an option chooses how a launch is cut or which filter pass answers a
+ * row, never what the answer is (the reference has one float64 path, nabo/_mapping.py:16-45).  Names: "splits" (reference
+ * splits of a filter launch, 0 = cost model), "tail_split", "lkeep" (kept list entries of the first pass), "coarse_slack",
+ * "cand_slack", "seeded_pass", "coarse_adapt", "wide_retry", "refine_overlap" (0 / 1: links of the pass chain), "prepass"
+ * (tournament seeds, percent of the planned length; 0 = off), "l2c_geo" (0 = A, 1 = B, 2 = C), "l2_r1", "split_refs_max",
+ * "cosine_centre" (takes effect at the next set_ref).  Unknown names: NABO_E_INVALID.
+ * The library reads TWO environment variables, once, in nabo_index_create: NABO_L2_MODE = f32 | f16x3 (which Euclidean /
+ * cosine filter runs first; default: the one-product pass) and NABO_CANBERRA_MODE = exact | swar | bits; the sharded
+ * transport reads NABO_COMM_TIMEOUT_S and NABO_RCCL_LIB. */
+int nabo_index_set_option(nabo_index *ix, const char *name, int64_t value);
 
 /* Upload / adopt the reference rows.  Y is [n_ref,g] float64 row-major; when
  * y_on_device != 0 it is a device pointer on the index's device and is BORROWED (must
@@ -146,6 +157,20 @@ int nabo_index_last_passes(const nabo_index *ix, int64_t rows[3]);
 #define NABO_PASS_EXACT       4   /* the exact float64 kernels (brute force)                                          */
 #define NABO_PASS_CANBERRA    5   /* the modified-Canberra filter (count + fp32 lower bound + float64 refine)         */
 int nabo_index_last_row_pass(const nabo_index *ix, uint8_t *out, int64_t m);
+
+/* The launch plan of a Euclidean / cosine query WITHOUT an index or a device: what nabo_index_query (n_cand = 0) or
+ * nabo_index_query_candidates (n_cand > 0) would launch first for this shape on a part with n_cu compute units -- a pure
+ * function of its arguments (l2_mode: what NABO_L2_MODE would hold, NULL = default; options: "name=value,..." of
+ * nabo_index_set_option, NULL = defaults).  out: [0] NABO_PASS_* of the first filter, [1] geometry of the one-product kernel
+ * (-1: another kernel), [2] target rows per workgroup, [3] / [4] workgroups (x) of the main / tail launch, [5] / [6] their
+ * reference splits, [7] kept list entries, [8] emitted list length, [9] reference tiles per split, [10] / [11] tournament
+ * tiles and tiles per group (0: no tournament), [12] workgroups resident at once, [13] workgroups launched in all,
+ * [14] padded target rows, [15] operand steps of 16 slots.  kernel (optional): the kernel's name as nabo_index_last_kernel
+ * reports it. */
+#define NABO_PLAN_FIELDS 16
+int nabo_query_plan(int64_t n_ref, int32_t g, int32_t metric, int64_t m, int32_t k, int32_t drop_first, int32_t n_cand,
+                    int32_t n_cu, const char *l2_mode, const char *options, int64_t out[NABO_PLAN_FIELDS], char *kernel,
+                    size_t kernel_len);
 
 /* ---- shard merge (reference rows sharded over GPUs) ---------------
  * parts_idx / parts_dist: [n_parts, m, kp] DEVICE arrays, each row sorted by the canonical

@@ -11,7 +11,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnabo_knn.so")
-SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2h_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "l2s_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "order.hip", "host_graph.hip"]
+SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "host_graph.hip"]
+# kernels of the experiments build only (-DNABO_EXPERIMENTS, tools/ab: measured slower than the product's and kept for A/B runs):
+# the f16x3 split on the 32x32x16 MFMA shape per wave / with LDS-shared tiles, locality-ordered streaming
+EXPERIMENT_SOURCES = ["l2h_topk.hip", "l2s_topk.hip", "order.hip"]
 # per-file extra flags: -fno-honor-nans for the fp32 score kernel (scores are finite or +inf by construction; without it
 # every fminf tree starts with two v_max canonicalisations, and on gfx950 the fp32 MFMA cannot overlap vector-ALU work);
 # (NOT for l2h_topk.hip: its masked / padding cells carry an inf - inf = NaN low part, and the filter relies on NaN
@@ -80,7 +83,7 @@ def build(force=False, verbose=False, extra=None, out=None):
 def _build(force, verbose, extra, objdir):
     os.makedirs(objdir, exist_ok=True)
     jobs, objs = [], []
-    for s in SOURCES:
+    for s in SOURCES + (EXPERIMENT_SOURCES if "-DNABO_EXPERIMENTS" in extra else []):
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         objs.append(obj)

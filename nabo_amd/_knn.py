@@ -27,14 +27,21 @@ def _mask(ref_mask, n):
     return mk, mk.ctypes.data
 
 
-def knn(X, Y, k, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=False, device=0):
+def knn(X, Y, k, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=False, device=0, options=None):
     """First k entries of every order row + their float64 distances (host arrays in/out).
 
-    X [m,g] targets, Y [n,g] references.  Returns (idx int64 [m,k], dist float64 [m,k])."""
+    X [m,g] targets, Y [n,g] references.  Returns (idx int64 [m,k], dist float64 [m,k]).
+    options ({name: value} of nabo_index_set_option): goes through a KnnIndex instead of the one-shot nabo_knn."""
     X, Y = _f64(X, "X"), _f64(Y, "Y")
     if X.shape[1] != Y.shape[1]:
         raise ValueError("ERROR: X and Y must have the same number of components")
     m, n, g = X.shape[0], Y.shape[0], X.shape[1]
+    if options:
+        ix = KnnIndex(n, g, metric=metric, dist_factor=dist_factor, device=device, options=options)
+        try:
+            return ix.set_ref(Y, ref_mask=ref_mask).query(X, k, drop_first=drop_first)
+        finally:
+            ix.close()
     mk, mp = _mask(ref_mask, n)
     idx = np.empty((m, k), dtype=np.int64)
     dist = np.empty((m, k), dtype=np.float64)
@@ -42,6 +49,24 @@ def knn(X, Y, k, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=F
                              mp, int(bool(drop_first)), idx.ctypes.data, dist.ctypes.data, int(device))
     _lib.check(rc)
     return idx, dist
+
+
+PLAN_FIELDS = ("first_pass", "geometry", "rows_per_wg", "workgroups_main", "workgroups_tail", "splits", "splits_tail", "lkeep",
+               "list_len", "tiles_per_split", "tournament_tiles", "tournament_group", "resident_workgroups", "workgroups",
+               "rows_padded", "operand_steps")
+
+
+def query_plan(n_ref, g, m, k, metric=EUCLIDEAN, drop_first=False, n_cand=0, n_cu=256, l2_mode=None, options=None):
+    """What a Euclidean / cosine query of this shape would launch first (nabo_query_plan: no index, no device)."""
+    out = (C.c_int64 * len(PLAN_FIELDS))()
+    kern = C.create_string_buffer(192)
+    opts = ",".join("%s=%d" % (a, int(b)) for a, b in (options or {}).items())
+    _lib.check(_lib.lib().nabo_query_plan(int(n_ref), int(g), int(metric), int(m), int(k), int(bool(drop_first)), int(n_cand),
+                                          int(n_cu), l2_mode.encode() if l2_mode else None, opts.encode() if opts else None,
+                                          out, kern, 192))
+    d = {name: int(out[i]) for i, name in enumerate(PLAN_FIELDS)}
+    d["kernel"] = kern.value.decode("ascii", "replace")
+    return d
 
 
 def pairwise(X, Y, metric=EUCLIDEAN, dist_factor=0.25, device=0):
@@ -61,12 +86,19 @@ class KnnIndex:
 
     `Y` may be a host array or, with `y_device_ptr`, a raw device pointer (borrowed)."""
 
-    def __init__(self, n_ref, g, metric=EUCLIDEAN, dist_factor=0.25, ref_index_base=0, device=0):
+    def __init__(self, n_ref, g, metric=EUCLIDEAN, dist_factor=0.25, ref_index_base=0, device=0, options=None):
+        """options: {name: value} of nabo_index_set_option (tuning / test hooks; every setting returns the same bits)"""
         self._h = C.c_void_p()
         self.n_ref, self.g, self.metric, self.device = int(n_ref), int(g), int(metric), int(device)
         _lib.check(_lib.lib().nabo_index_create(C.byref(self._h), self.device, self.n_ref, self.g, self.metric,
                                                 float(dist_factor), int(ref_index_base)))
         self._keep = None
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
+
+    def set_option(self, name, value):
+        _lib.check(_lib.lib().nabo_index_set_option(self._h, str(name).encode(), int(value)))
+        return self
 
     def set_ref(self, Y=None, ref_mask=None, y_device_ptr=None):
         mk, mp = _mask(ref_mask, self.n_ref)

@@ -20,7 +20,7 @@ _lib = None
 # every symbol include/nabo_knn.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
-    "nabo_index_create", "nabo_index_destroy", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
+    "nabo_index_create", "nabo_index_destroy", "nabo_index_set_option", "nabo_query_plan", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
     "nabo_index_query_candidates",
     "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_index_last_row_pass", "nabo_merge_topk", "nabo_snn_counts", "nabo_pyset_order", "nabo_component_labels", "nabo_group_edges", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize", "nabo_dev_mem_info",
@@ -51,6 +51,8 @@ def lib():
     L.nabo_pairwise.argtypes = [vp, i64, vp, i64, i32, i32, dbl, vp, i32]
     L.nabo_index_create.argtypes = [C.POINTER(vp), i32, i64, i32, i32, dbl, i64]
     L.nabo_index_destroy.argtypes = [vp]
+    L.nabo_index_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.nabo_query_plan.argtypes = [i64, i32, i32, i64, i32, i32, i32, i32, C.c_char_p, C.c_char_p, C.POINTER(i64), C.c_char_p, C.c_size_t]
     L.nabo_index_set_ref.argtypes = [vp, vp, i32, vp]
     L.nabo_index_set_mask.argtypes = [vp, vp]
     L.nabo_index_query.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, i32]
@@ -100,7 +102,7 @@ def so_digest():
 # sources a kernel's counter record depends on (profiles/pmc.json): the kernel, what it includes, the operand packing,
 # the launch logic and the compiler flags
 KERNEL_SOURCES = {
-    "euclid": ["l2c_topk.hip", "l2q_topk.hip", "l2h_topk.hip", "l2s_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "order.hip", "api.hip", "_build.py"],
+    "euclid": ["l2c_topk.hip", "l2q_topk.hip", "topk_lists.h", "knn_common.h", "pack.hip", "api.hip", "_build.py"],
     "canberra": ["canberra_f32.hip", "canberra_bits.hip", "knn_common.h", "api.hip", "_build.py"],
 }
 

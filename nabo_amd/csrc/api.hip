@@ -24,20 +24,15 @@ hipError_t l2_topk_launch(int ksteps, int epl, const float *Xpk, const float *Yp
                           int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                           hipStream_t st);
 void l2_topk_geometry(int ksteps, int epl, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
-// f16x3 variant (l2h_topk.hip)
+// f16 operands of the matrix-pipe filters (pack.hip): K-concatenated tiles, nseg = 3 the f16x3 split, 1 the one-product form
 hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st);
-hipError_t l2h_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
-                           int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
-                           int64_t pad_tile, hipStream_t st);
-void l2h_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
-int l2h_pick_kc(int g);
-// f16x3 variant with K-concatenated operands and reference tiles shared per workgroup through an LDS ring (l2s_topk.hip)
 hipError_t pack_cref_launch(const double *Y, int64_t n, int g, const double *centre, double scale, int kc,
                             int64_t ntiles_total, const uint8_t *mask, unsigned char *out, unsigned int *norm_max_bits,
                             bool layout16, hipStream_t st, const uint32_t *perm = nullptr, int nseg = 3);
 hipError_t pack_cquery_launch(const double *X, int64_t m, int g, const double *centre, double scale, int kc,
                               int64_t ntiles_total, unsigned char *out, double *xnorm, bool layout16, hipStream_t st,
                               const uint32_t *perm = nullptr, int nseg = 3);
+int l2q_pick_kc(int g);
 int l2q_pick_kc1(int g);
 // the one-product first pass (l2c_topk.hip; operands packed with layout16, nseg = 1)
 hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
@@ -50,24 +45,32 @@ hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const uns
                           int64_t rows, int64_t tile_off, int pre_tiles, int gt, int64_t pad_tile, hipStream_t st,
                           int64_t rows_valid, float *tau_out);
 int l2c_pick_kc(int g);
-int l2c_geometry(int kc, int lkeep_want);
-void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
+int l2c_geometry(int kc, int lkeep_want, int pin);
+void l2c_topk_geometry(int kc, int lkeep_want, int pin, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 // the same filter on v_mfma_f32_16x16x32_f16 (l2q_topk.hip; operands packed with layout16)
 hipError_t l2q_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, const int32_t *wave_start = nullptr);
-// locality order of the streamed cells (order.hip)
+#ifdef NABO_EXPERIMENTS
+// kernels of the experiments build only (tools/ab; measured slower than the product's, kept for A/B runs -- DESIGN.md 4.1b-d):
+// the f16x3 split on v_mfma_f32_32x32x16_f16 (l2h_topk.hip), the same with reference tiles shared through an LDS ring
+// (l2s_topk.hip), locality order of the streamed cells (order.hip)
+hipError_t l2h_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
+                           int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
+                           int64_t pad_tile, hipStream_t st);
+void l2h_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 int loc_key_bits(int g);
 hipError_t loc_sort_temp_bytes(int64_t n, int nb, size_t *bytes);
 hipError_t loc_order_launch(const double *V, int64_t n, int g, const double *centre, uint32_t *keys_a, uint32_t *pos_a,
                             uint32_t *keys_sorted, uint32_t *perm, void *temp, size_t temp_bytes, hipStream_t st);
 hipError_t wave_start_launch(const uint32_t *tkeys, int64_t m, int rows_per_wave, const uint32_t *rkeys, int64_t n,
                              int64_t n_waves, int32_t *start, hipStream_t st);
-void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 hipError_t l2s_topk_launch(int kc, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                            int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau, hipStream_t st);
 void l2s_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 int l2s_pick_kc(int g);
+#endif
+void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
 hipError_t pairwise_launch(const double *X, int64_t m, const double *Y, int64_t n, int g, int metric, double f,
                            double *D, hipStream_t st);
 hipError_t refine_launch(const double *X, int64_t row0, int64_t m, const double *Y, int g, const uint32_t *cand_idx,
@@ -216,11 +219,62 @@ int pick_ksteps(int g)
     return -1;
 }
 
-int env_int(const char *name, int dflt)
+// Tuning options of an index (nabo_index_set_option; the defaults are the product's behaviour).  EVERY setting returns the
+// same bits -- an option chooses how a launch is cut or which filter pass answers a row, never what the answer is.  The
+// library reads two environment variables, once, in nabo_index_create: NABO_L2_MODE and NABO_CANBERRA_MODE (which first
+// filter); -DNABO_EXPERIMENTS builds (tools/ab) also take every option below as NABO_OPT_<NAME>.
+struct Options {
+    int splits = 0;            // reference splits of a filter launch (0: the cost model decides)
+    int tail_split = 1;        // the last, partially filled round of workgroups gets its own split count
+    int lkeep = 0;             // kept entries of the first pass's lists (0: k' + 8)
+    int coarse_slack = -1;     // kept entries of the one-product pass beyond k' + 8 (-1: 0 on 32-entry lists, 6 on 64-entry lists)
+    int cand_slack = -1;       // candidate mode on the one-product pass: kept entries beyond the emitted ones (-1: the sharded query's rule)
+    int seeded_pass = 1;       // links of the pass chain: rows the first pass fails go through the seeded one-product pass,
+    int coarse_adapt = 1;      //   a weak one-product bound is remembered until the references change,
+    int wide_retry = 1;        //   rows the 32-entry lists fail get 64-entry lists before the exact kernels
+    int refine_overlap = 1;    // the refine of the main launch's rows runs beside the filter's tail launch
+    int prepass = 100;         // tournament seeds: percent of the planned length (0: lists start from +inf)
+    int l2c_geo = -1;          // pin the one-product kernel's geometry: 0 = A, 1 = B, 2 = C (-1: by list length)
+    int l2_r1 = -1;            // fp32 filter: one row-block per wave (-1 auto, 0 never, 1 always)
+    int split_refs_max = 0;    // lower the 2^25-references-per-split bound (tests see the rule at ordinary sizes)
+    int cosine_centre = 1;     // cosine: centre the unit rows before packing (takes effect at the next set_ref)
+    int coarse_kernel_q = 0;   // experiments: the one-product operands through the l2q kernel
+    int order_flags = 0;       // experiments: locality-ordered streaming (order.hip)
+};
+
+struct OptionName { const char *name; int Options::*field; };
+const OptionName OPTION_NAMES[] = {
+    {"splits", &Options::splits}, {"tail_split", &Options::tail_split}, {"lkeep", &Options::lkeep},
+    {"coarse_slack", &Options::coarse_slack}, {"cand_slack", &Options::cand_slack}, {"seeded_pass", &Options::seeded_pass},
+    {"coarse_adapt", &Options::coarse_adapt}, {"wide_retry", &Options::wide_retry}, {"refine_overlap", &Options::refine_overlap},
+    {"prepass", &Options::prepass}, {"l2c_geo", &Options::l2c_geo}, {"l2_r1", &Options::l2_r1},
+    {"split_refs_max", &Options::split_refs_max}, {"cosine_centre", &Options::cosine_centre},
+    {"coarse_kernel_q", &Options::coarse_kernel_q}, {"order_flags", &Options::order_flags},
+};
+
+bool option_set(Options &o, const char *name, int64_t value)
 {
-    const char *s = getenv(name);
-    return (s && *s) ? atoi(s) : dflt;
+    for (const OptionName &e : OPTION_NAMES)
+        if (strcmp(e.name, name) == 0) {
+            o.*(e.field) = (int)value;
+            return true;
+        }
+    return false;
 }
+
+#ifdef NABO_EXPERIMENTS
+void options_from_env(Options &o)
+{
+    for (const OptionName &e : OPTION_NAMES) {
+        char key[64] = "NABO_OPT_";
+        size_t k = strlen(key);
+        for (const char *c = e.name; *c && k + 1 < sizeof(key); ++c) key[k++] = (char)(*c >= 'a' && *c <= 'z' ? *c - 32 : *c);
+        key[k] = 0;
+        const char *v = getenv(key);
+        if (v && *v) o.*(e.field) = atoi(v);
+    }
+}
+#endif
 
 }  // namespace
 
@@ -287,6 +341,7 @@ struct nabo_index {
     // bit-sliced counting pass (canberra_bits.hip): quantile edges [g][B-1], cumulative bitmaps, valid bits, target row numbers
     DevBuf cbedges, cbtab, cbvalid, cbrow;
     bool cb_bits = false;
+    int cb_mode = 0;              // NABO_CANBERRA_MODE at creation: 0 by size, 1 exact kernel only, 2 SWAR count, 3 bitmaps
 
     // query workspace
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
@@ -307,6 +362,7 @@ struct nabo_index {
     bool wide_retry = false;       // inside the second-chance pass (64-entry lists for the rows the first pass could not certify)
     DevBuf xbuf, xpk, xnorm, cand_idx, cand_tau, cand_idx2, cand_tau2, cand_d, fails, failcnt, oidx, odist, nfound;
     int n_cu = 256;
+    Options opt;
 
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
@@ -332,6 +388,47 @@ void index_set_shard_mode(nabo_index *ix, bool on) { ix->shard_mode = on; }
 void index_set_cand_slack(nabo_index *ix, int s) { ix->cand_slack = s < 0 ? 0 : s; }
 }  // namespace nabo
 
+
+// Which filter kernels serve an index of this shape (n, g, metric are set): decided from the arguments and the mode string
+// alone -- no device state -- so that nabo_query_plan can describe an index that does not exist.
+//   mode (NABO_L2_MODE at nabo_index_create): unset / "f16x1" -- the DEFAULT chain: one-product pass (l2c_topk.hip, g <= 125)
+//   -> seeded one-product pass -> f16x3 split (l2q_topk.hip, g < 64 and k' <= 28) or fp32-MFMA filter (l2_topk.hip) ->
+//   64-entry lists -> exact float64 kernels;  "f16x3": the f16x3 split is the first pass;  "f32": the fp32-MFMA filter is.
+//   (-DNABO_EXPERIMENTS builds also know "f16x3h", "f16x3s", "f16x1h": the 32x32x16 kernels of l2h_topk.hip / l2s_topk.hip.)
+static void index_init_filters(nabo_index *ix, const char *md)
+{
+    const int g = ix->g;
+    ix->mode = 0;
+    ix->kc = ix->kc1 = 0;
+    ix->shared = ix->coarse = ix->order = false;
+    ix->q16 = true;
+    ix->order_flags = 0;
+    ix->ksteps = 0;
+    if (ix->metric == NABO_METRIC_MOD_CANBERRA) return;
+    ix->ksteps = pick_ksteps(g);           // -1: g > NABO_MAX_COMPS, every query takes the exact float64 route
+    const bool f32 = md && strcmp(md, "f32") == 0, f16x3 = md && strncmp(md, "f16x3", 5) == 0;
+    if (ix->ksteps <= 0) return;
+    if (!f32 && nabo::l2q_pick_kc(g) > 0) {
+        ix->mode = 1;                       // an f16x3 kernel exists for this g (g < 64)
+        ix->kc = nabo::l2q_pick_kc(g);
+#ifdef NABO_EXPERIMENTS
+        ix->shared = md && strcmp(md, "f16x3s") == 0 && nabo::l2s_pick_kc(g) == ix->kc;
+        ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0 || strcmp(md, "f16x1h") == 0));
+        // locality order (order.hip; option "order_flags", bit flags: 1 references, 2 targets in key order, 4 home pre-pass):
+        // cuts the list updates by 30 % and the kernel is 20 % SLOWER on it (profiles/r3_order_experiment.txt)
+        ix->order_flags = ix->q16 ? ix->opt.order_flags : 0;
+        ix->order = (ix->order_flags & 1) != 0;
+#endif
+        ix->kc1 = ix->q16 ? nabo::l2c_pick_kc(g) : nabo::l2q_pick_kc1(g);
+        ix->coarse = !ix->shared && ix->kc1 > 0 && !f16x3;
+    } else if (!f32 && !f16x3 && nabo::l2c_pick_kc(g) > 0) {
+        // 64 <= g <= 125: no f16x3 kernel is instantiated, but the one-product operands (g + 3 slots: four steps of 32)
+        // are -- the one-product pass runs first, the fp32-MFMA filter takes the rows it cannot certify
+        ix->kc1 = nabo::l2c_pick_kc(g);
+        ix->coarse = true;
+    }
+}
+
 // Entries of the masked-reference list a row may continue with when it has fewer than k' unmasked references
 // (numpy.ma's NaN fill sorts the ignored references last, by index: nabo/_mapping.py:135-146).  A SHARD must not do
 // that: its masked references would enter the global merge as if they were neighbours (found by the randomised
@@ -353,6 +450,7 @@ static int note_row_pass(nabo_index *ix, const uint32_t *d_rows, int64_t nf, uin
     return NABO_OK;
 }
 
+#ifdef NABO_EXPERIMENTS
 // Locality order of `n` rows of V (order.hip): sorted keys and the permutation, on the index's stream.
 static int order_rows(nabo_index *ix, const double *V, int64_t n, DevBuf &keys, DevBuf &perm)
 {
@@ -366,6 +464,7 @@ static int order_rows(nabo_index *ix, const double *V, int64_t n, DevBuf &keys, 
                                    keys.as<uint32_t>(), perm.as<uint32_t>(), ix->otemp.p, tb, ix->stream));
     return NABO_OK;
 }
+#endif
 
 // Pack the resident references for the fp32-MFMA kernel (want = 0), the f16x3 kernels (1: K-concatenated f16 tiles) or
 // the one-product pass of the l2q kernel (2).
@@ -396,10 +495,12 @@ static int ensure_packed(nabo_index *ix, int want)
         if ((rc = ix->ycpk1.reserve((size_t)ix->ref_tiles_alloc * ix->kc1 * 1024 + 128))) return rc;
         ix->hscale = scale = std::ldexp(1.0, e2 + 12);
         ix->ref_ordered = false;
+#ifdef NABO_EXPERIMENTS
         if (ix->order) {             // (the same keys, hence the same permutation, as the f16x3 operands of the second pass)
             if ((rc = order_rows(ix, ix->dYp, ix->n, ix->rkeys, ix->rperm))) return rc;
             ix->ref_ordered = true;
         }
+#endif
         HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc1,
                                        ix->ref_tiles_alloc, ix->dmask, ix->ycpk1.as<unsigned char>(),
                                        ix->normmax.as<unsigned int>(), ix->q16, st,
@@ -409,10 +510,12 @@ static int ensure_packed(nabo_index *ix, int want)
         // |v| <= 2^12 after scaling (f16 overflows at 65504; targets carry a factor 2)
         ix->hscale = scale = std::ldexp(1.0, e2 + 12);
         ix->ref_ordered = false;
+#ifdef NABO_EXPERIMENTS
         if (ix->order) {
             if ((rc = order_rows(ix, ix->dYp, ix->n, ix->rkeys, ix->rperm))) return rc;
             ix->ref_ordered = true;
         }
+#endif
         HIP_TRY(nabo::pack_cref_launch(ix->dYp, ix->n, ix->g, ix->centre.as<double>(), ix->hscale, ix->kc,
                                        ix->ref_tiles_alloc, ix->dmask, ix->ycpk.as<unsigned char>(),
                                        ix->normmax.as<unsigned int>(), ix->q16, st,
@@ -501,42 +604,14 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
     ix->metric = metric;
     ix->f = dist_factor;
     ix->base = ref_index_base;
-    if (metric != NABO_METRIC_MOD_CANBERRA) {
-        ix->ksteps = pick_ksteps(g);           // -1: g > NABO_MAX_COMPS, every query takes the exact float64 route
-        // Filter kernel: the f16x3 split on the f16 matrix pipe wherever it is instantiated (g < 64; per query also
-        // k + drop_first + 4 <= 32) -- same results, ~2x the fp32-MFMA kernel; NABO_L2_MODE=f32 pins the fp32 kernel,
-        // =f16x3 is the default spelled out.
-        const char *md = getenv("NABO_L2_MODE");
-        // NABO_L2_MODE=f16x3s selects the shared-tile kernel (l2s_topk.hip) where it is instantiated, =f16x3h / unset
-        // the per-wave one (l2h_topk.hip), which measured faster at 1M x 1M
-        if (!(md && strcmp(md, "f32") == 0) && ix->ksteps > 0 && nabo::l2h_pick_kc(g) > 0) {
-            ix->mode = 1;
-            ix->kc = nabo::l2h_pick_kc(g);
-            ix->shared = md && strcmp(md, "f16x3s") == 0 && nabo::l2s_pick_kc(g) == ix->kc;
-            // default: the 16x16x32 MFMA shape (l2q_topk.hip; the chip holds a higher clock on it); =f16x3h pins the
-            // 32x32x16 per-wave kernel, =f16x3s the shared-tile one (both use the 32x32 operand layout)
-            ix->q16 = !(md && (strcmp(md, "f16x3h") == 0 || strcmp(md, "f16x3s") == 0 || strcmp(md, "f16x1h") == 0));
-            // NABO_L2Q_ORDER (bit flags; every setting gives the same results): 1 = references packed in key order,
-            // 2 = targets packed in key order, 4 = home pre-pass of every wave; 0 = caller order, the DEFAULT: key order
-            // cuts the list updates by 30 % and the hit episodes by 70 %, and the kernel is 20 % SLOWER on it -- sorted
-            // operands cost more clock than the hit path they save (order.hip, profiles/r3_order_experiment.txt)
-            ix->order_flags = ix->q16 ? env_int("NABO_L2Q_ORDER", 0) : 0;
-            ix->order = (ix->order_flags & 1) != 0;
-            // DEFAULT first pass: the ONE-PRODUCT filter (hi x hi with the split's error as an operand slot: a rigorous
-            // lower bound of the f16x3 score at 2 / 5 of its matrix work); rows it cannot certify go through the f16x3
-            // pass.  NABO_L2_MODE=f16x3 pins the three-product filter as the first pass, =f16x1 is the default spelled out.
-            ix->kc1 = ix->q16 ? nabo::l2c_pick_kc(g) : nabo::l2q_pick_kc1(g);
-            // (=f16x1h: the one-product pass on the 32x32x16 shape, l2h_topk.hip -- an experiment)
-            ix->coarse = !ix->shared && (ix->order_flags == 0 || ix->q16) && ix->kc1 > 0 &&
-                         !(md && strncmp(md, "f16x3", 5) == 0);
-        } else if (!(md && (strcmp(md, "f32") == 0 || strncmp(md, "f16x3", 5) == 0)) && ix->ksteps > 0 && nabo::l2c_pick_kc(g) > 0) {
-            // 64 <= g <= 125: no f16x3 kernel is instantiated, but the one-product operands (g + 3 slots: four steps of 32)
-            // are -- the one-product pass runs first, the fp32-MFMA filter takes the rows it cannot certify
-            ix->q16 = true;
-            ix->kc1 = nabo::l2c_pick_kc(g);
-            ix->coarse = true;
-        }
+#ifdef NABO_EXPERIMENTS
+    options_from_env(ix->opt);
+#endif
+    {   // NABO_CANBERRA_MODE = exact | swar | bits pins the modified-Canberra path (default: by the size of the reference set)
+        const char *cmode = getenv("NABO_CANBERRA_MODE");
+        ix->cb_mode = !cmode ? 0 : strcmp(cmode, "exact") == 0 ? 1 : strcmp(cmode, "swar") == 0 ? 2 : strcmp(cmode, "bits") == 0 ? 3 : 0;
     }
+    index_init_filters(ix, getenv("NABO_L2_MODE"));
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
         ix->n_cu = cus;
@@ -550,6 +625,23 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
         return fail(NABO_E_HIP, "stream/event creation failed: %s", hipGetErrorString(e));
     }
     *out = ix;
+    return NABO_OK;
+}
+
+int nabo_index_set_option(nabo_index *ix, const char *name, int64_t value)
+{
+    if (!ix || !name) return fail(NABO_E_INVALID, "NULL argument");
+    if (!option_set(ix->opt, name, value)) return fail(NABO_E_INVALID, "unknown option '%s'", name);
+    if (strcmp(name, "order_flags") == 0) {
+#ifdef NABO_EXPERIMENTS
+        ix->order_flags = ix->q16 ? (int)value : 0;
+        ix->order = (ix->order_flags & 1) != 0;
+        ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
+#else
+        ix->opt.order_flags = 0;
+        return fail(NABO_E_UNSUPPORTED, "option '%s' exists in -DNABO_EXPERIMENTS builds only", name);
+#endif
+    }
     return NABO_OK;
 }
 
@@ -598,7 +690,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
             // unit rows of PCA-like data sit in a cap around their mean direction, ||x^ - c|| is a fraction of 1)
             if ((rc = ix->ynbuf.reserve(ybytes))) return rc;
             HIP_TRY(nabo::normalise_rows_launch(ix->dY, ix->n, ix->g, ix->ynbuf.as<double>(), st));
-            if (env_int("NABO_COSINE_CENTRE", 1) != 0)
+            if (ix->opt.cosine_centre != 0)
                 HIP_TRY(nabo::centre_launch(ix->ynbuf.as<double>(), ix->n, ix->g, ix->centre.as<double>(), st));
             else
                 HIP_TRY(hipMemsetAsync(ix->centre.p, 0, (size_t)ix->g * sizeof(double), st));
@@ -615,8 +707,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
         ix->cb_gp = nabo::cbf_pick_gp(ix->g);
         ix->cb_f32 = false;
         ix->cb_bits = false;
-        const char *cmode = getenv("NABO_CANBERRA_MODE");
-        if (ix->cb_gp > 0 && !(cmode && strcmp(cmode, "exact") == 0)) {
+        if (ix->cb_gp > 0 && ix->cb_mode != 1) {
             unsigned int flag = 0;
             if ((rc = ix->ycf.reserve((size_t)chunks * 64 * ix->cb_gp * sizeof(float)))) return rc;      // chunk-major (range check)
             if ((rc = ix->yrow.reserve((size_t)ix->n * ix->cb_gp * sizeof(float)))) return rc;           // row-major (bound pass)
@@ -661,7 +752,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                 // QUANTILE bucket edges from a strided sample of the references (any edges give correct results -- they
                 // only decide how sharp the count is), cumulative bitmaps per block of 2048 references.
                 ix->cb_bits = false;
-                const bool want_bits = cmode ? strcmp(cmode, "bits") == 0 : ix->n >= 128 * 2048;
+                const bool want_bits = ix->cb_mode ? ix->cb_mode == 3 : ix->n >= 128 * 2048;
                 if (want_bits && nabo::cbb_available(G, ix->cb_gp, 1)) {
                     const int B = nabo::cbb_buckets();
                     int64_t ns = ix->n < 2048 ? ix->n : 2048;          // (32 sample values per bucket; the sort is host time inside set_ref)
@@ -712,6 +803,200 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
         ix->packed_f32 = ix->packed_c16 = ix->packed_c1 = false;
         ix->coarse_weak = false;
         if ((rc = ensure_packed(ix, ix->coarse ? 2 : ix->mode == 1 ? 1 : 0))) return rc;
+    }
+    return NABO_OK;
+}
+
+// ---- the launch plan of an Euclidean / cosine filter pass -------------------------------------------------------------------
+// Everything the launch logic decides -- which kernel, in which geometry, how long the lists, how the reference range and the
+// target rows are cut -- from the index's SHAPE and options and the query's shape alone: no device call, no state change.
+// query_body executes it; nabo_query_plan returns it for an index that need not exist (tests/test_host_logic.py checks the
+// rules on the CPU box: >= 256 workgroups whenever m x n allows, list lengths per pass, split bounds).
+struct L2Plan {
+    int epl = 1, L = 32;                 // emitted candidate lists hold L = 32 epl entries
+    bool use_h = false;                  // an f16 kernel runs (one-product or f16x3 operands); false: the fp32-MFMA filter
+    bool use_c = false;                  // experiments: the shared-tile f16x3 kernel
+    bool use_1 = false;                  // one-product operands
+    bool on_l2c = false;                 // ... on the l2c kernel (geo: its geometry)
+    bool r1 = false;                     // fp32 filter: one row-block per wave
+    int geo = -1, kcq = 0, slack1 = 0, cslack = 0;
+    int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = 32, lkeep = 16, want = 16;
+    int S = 1, S2 = 1;                   // reference splits of the main / tail launch
+    bool forced = false;                 // the split count is the caller's (option "splits")
+    int64_t gx = 0, gx_main = 0, gx_tail = 0, rows_pad = 0, tps = 0, tps2 = 0;
+    char kernel[160] = "";
+};
+
+static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_mode, L2Plan *P)
+{
+    const int kk = k + drop;
+    const int epl = ((kk <= 24 && !ix->wide_retry) || cand_mode) ? 1 : 2;
+    const int L = 32 * epl;
+    int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = L;
+    bool use_h = false, use_c = false;                   // use_h: an f16x3 kernel runs; use_c: the shared-tile one
+    if (ix->mode == 1 && epl == 1) {
+#ifdef NABO_EXPERIMENTS
+        if (ix->shared) {
+            nabo::l2s_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
+            use_c = (cand_mode ? kk : kk + 4) <= lkeep_max;
+        }
+        if (!use_c && !ix->q16) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        else
+#endif
+        if (!use_c) nabo::l2q_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
+    }
+    // The one-product first pass (kc1-step operands; see nabo_index::coarse) -- on the l2c kernel, in the geometry that
+    // serves the list length the pass wants (l2c_topk.hip: two waves per SIMD up to 23 kept entries, 32-entry lists,
+    // 64-entry lists for k' > 24), unless the locality order, the 32x32x16 experiment or an A/B run sends the operands
+    // through the l2q / l2h kernel (those serve 32-entry lists and g < 64 only).
+    const bool pass1 = ix->coarse && !(ix->coarse_weak && ix->opt.coarse_adapt != 0) && ix->pass_level < 2 &&
+                       !ix->wide_retry && (!cand_mode || kk + 3 <= 32);
+    // (k' > 24, the 64-entry lists: six entries more -- there a row the first pass fails is expensive, the pass behind the
+    // seeded one is the fp32 filter: cosine 1M x 1M, d = 100, k = 50: 689 -> 597 ms per step)
+    const int slack1 = ix->opt.coarse_slack >= 0 ? ix->opt.coarse_slack : (epl == 2 ? 6 : 0);
+    const int cslack = ix->opt.cand_slack >= 0 ? ix->opt.cand_slack : ix->cand_slack;
+    int want = cand_mode ? (kk < 4 ? 4 : kk) + cslack : kk + 8 + slack1;
+    if (ix->pass_level == 1) want = L;                   // seeded pass: room for everything below the seed
+    if (epl == 1 && want > 32) want = 32;                // (the emitted lists hold 32 epl entries)
+    if (epl == 2) want = want < 33 ? 33 : (want > 64 ? 64 : want);
+    int geo = -1;
+    if (pass1 && ix->q16 && ix->order_flags == 0 && ix->opt.coarse_kernel_q == 0 && kk + 4 <= L) {
+        geo = nabo::l2c_geometry(ix->kc1, want, ix->opt.l2c_geo);
+        if (epl == 1 && geo == 2) geo = 0;               // (NABO_L2C_GEO=c with 32-entry emitted lists: geometry A)
+    }
+    const bool on_l2c = geo >= 0;
+    const bool use_1 = on_l2c || (pass1 && use_h && !use_c);
+    if (on_l2c) {
+        use_h = true;
+        use_c = false;
+        nabo::l2c_topk_geometry(ix->kc1, want, ix->opt.l2c_geo, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        if (geo == 0) { rows_per_wg = 4 * 128; lkeep_max = 32; }
+    }
+    const int kcq = use_1 ? ix->kc1 : ix->kc;
+    // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
+    // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
+    bool r1 = false;
+    if (!use_h) {
+        nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        const int r1_mode = ix->opt.l2_r1;             // -1 auto, 0 never, 1 always (experiments)
+        // ... and also when the list warm-up is a large share of a workgroup's time (short reference streams,
+        // e.g. one shard of eight): the same per-workgroup model as the split choice below, threshold measured
+        // (the variant pays ~8 % more per reference tile, it wins from ~7.5 % warm-up share on)
+        int lk_est = cand_mode ? (kk < 4 ? 4 : kk) : (kk + 8 < 16 ? 16 : kk + 8);
+        if (lk_est > L) lk_est = L;
+        const double stream_ms = (double)((ix->n + 31) / 32) * 3.36e-3 * (ix->ksteps / 25.0);
+        const double lg_est = std::log((double)ix->n / lk_est > 2.0 ? (double)ix->n / lk_est : 2.0);
+        const double warm_ms = 5.1 * (lk_est / 24.0) * (lg_est / 10.6);
+        if (epl == 1 && ix->ksteps <= 25 && r1_mode != 0 &&
+            (r1_mode == 1 || (m + rows_per_wg - 1) / rows_per_wg < (int64_t)ix->n_cu * wg_per_cu ||
+             warm_ms > 0.075 * stream_ms)) {
+            r1 = true;
+            nabo::l2_topk_geometry(ix->ksteps, -1, &rows_per_wg, &wg_per_cu, &lkeep_max);
+        }
+    }
+    const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
+    const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
+    const int64_t rows_pad = gx * rows_per_wg;
+    // kept-list length: k' + 8 slack (the certification needs a gap above the k'-th distance)
+    int lkeep = kk + 8;
+    if (lkeep < 16) lkeep = 16;
+    if (ix->wide_retry) lkeep = lkeep_max;              // as many kept entries as the 64-entry lists allow
+    // one-product pass: its scores sit up to 2^-9 ||x|| ||y|| below the real ones and the gap above the k'-th distance
+    // has to cover that -- 1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass (7 ms), k' + 13 a
+    // third of that, but every five entries more cost 14 ms of list updates in the kernel: no extra slack by default
+    if (use_1) lkeep = kk + 8 + slack1;
+    if (use_1 && ix->pass_level == 1) lkeep = lkeep_max;       // seeded pass: room for everything below the seed
+    if (on_l2c && lkeep > want) lkeep = want;
+    if (cand_mode) lkeep = kk < 4 ? 4 : kk;
+    // (candidate mode on the one-product pass: three kept entries more than are emitted, so that the bound is the exact
+    // distance of the first candidate left out and not the one-product threshold, which sits 2^-9 ||x|| ||y|| lower)
+    if (cand_mode && use_1) lkeep += cslack;
+    if (lkeep > lkeep_max) lkeep = lkeep_max;
+    // (experiments and tests: the first pass's list length; the passes behind it keep theirs)
+    if (ix->pass_level == 0 && !ix->wide_retry) { const int lk = ix->opt.lkeep; if (lk >= kk && lk <= lkeep_max) lkeep = lk; }
+    // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
+    // chip is full.  Many rows: the last, partially filled round of workgroups is launched with
+    // its own split factor S2 so that it takes ~1/S2 of a round instead of a whole one.
+    int64_t gx_main = gx, gx_tail = 0;
+    int S2 = 1;
+    int S = ix->opt.splits;
+    const bool forced = S > 0;
+    if (!forced) {
+        S = 1;
+        if (gx < slots) {
+            // Fewer workgroups than the chip holds: pick the split count from a cost model.  A workgroup costs
+            // (reference tiles it streams) x t_tile for the MFMA chains PLUS a per-row list warm-up that does
+            // not shrink with the stream (~lkeep * ln(stream / lkeep) appends per row: 5.1 ms per workgroup at
+            // lkeep = 24 over 1M references, measured); every split pays the warm-up again.
+            int64_t s_hi = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
+            if (s_hi > 1024 / L) s_hi = 1024 / L;
+            // ms per reference tile and workgroup, measured: 105 ms / 31250 tiles (fp32, 256 rows, 25 k-steps); 1.2 us f16x3
+            const double t_tile = use_c ? 0.7e-3 * ix->kc / 10.0 : use_h ? 1.1e-3 * kcq / 10.0
+                                                                    : 3.36e-3 * (rows_per_wg / 256.0) * (ix->ksteps / 25.0);
+            double best = 1e30;
+            for (int s2 = 1; s2 <= (int)s_hi; ++s2) {
+                const double rounds = (double)((gx * s2 + slots - 1) / slots);
+                const double stream = (double)ix->n / s2;
+                double lg = std::log(stream / lkeep > 2.0 ? stream / lkeep : 2.0);
+                const double warm = 5.1 * (lkeep / 24.0) * (lg / 10.6) * (rows_per_wg / 256.0);
+                const double cost = rounds * ((double)ix->ref_tiles / s2 * t_tile + warm);
+                if (cost < best * (1.0 - 1e-3)) { best = cost; S = s2; }
+            }
+        } else if (gx % slots != 0 && ix->opt.tail_split != 0 && ix->ref_tiles >= 256) {
+            const int64_t tail = gx % slots;
+            double best = 1.0;
+            // (at most 8 splits: 11 would fill the chip exactly at 1M x 1M -- kernel 0.6 ms shorter, refine of the tail
+            // rows' 11 lists 1.1 ms longer)
+            for (int s2 = 2; s2 <= 8; ++s2) {
+                const double t = (double)((tail * s2 + slots - 1) / slots) / s2;
+                if (t < best - 1e-9) { best = t; S2 = s2; }
+            }
+            if (S2 > 1) { gx_tail = tail; gx_main = gx - tail; }
+        }
+    }
+    if (S > 1024 / L) S = 1024 / L;                     // refine merges at most 1024 candidates per row (32 or 16 lists)
+    if (S < 1) S = 1;
+    if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
+    // A seeded pass keeps at most L entries per list: where the first pass already kept (nearly) as many -- k' >= 43 on the
+    // 64-entry lists: cosine d = 100, k = 50 -- one list per row certifies nothing the first pass could not.  Four
+    // reference splits give a row four lists: the references below its seed (a few more than 64) spread over them.
+    if (use_1 && ix->pass_level == 1 && !forced && kk + 8 + slack1 + 8 > L) {
+        if (S < 4) S = 4;
+        if (gx_tail > 0 && S2 < 4) S2 = 4;
+    }
+    {   // a list entry holds 25 bits of offset into its split (topk_lists.h): very large sets take more splits
+        // (NABO_SPLIT_REFS_MAX: tests lower the bound to see the rule at ordinary sizes)
+        int64_t split_refs = ix->opt.split_refs_max;
+        if (split_refs < 64 || split_refs > NABO_LIST_SPLIT_REFS) split_refs = NABO_LIST_SPLIT_REFS;
+        const int64_t split_tiles = (split_refs - 1) / 32;
+        const int64_t s_min = (ix->ref_tiles + split_tiles - 1) / split_tiles;
+        if (s_min > 1024 / L) return fail(NABO_E_INVALID, "more than 2^25 x (1024 / list length) reference cells in one index");
+        if (S < s_min) S = (int)s_min;
+        if (gx_tail > 0 && S2 < s_min) S2 = (int)s_min;
+    }
+    const int64_t tps = (ix->ref_tiles + S - 1) / S;
+    const int64_t tps2 = (ix->ref_tiles + S2 - 1) / S2;
+    if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
+        return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
+
+    P->epl = epl; P->L = L;
+    P->use_h = use_h; P->use_c = use_c; P->use_1 = use_1; P->on_l2c = on_l2c; P->r1 = r1;
+    P->geo = geo; P->kcq = kcq; P->slack1 = slack1; P->cslack = cslack;
+    P->rows_per_wg = rows_per_wg; P->wg_per_cu = wg_per_cu; P->lkeep_max = lkeep_max; P->lkeep = lkeep; P->want = want;
+    P->S = S; P->S2 = S2; P->forced = forced;
+    P->gx = gx; P->gx_main = gx_main; P->gx_tail = gx_tail; P->rows_pad = rows_pad; P->tps = tps; P->tps2 = tps2;
+    {
+        // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
+        if (use_1 && ix->q16 && !on_l2c)
+            snprintf(P->kernel, sizeof(P->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq);
+        else if (use_1 && ix->q16) snprintf(P->kernel, sizeof(P->kernel), "l2c_topk_kernel<%d,%s> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2, geo == 1 ? "1,23,6,32,4,2" : geo == 2 ? "2,65,4,64,4,1" : "1,33,8,64,4,1");
+        else if (use_1) snprintf(P->kernel, sizeof(P->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, one-product f16 filter with the split error as an operand slot)", kcq);
+        else if (use_c) snprintf(P->kernel, sizeof(P->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
+        else if (use_h && ix->q16) snprintf(P->kernel, sizeof(P->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, K-concatenated f16x3 split)", ix->kc);
+        else if (use_h) snprintf(P->kernel, sizeof(P->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
+        else snprintf(P->kernel, sizeof(P->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
+                      r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 33 : 65);
     }
     return NABO_OK;
 }
@@ -814,166 +1099,21 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(nabo::normalise_rows_launch(dX, m, g, ix->xnbuf.as<double>(), st));
             dXp = ix->xnbuf.as<double>();
         }
-        int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = L;
-        bool use_h = false, use_c = false;                   // use_h: an f16x3 kernel runs; use_c: the shared-tile one
-        if (ix->mode == 1 && epl == 1) {
-            if (ix->shared) {
-                nabo::l2s_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
-                use_c = (cand_mode ? kk : kk + 4) <= lkeep_max;
-            }
-            if (!use_c && ix->q16) nabo::l2q_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            else if (!use_c) nabo::l2h_topk_geometry(ix->kc, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            use_h = (cand_mode ? kk : kk + 4) <= lkeep_max;   // needs at least 4 entries of slack
-        }
-        // The one-product first pass (kc1-step operands; see nabo_index::coarse) -- on the l2c kernel, in the geometry that
-        // serves the list length the pass wants (l2c_topk.hip: two waves per SIMD up to 23 kept entries, 32-entry lists,
-        // 64-entry lists for k' > 24), unless the locality order, the 32x32x16 experiment or an A/B run sends the operands
-        // through the l2q / l2h kernel (those serve 32-entry lists and g < 64 only).
-        const bool pass1 = ix->coarse && !(ix->coarse_weak && env_int("NABO_COARSE_ADAPT", 1) != 0) && ix->pass_level < 2 &&
-                           !ix->wide_retry && (!cand_mode || kk + 3 <= 32);
-        // (k' > 24, the 64-entry lists: six entries more -- there a row the first pass fails is expensive, the pass behind the
-        // seeded one is the fp32 filter: cosine 1M x 1M, d = 100, k = 50: 689 -> 597 ms per step)
-        const int slack1 = env_int("NABO_COARSE_SLACK", epl == 2 ? 6 : 0);
-        int want = cand_mode ? (kk < 4 ? 4 : kk) + env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack) : kk + 8 + slack1;
-        if (ix->pass_level == 1) want = L;                   // seeded pass: room for everything below the seed
-        if (epl == 1 && want > 32) want = 32;                // (the emitted lists hold 32 epl entries)
-        if (epl == 2) want = want < 33 ? 33 : (want > 64 ? 64 : want);
-        int geo = -1;
-        if (pass1 && ix->q16 && ix->order_flags == 0 && env_int("NABO_COARSE_KERNEL_Q", 0) == 0 && kk + 4 <= L) {
-            geo = nabo::l2c_geometry(ix->kc1, want);
-            if (epl == 1 && geo == 2) geo = 0;               // (NABO_L2C_GEO=c with 32-entry emitted lists: geometry A)
-        }
-        const bool on_l2c = geo >= 0;
-        const bool use_1 = on_l2c || (pass1 && use_h && !use_c);
-        if (on_l2c) {
-            use_h = true;
-            use_c = false;
-            nabo::l2c_topk_geometry(ix->kc1, want, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            if (geo == 0) { rows_per_wg = 4 * 128; lkeep_max = 32; }
-        }
-        const int kcq = use_1 ? ix->kc1 : ix->kc;
-        if (ix->pass_level == 0 && !ix->wide_retry) ix->pass_rows[0] = ix->pass_rows[1] = ix->pass_rows[2] = 0;
-        // fewer rows than two-row-block workgroups fill the chip with: one row-block per wave, three waves per SIMD
-        // (128-row workgroups balance the CUs and the third wave covers the list warm-up that dominates short streams)
-        bool r1 = false;
-        if (!use_h) {
-            nabo::l2_topk_geometry(ix->ksteps, epl, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            const int r1_mode = env_int("NABO_L2_R1", -1);             // -1 auto, 0 never, 1 always (experiments)
-            // ... and also when the list warm-up is a large share of a workgroup's time (short reference streams,
-            // e.g. one shard of eight): the same per-workgroup model as the split choice below, threshold measured
-            // (the variant pays ~8 % more per reference tile, it wins from ~7.5 % warm-up share on)
-            int lk_est = cand_mode ? (kk < 4 ? 4 : kk) : (kk + 8 < 16 ? 16 : kk + 8);
-            if (lk_est > L) lk_est = L;
-            const double stream_ms = (double)((ix->n + 31) / 32) * 3.36e-3 * (ix->ksteps / 25.0);
-            const double lg_est = std::log((double)ix->n / lk_est > 2.0 ? (double)ix->n / lk_est : 2.0);
-            const double warm_ms = 5.1 * (lk_est / 24.0) * (lg_est / 10.6);
-            if (epl == 1 && ix->ksteps <= 25 && r1_mode != 0 &&
-                (r1_mode == 1 || (m + rows_per_wg - 1) / rows_per_wg < (int64_t)ix->n_cu * wg_per_cu ||
-                 warm_ms > 0.075 * stream_ms)) {
-                r1 = true;
-                nabo::l2_topk_geometry(ix->ksteps, -1, &rows_per_wg, &wg_per_cu, &lkeep_max);
-            }
-        }
-        const int epl_launch = r1 ? -1 : epl;
-        if (!ix->wide_retry && ix->pass_level == 0) {
-            // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
-            if (use_1 && ix->q16 && !on_l2c)
-                snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq);
-            else if (use_1 && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2c_topk_kernel<%d,%s> (v_mfma_f32_16x16x32_f16, one-product f16 filter with the split error as an operand slot)", kcq / 2, geo == 1 ? "1,23,6,32,8" : geo == 2 ? "2,65,4,64,4" : "1,33,8,64,4");
-            else if (use_1) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, one-product f16 filter with the split error as an operand slot)", kcq);
-            else if (use_c) snprintf(ix->kernel, sizeof(ix->kernel), "l2s_topk_kernel<%d> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split, LDS tile ring)", ix->kc);
-            else if (use_h && ix->q16) snprintf(ix->kernel, sizeof(ix->kernel), "l2q_topk_kernel<%d,1,33> (v_mfma_f32_16x16x32_f16, K-concatenated f16x3 split)", ix->kc);
-            else if (use_h) snprintf(ix->kernel, sizeof(ix->kernel), "l2h_topk_kernel<%d,4,1,33> (v_mfma_f32_32x32x16_f16, K-concatenated f16x3 split)", ix->kc);
-            else snprintf(ix->kernel, sizeof(ix->kernel), "l2_topk_kernel<%d,%d,%d,%d> (v_mfma_f32_32x32x2_f32)", ix->ksteps,
-                          r1 ? 1 : (epl == 1 ? 2 : 1), epl, epl == 1 ? 33 : 65);
+        L2Plan P;
+        if ((rc = plan_l2(ix, m, k, drop, cand_mode, &P))) return rc;
+        const bool use_h = P.use_h, use_c = P.use_c, use_1 = P.use_1, on_l2c = P.on_l2c, forced = P.forced;
+        const int geo = P.geo, kcq = P.kcq, slack1 = P.slack1, lkeep = P.lkeep, rows_per_wg = P.rows_per_wg, S2 = P.S2;
+        const int epl_launch = P.r1 ? -1 : epl;
+        const int64_t gx_main = P.gx_main, gx_tail = P.gx_tail, rows_pad = P.rows_pad, tps = P.tps, tps2 = P.tps2;
+        const int Q = (ix->ksteps + 3) / 4;
+        S = P.S;
+        (void)forced; (void)slack1;
+        if (ix->pass_level == 0 && !ix->wide_retry) {
+            ix->pass_rows[0] = ix->pass_rows[1] = ix->pass_rows[2] = 0;
+            snprintf(ix->kernel, sizeof(ix->kernel), "%s", P.kernel);
         }
         if ((rc = ensure_packed(ix, use_1 ? 2 : use_h ? 1 : 0))) return rc;
         if (top) ix->row_pass.assign((size_t)m, (uint8_t)(use_1 ? NABO_PASS_ONE_PRODUCT : NABO_PASS_SECOND));
-        const int64_t slots = (int64_t)ix->n_cu * wg_per_cu;          // workgroups resident at once
-        const int64_t gx = (m + rows_per_wg - 1) / rows_per_wg;
-        const int64_t rows_pad = gx * rows_per_wg;
-        const int Q = (ix->ksteps + 3) / 4;
-        // kept-list length: k' + 8 slack (the certification needs a gap above the k'-th distance)
-        int lkeep = kk + 8;
-        if (lkeep < 16) lkeep = 16;
-        if (ix->wide_retry) lkeep = lkeep_max;              // as many kept entries as the 64-entry lists allow
-        // one-product pass: its scores sit up to 2^-9 ||x|| ||y|| below the real ones and the gap above the k'-th distance
-        // has to cover that -- 1M x 1M x 50: k' + 8 entries leave ~1 % of the rows to the f16x3 pass (7 ms), k' + 13 a
-        // third of that, but every five entries more cost 14 ms of list updates in the kernel: no extra slack by default
-        if (use_1) lkeep = kk + 8 + slack1;
-        if (use_1 && ix->pass_level == 1) lkeep = lkeep_max;       // seeded pass: room for everything below the seed
-        if (on_l2c && lkeep > want) lkeep = want;
-        if (cand_mode) lkeep = kk < 4 ? 4 : kk;
-        // (candidate mode on the one-product pass: three kept entries more than are emitted, so that the bound is the exact
-        // distance of the first candidate left out and not the one-product threshold, which sits 2^-9 ||x|| ||y|| lower)
-        if (cand_mode && use_1) lkeep += env_int("NABO_COARSE_CAND_SLACK", ix->cand_slack);
-        if (lkeep > lkeep_max) lkeep = lkeep_max;
-        // (experiments and tests: the first pass's list length; the passes behind it keep theirs)
-        if (ix->pass_level == 0 && !ix->wide_retry) { const int lk = env_int("NABO_LKEEP", 0); if (lk >= kk && lk <= lkeep_max) lkeep = lk; }
-        // Work decomposition.  Few target rows: split the reference range S ways (grid.y) so the
-        // chip is full.  Many rows: the last, partially filled round of workgroups is launched with
-        // its own split factor S2 so that it takes ~1/S2 of a round instead of a whole one.
-        int64_t gx_main = gx, gx_tail = 0;
-        int S2 = 1;
-        S = env_int("NABO_SPLITS", 0);
-        const bool forced = S > 0;
-        if (!forced) {
-            S = 1;
-            if (gx < slots) {
-                // Fewer workgroups than the chip holds: pick the split count from a cost model.  A workgroup costs
-                // (reference tiles it streams) x t_tile for the MFMA chains PLUS a per-row list warm-up that does
-                // not shrink with the stream (~lkeep * ln(stream / lkeep) appends per row: 5.1 ms per workgroup at
-                // lkeep = 24 over 1M references, measured); every split pays the warm-up again.
-                int64_t s_hi = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;
-                if (s_hi > 1024 / L) s_hi = 1024 / L;
-                // ms per reference tile and workgroup, measured: 105 ms / 31250 tiles (fp32, 256 rows, 25 k-steps); 1.2 us f16x3
-                const double t_tile = use_c ? 0.7e-3 * ix->kc / 10.0 : use_h ? 1.1e-3 * kcq / 10.0
-                                                                        : 3.36e-3 * (rows_per_wg / 256.0) * (ix->ksteps / 25.0);
-                double best = 1e30;
-                for (int s2 = 1; s2 <= (int)s_hi; ++s2) {
-                    const double rounds = (double)((gx * s2 + slots - 1) / slots);
-                    const double stream = (double)ix->n / s2;
-                    double lg = std::log(stream / lkeep > 2.0 ? stream / lkeep : 2.0);
-                    const double warm = 5.1 * (lkeep / 24.0) * (lg / 10.6) * (rows_per_wg / 256.0);
-                    const double cost = rounds * ((double)ix->ref_tiles / s2 * t_tile + warm);
-                    if (cost < best * (1.0 - 1e-3)) { best = cost; S = s2; }
-                }
-            } else if (gx % slots != 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && ix->ref_tiles >= 256) {
-                const int64_t tail = gx % slots;
-                double best = 1.0;
-                // (at most 8 splits: 11 would fill the chip exactly at 1M x 1M -- kernel 0.6 ms shorter, refine of the tail
-                // rows' 11 lists 1.1 ms longer)
-                for (int s2 = 2; s2 <= 8; ++s2) {
-                    const double t = (double)((tail * s2 + slots - 1) / slots) / s2;
-                    if (t < best - 1e-9) { best = t; S2 = s2; }
-                }
-                if (S2 > 1) { gx_tail = tail; gx_main = gx - tail; }
-            }
-        }
-        if (S > 1024 / L) S = 1024 / L;                     // refine merges at most 1024 candidates per row (32 or 16 lists)
-        if (S < 1) S = 1;
-        if ((int64_t)S > ix->ref_tiles) S = (int)ix->ref_tiles;
-        // A seeded pass keeps at most L entries per list: where the first pass already kept (nearly) as many -- k' >= 43 on the
-        // 64-entry lists: cosine d = 100, k = 50 -- one list per row certifies nothing the first pass could not.  Four
-        // reference splits give a row four lists: the references below its seed (a few more than 64) spread over them.
-        if (use_1 && ix->pass_level == 1 && !forced && kk + 8 + slack1 + 8 > L) {
-            if (S < 4) S = 4;
-            if (gx_tail > 0 && S2 < 4) S2 = 4;
-        }
-        {   // a list entry holds 25 bits of offset into its split (topk_lists.h): very large sets take more splits
-            // (NABO_SPLIT_REFS_MAX: tests lower the bound to see the rule at ordinary sizes)
-            int64_t split_refs = env_int("NABO_SPLIT_REFS_MAX", 0);
-            if (split_refs < 64 || split_refs > NABO_LIST_SPLIT_REFS) split_refs = NABO_LIST_SPLIT_REFS;
-            const int64_t split_tiles = (split_refs - 1) / 32;
-            const int64_t s_min = (ix->ref_tiles + split_tiles - 1) / split_tiles;
-            if (s_min > 1024 / L) return fail(NABO_E_INVALID, "more than 2^25 x (1024 / list length) reference cells in one index");
-            if (S < s_min) S = (int)s_min;
-            if (gx_tail > 0 && S2 < s_min) S2 = (int)s_min;
-        }
-        const int64_t tps = (ix->ref_tiles + S - 1) / S;
-        const int64_t tps2 = (ix->ref_tiles + S2 - 1) / S2;
-        if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
-            return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
         const int64_t rows_main = gx_main * rows_per_wg, rows_tail = gx_tail * rows_per_wg;
         const size_t xtile_bytes = use_h ? (size_t)kcq * 1024 : (size_t)Q * 256 * sizeof(float);
         if ((rc = ix->xpk.reserve((size_t)(rows_pad / 32) * xtile_bytes))) return rc;
@@ -993,6 +1133,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
         const bool t_ordered = use_h && !use_c && ix->q16 && (ix->order_flags & 2) != 0;
         const uint32_t *rperm = nullptr, *tperm = nullptr;
         const int32_t *wstart = nullptr;
+#ifdef NABO_EXPERIMENTS
         if (ordered) rperm = ix->rperm.as<uint32_t>();
         if (t_ordered) {
             if ((rc = order_rows(ix, dXp, m, ix->tkeys, ix->tperm))) return rc;
@@ -1005,6 +1146,9 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                             ix->wstart.as<int32_t>(), st));
             wstart = ix->wstart.as<int32_t>();
         }
+#else
+        (void)ordered; (void)t_ordered;
+#endif
         if (use_h)
             HIP_TRY(nabo::pack_cquery_launch(dXp, m, g, ix->centre.as<double>(), ix->hscale, kcq, rows_pad / 32,
                                              ix->xpk.as<unsigned char>(), ix->xnorm.as<double>(), ix->q16, st, tperm,
@@ -1015,6 +1159,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipEventRecord(ix->ev[1], st));
         bool seedable = false;               // the l2c kernel ran: its failed rows can go through a seeded pass
         bool refine_beside_tail = false;
+#ifdef NABO_EXPERIMENTS
         if (use_c) {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2s_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(), (int)tps, S,
@@ -1024,17 +1169,19 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 HIP_TRY(nabo::l2s_topk_launch(ix->kc, ix->xpk.as<unsigned char>(), ix->ycpk.as<unsigned char>(), (int)tps2, S2,
                                               (int)gx_tail, rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
                                               ix->cand_tau2.as<float>(), st));
-        } else if (use_h && ix->q16) {
+        } else
+#endif
+        if (use_h && ix->q16) {
             const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
             // the l2q kernel on the one-product operands: A/B runs, and the locality-ordered stream (its home pre-pass)
             const bool coarse_on_q = !on_l2c;
-            seedable = use_1 && !coarse_on_q && !cand_mode && env_int("NABO_SEEDED_PASS", 1) != 0;
+            seedable = use_1 && !coarse_on_q && !cand_mode && ix->opt.seeded_pass != 0;
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             if (use_1 && !coarse_on_q) {
                 // Tournament seeds (l2c_topk.hip: l2c_pre_kernel): every (row, split) list starts from an upper bound of its
                 // lkeep-th smallest score among the split's first references instead of +inf -- not for a pass that has its
                 // seeds already.  NABO_PREPASS: 0 off, otherwise percent of the planned length (A/B runs; same bits always).
-                const int pre_pct = seeds ? 0 : env_int("NABO_PREPASS", 100);
+                const int pre_pct = seeds ? 0 : ix->opt.prepass;
                 const float *seeds_main = seeds, *seeds_tail = seeds;
                 int stride_main = 0, stride_tail = 0;
                 if (ix->pass_level == 0 && !ix->wide_retry) ix->pre_tiles_last = 0;
@@ -1064,7 +1211,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                                   ix->ref_tiles_alloc - 1, st, m, seeds_main, stride_main, 0));
                 // the tail launch (a fraction of a round, reference splits) leaves most CUs idle: the refine of the main
                 // launch's rows (an HBM gather) runs beside it on the second stream
-                if (gx_main > 0 && gx_tail > 0 && !cand_mode && env_int("NABO_REFINE_OVERLAP", 1) != 0) {
+                if (gx_main > 0 && gx_tail > 0 && !cand_mode && ix->opt.refine_overlap != 0) {
                     HIP_TRY(hipEventRecord(ix->ev_main, st));
                     refine_beside_tail = true;
                 }
@@ -1084,6 +1231,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
                                               ix->ref_tiles_alloc - 1, st, wstart));
             }
+#ifdef NABO_EXPERIMENTS
         } else if (use_h) {
             const unsigned char *ytiles = use_1 ? ix->ycpk1.as<unsigned char>() : ix->ycpk.as<unsigned char>();
             if (gx_main > 0)
@@ -1095,6 +1243,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                               (int)tps2, S2, (int)gx_tail, rows_main / 32, lkeep,
                                               ix->cand_idx2.as<uint32_t>(), nullptr, ix->cand_tau2.as<float>(),
                                               ix->ref_tiles_alloc - 1, st));
+#endif
         } else {
             if (gx_main > 0)
                 HIP_TRY(nabo::l2_topk_launch(ix->ksteps, epl_launch, ix->xpk.as<float>(), ix->ypk.as<float>(), (int)tps, S,
@@ -1221,7 +1370,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                               nf, k, d_oidx, d_odist, st));
             HIP_TRY(hipEventRecord(ix->ev[3], st));          // (ev[0..5] were reused by the inner call)
             retried = true;
-        } else if (n_fail >= 16 && epl == 1 && !ix->wide_retry && env_int("NABO_WIDE_RETRY", 1) != 0) {
+        } else if (n_fail >= 16 && epl == 1 && !ix->wide_retry && ix->opt.wide_retry != 0) {
             // Second chance: rows the 32-entry lists could not certify (ties / near-ties reaching past the kept
             // entries) go through the same filter once more with 64-entry lists before anything is brute-forced.
             // The flagged rows are gathered into a dense batch; this very function solves it (wide_retry) and
@@ -1267,7 +1416,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
     } else {
         const int64_t n_chunks = (ix->n + 63) / 64;
         const int64_t gx = (m + 63) / 64;
-        S = env_int("NABO_SPLITS", 0);
+        S = ix->opt.splits;
         if (S <= 0) {
             S = 1;
             if (gx < 512) {
@@ -1299,7 +1448,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // resident workgroups: SWAR pass -- one-wave workgroups, 2 per SIMD; bitmap pass -- ONE 8-wave workgroup per CU
             // (its LDS copy of the table rows + eight waves' lists fill the CU's LDS)
             const int64_t slots = bits ? (int64_t)ix->n_cu : (int64_t)ix->n_cu * 8;
-            int Sf = env_int("NABO_SPLITS", 0);
+            int Sf = ix->opt.splits;
             int s_max = 1024 / (lists * L);                   // refine handles <= 1024 candidates per row
             if (bits) {                                       // splits are ranges of 2048-reference blocks, >= 2 each
                 const int64_t nb2 = ((ix->n + 2047) / 2048) / 2;
@@ -1321,7 +1470,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // split factor so that it takes a fraction of a round -- same idea as in the Euclidean launch above
             int64_t gx_main = gxf, gx_tail = 0;
             int S2 = 1;
-            if (env_int("NABO_SPLITS", 0) <= 0 && env_int("NABO_TAIL_SPLIT", 1) != 0 && gxf > slots && gxf % slots != 0 &&
+            if (ix->opt.splits <= 0 && ix->opt.tail_split != 0 && gxf > slots && gxf % slots != 0 &&
                 s_max >= 2) {
                 const int64_t tail = gxf % slots;
                 double best_t = 1e30;
@@ -1507,6 +1656,67 @@ int nabo_index_last_passes(const nabo_index *ix, int64_t rows[3])
     rows[0] = ix->pass_rows[0];
     rows[1] = ix->pass_rows[1];
     rows[2] = ix->pass_rows[2];
+    return NABO_OK;
+}
+
+int nabo_query_plan(int64_t n_ref, int32_t g, int32_t metric, int64_t m, int32_t k, int32_t drop_first, int32_t n_cand,
+                    int32_t n_cu, const char *l2_mode, const char *options, int64_t out[NABO_PLAN_FIELDS], char *kernel,
+                    size_t kernel_len)
+{
+    if (!out) return fail(NABO_E_INVALID, "NULL argument");
+    if (n_ref < 1 || g < 1 || m < 1 || k < 1 || n_cu < 1) return fail(NABO_E_INVALID, "bad shape");
+    if (metric != NABO_METRIC_EUCLIDEAN && metric != NABO_METRIC_COSINE)
+        return fail(NABO_E_UNSUPPORTED, "nabo_query_plan describes the Euclidean / cosine filter launches");
+    nabo_index ix;                                   // a shape, never a device object: nothing here touches HIP
+    ix.n = n_ref;
+    ix.g = g;
+    ix.metric = metric;
+    ix.n_cu = n_cu;
+    if (options && *options) {                       // "name=value,name=value"
+        char buf[512];
+        snprintf(buf, sizeof(buf), "%s", options);
+        for (char *tok = strtok(buf, ","); tok; tok = strtok(nullptr, ",")) {
+            char *eq = strchr(tok, '=');
+            if (!eq) return fail(NABO_E_INVALID, "option '%s': expected name=value", tok);
+            *eq = 0;
+            if (!option_set(ix.opt, tok, atoll(eq + 1))) return fail(NABO_E_INVALID, "unknown option '%s'", tok);
+        }
+    }
+    index_init_filters(&ix, (l2_mode && *l2_mode) ? l2_mode : nullptr);
+    ix.ref_tiles = (n_ref + 31) / 32;
+    ix.ref_tiles_alloc = ix.ref_tiles + 64;
+    const int drop = drop_first ? 1 : 0;
+    const bool cand = n_cand > 0;
+    const int kq = cand ? n_cand : k;
+    for (int i = 0; i < NABO_PLAN_FIELDS; ++i) out[i] = 0;
+    if (kq + (cand ? 0 : drop) > NABO_MAX_K || ix.ksteps < 0) {          // the exact float64 kernels answer every row
+        out[0] = NABO_PASS_EXACT;
+        out[1] = -1;
+        if (kernel && kernel_len) snprintf(kernel, kernel_len, "exact_dist_rows_kernel + exact_select_rows_kernel (float64 brute force)");
+        return NABO_OK;
+    }
+    L2Plan P;
+    int rc = plan_l2(&ix, m, kq, cand ? 0 : drop, cand, &P);
+    if (rc) return rc;
+    int pt = 0, gt = 0;
+    if (P.on_l2c && ix.opt.prepass > 0) nabo::l2c_pre_plan(P.kcq, P.lkeep, (int)P.tps, ix.opt.prepass, &pt, &gt);
+    out[0] = P.use_1 ? NABO_PASS_ONE_PRODUCT : NABO_PASS_SECOND;
+    out[1] = P.geo;
+    out[2] = P.rows_per_wg;
+    out[3] = P.gx_main;
+    out[4] = P.gx_tail;
+    out[5] = P.S;
+    out[6] = P.S2;
+    out[7] = P.lkeep;
+    out[8] = P.L;
+    out[9] = P.tps;
+    out[10] = pt;
+    out[11] = gt;
+    out[12] = (int64_t)n_cu * P.wg_per_cu;
+    out[13] = P.gx_main * P.S + P.gx_tail * P.S2;
+    out[14] = P.rows_pad;
+    out[15] = P.kcq;
+    if (kernel && kernel_len) snprintf(kernel, kernel_len, "%s", P.kernel);
     return NABO_OK;
 }
 

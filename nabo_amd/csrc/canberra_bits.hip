@@ -369,8 +369,13 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
         }
     };
     fetch(0);
+    cbb_u32x2 rnx[TS];                                      // row addresses of the step about to run (CBB_STEP)
+#pragma unroll
+    for (int s = 0; s < TS; ++s) rnx[s] = cbb_u32x2{0u, 0u};
     cbb_dma_wait();
-    __syncthreads();
+    __syncthreads();                                         // (also: ro2 and the zero rows are written)
+#pragma unroll
+    for (int s = 0; s < TS; ++s) rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(ro2_off + (uint32_t)((4 * s + q) * 8));
     int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
         uint32_t pl[TS][4][6];                               // bit-sliced counters: pl[s][w][b] = bit b of the 32 counts of word w
@@ -389,16 +394,26 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
 #define CBB_STEP(DP, ROLE)                                                                                                   \
         {                                                                                                                    \
             const int dp_ = (DP);                                                                                            \
-            fetch(buf ^ 1);                                                                                                  \
+            /* the row addresses come from rnx, read from ro2 BEFORE the previous step's barrier: all eight row reads of the  \
+               step leave at once, the table rows of the next step are requested while they fly, slot 1's rows arrive under   \
+               slot 0's arithmetic */                                                                                        \
             const uint32_t lb = (uint32_t)sub * 16u | ((uint32_t)buf << 16);      /* row | lane | buffer bits never overlap */  \
+            cbb_u32x4 lA[TS], hA[TS], lB[TS], hB[TS];                                                                        \
             _Pragma("unroll") for (int s = 0; s < TS; ++s) {                                                                 \
-                const cbb_u32x2 r = *(cbb_lds_u2 *)(uintptr_t)(ro2_off + (uint32_t)((dp_ * T + 4 * s + q) * 8));                 \
-                const cbb_u32x4 lA = *(cbb_lds_u4 *)(uintptr_t)((r.x & 0xFFFFu) | lb);                                           \
-                const cbb_u32x4 hA = *(cbb_lds_u4 *)(uintptr_t)((r.x >> 16) | lb);                                               \
-                const cbb_u32x4 lB = *(cbb_lds_u4 *)(uintptr_t)((r.y & 0xFFFFu) | lb);                                           \
-                const cbb_u32x4 hB = *(cbb_lds_u4 *)(uintptr_t)((r.y >> 16) | lb);                                               \
-                const uint32_t la_[4] = {lA.x, lA.y, lA.z, lA.w}, ha_[4] = {hA.x, hA.y, hA.z, hA.w};                         \
-                const uint32_t lb_[4] = {lB.x, lB.y, lB.z, lB.w}, hb_[4] = {hB.x, hB.y, hB.z, hB.w};                         \
+                lA[s] = *(cbb_lds_u4 *)(uintptr_t)((rnx[s].x & 0xFFFFu) | lb);                                               \
+                hA[s] = *(cbb_lds_u4 *)(uintptr_t)((rnx[s].x >> 16) | lb);                                                   \
+                lB[s] = *(cbb_lds_u4 *)(uintptr_t)((rnx[s].y & 0xFFFFu) | lb);                                               \
+                hB[s] = *(cbb_lds_u4 *)(uintptr_t)((rnx[s].y >> 16) | lb);                                                   \
+            }                                                                                                                \
+            fetch(buf ^ 1);                                                                                                  \
+            {   /* ro2 of the NEXT step (wave-private: no barrier needed) */                                                 \
+                const int dn_ = dp_ + 1 < npair ? dp_ + 1 : 0;                                                               \
+                _Pragma("unroll") for (int s = 0; s < TS; ++s)                                                               \
+                    rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(ro2_off + (uint32_t)((dn_ * T + 4 * s + q) * 8));                    \
+            }                                                                                                                \
+            _Pragma("unroll") for (int s = 0; s < TS; ++s) {                                                                 \
+                const uint32_t la_[4] = {lA[s].x, lA[s].y, lA[s].z, lA[s].w}, ha_[4] = {hA[s].x, hA[s].y, hA[s].z, hA[s].w}; \
+                const uint32_t lb_[4] = {lB[s].x, lB[s].y, lB[s].z, lB[s].w}, hb_[4] = {hB[s].x, hB[s].y, hB[s].z, hB[s].w}; \
                 _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                              \
                     const uint32_t m0 = ha_[w] & ~la_[w], m1 = hb_[w] & ~lb_[w];                                             \
                     uint32_t c = __builtin_amdgcn_bitop3_b32(pl[s][w][0], m0, m1, 0xE8);                                     \
@@ -443,7 +458,7 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                     if ((ROLE) == 1) asm volatile("" : "+v"(c4a[s][w]));                                                     \
                     if ((ROLE) >= 3) { _Pragma("unroll") for (int b = 2; b < 6; ++b) asm volatile("" : "+v"(pl[s][w][b])); }  \
                 }                                                                                                            \
-                __builtin_amdgcn_sched_barrier(0);      /* one slot's rows at a time: 16 registers of reads in flight, not 32 */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                           \
             }                                                                                                                \
             cbb_dma_wait();                                                                                                  \
             __syncthreads();                                                                                                 \

@@ -55,8 +55,8 @@ constexpr bool L2C_ABLATED = false;
 #endif
 // Three geometries (claunch_one), by the list length a pass wants:
 //   A  one wave per SIMD: 4 waves x 128 rows, lists of <= 32 kept entries (33-entry rows), 64 staging records;
-//   B  TWO waves per SIMD: 8 waves x 96 rows, lists of <= 23 kept entries (23-entry rows: k' + 8 at k' = 15), 32 staging
-//      records -- 8 x 20 096 bytes of LDS.  While one wave of a SIMD stages hits or drains its lists, the other one's
+//   B  TWO waves per SIMD: 4 waves x 96 rows per workgroup, TWO workgroups per CU (round 3: one of 8 waves), lists of <= 23
+//      kept entries (23-entry rows: k' + 8 at k' = 15), 32 staging records -- 2 x 4 x 20 096 bytes of LDS.  While one wave of a SIMD stages hits or drains its lists, the other one's
 //      MFMAs keep the matrix pipe busy; the price is 8 x 4 KB of tile per 24 MFMAs instead of 4 x 4 KB per 32.
 //   C  one wave per SIMD: 4 waves x 64 rows, lists of <= 64 kept entries (65-entry rows, emitted lists of 64): k' up to 56
 //      (BASELINE configs[4]: k = 50), which the fp32-MFMA kernel served before.
@@ -281,8 +281,12 @@ __device__ __forceinline__ void cstage2(const cacc &acc, const cmins &m, int p, 
 }
 
 // Grid: x = target super-blocks (4 waves x 128 rows), y = reference splits.
-template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned char *__restrict__ Xpk,
+// WPS: waves per SIMD the kernel is built for (1: the whole register file, B operands in AGPRs, a ring of four tile sets;
+// 2: 256 registers, a ring of two).  Geometry B is WAVES = 4, WPS = 2: TWO 384-row workgroups per CU -- the same occupancy
+// as one 768-row workgroup of eight waves, at half the granularity: 100k target rows are 261 workgroups on 512 slots (every
+// CU busy, each wave alone on its SIMD) instead of 131 on 256 (half the chip idle), and the last round of a long query is cut finer.
+template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES, int WPS>
+__global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigned char *__restrict__ Xpk,
                                                           const unsigned char *__restrict__ Ypk,
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
                                                           uint32_t *__restrict__ cand_idx,
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             // pinned in AGPRs (l2h_topk.hip) at one wave per SIMD.  NOT at two: with 256 registers per wave hipcc then
             // parks ACCUMULATORS in the spare AGPRs and copies them (v_accvgpr_write) right behind the inline-assembly
             // MFMA that is still writing them -- a hazard it cannot see (wrong neighbours in 3 of 9 test shapes).
-            if (WAVES <= 4) asm volatile("" : "+a"(xb[rb][s]));
+            if (WPS == 1) asm volatile("" : "+a"(xb[rb][s]));
         }
     }
     unsigned char *wl = smem_raw + (size_t)wave * C::BYTES;          // this wave's lists (topk_lists.h)
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
     // SIMD, where the other wave covers the latency and 256 registers have to hold everything
     // (... and at four operand steps with eight row-blocks: 4 x 32 + 2 x 64 + ... arch VGPRs would not fit 256, hipcc would
     // park values in AGPRs -- see the B operands above for why that must not happen next to inline-assembly MFMAs)
-    constexpr int RING = (WAVES > 4 || (KS >= 4 && NBv >= 8)) ? 2 : 4;
+    constexpr int RING = (WPS > 1 || (KS >= 4 && NBv >= 8)) ? 2 : 4;
     f16x8 a0[2][KS], a1[2][KS], a2[2][KS], a3[2][KS];
     tile_load(a0, t_begin);
     if (RING == 4) {
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void l2c_topk_kernel(const unsigned 
             hit[p] = 0;
 #else
             if constexpr ((KS == 2 || KS == 4) && !L2C_BUILTIN) {
-                cpair<KS, (WAVES <= 4)>(a, xb[2 * p], xb[2 * p + 1], cur[p], old[p], tauv[2 * p], tauv[2 * p + 1], mm[p], hit[p]);
+                cpair<KS, (WPS == 1)>(a, xb[2 * p], xb[2 * p + 1], cur[p], old[p], tauv[2 * p], tauv[2 * p + 1], mm[p], hit[p]);
             } else {                                    // hipcc's own schedule of builtin MFMAs (other shapes; A/B runs)
                 mm[p] = cmin8x2(old[p]);
                 hit[p] = __builtin_amdgcn_ballot_w64((mm[p].m0 < tauv[2 * p]) | (mm[p].m1 < tauv[2 * p + 1]));
@@ -668,7 +672,7 @@ hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const uns
 #undef NABO_PRE
 }
 
-template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES>
+template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES, int WPS>
 static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
@@ -677,11 +681,11 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
     const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)WAVES * ListCfg<EPL, ROWN, NBv, NRECv, 16, (ROWN >= 64)>::BYTES;
     static_assert(lds <= 163840, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 grid(gx, S), block(64 * WAVES);
-    hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
+    hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
                        cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride, tau_row0);
 #ifdef NABO_LISTS_PROF
     {
@@ -703,32 +707,31 @@ static hipError_t claunch_one(int geo, const unsigned char *Xpk, const unsigned 
 {
     if constexpr (KS <= 2) {
         if (geo == 1)
-            return claunch_geo<KS, 1, L2C_ROW_B, 6, L2C_NREC_B, 8>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx,
+            return claunch_geo<KS, 1, L2C_ROW_B, 6, L2C_NREC_B, 4, 2>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx,
                                                                   cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
     }
     if (geo == 2)
-        return claunch_geo<KS, 2, L2C_ROW_C, 4, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
+        return claunch_geo<KS, 2, L2C_ROW_C, 4, L2C_NREC, 4, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
                                                             cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
-    return claunch_geo<KS, 1, L2C_ROW, 8, L2C_NREC, 4>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau,
+    return claunch_geo<KS, 1, L2C_ROW, 8, L2C_NREC, 4, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau,
                                                       pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
 }
 
 // Which geometry serves lists of `lkeep_want` kept entries: 1 = B (two waves per SIMD) up to 23 entries and KS <= 2 (its
-// 256 registers per wave hold two steps of operands), 0 = A up to 32, 2 = C up to 64; -1: none.  NABO_L2C_GEO=a|b|c pins
-// one where it can serve the lists at all.
-int l2c_geometry(int kc, int lkeep_want)
+// 256 registers per wave hold two steps of operands), 0 = A up to 32, 2 = C up to 64; -1: none.  pin (the index option
+// "l2c_geo": 0 = A, 2 = C, anything else none) selects one where it can serve the lists at all.
+int l2c_geometry(int kc, int lkeep_want, int pin)
 {
-    const char *pin = getenv("NABO_L2C_GEO");
     if (lkeep_want > 64) return -1;
-    if (lkeep_want > 32 || (pin && pin[0] == 'c')) return 2;
-    if (kc > 4 || lkeep_want > L2C_ROW_B || (pin && pin[0] == 'a')) return 0;
+    if (lkeep_want > 32 || pin == 2) return 2;
+    if (kc > 4 || lkeep_want > L2C_ROW_B || pin == 0) return 0;
     return 1;
 }
 
-void l2c_topk_geometry(int kc, int lkeep_want, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
+void l2c_topk_geometry(int kc, int lkeep_want, int pin, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
 {
-    switch (l2c_geometry(kc, lkeep_want)) {
-    case 1: *rows_per_wg = 8 * 96; *lkeep_max = L2C_ROW_B; break;
+    switch (l2c_geometry(kc, lkeep_want, pin)) {
+    case 1: *rows_per_wg = 4 * 96; *wg_per_cu = 2; *lkeep_max = L2C_ROW_B; return;
     case 2: *rows_per_wg = 4 * 64; *lkeep_max = 64; break;
     default: *rows_per_wg = 4 * 128; *lkeep_max = L2C_ROW < 32 ? L2C_ROW : 32; break;
     }

@@ -163,30 +163,6 @@ __global__ __launch_bounds__(256, 1) void l2h_topk_kernel(const unsigned char *_
     lists_flush<C, EPL, R>(wl, scnt, ltile0 * 32, split, S, lkeep, tauv, cand_idx, cand_key, cand_tau);
 }
 
-// max |V - centre| over all components, in float64 (bits of a non-negative double order like unsigned 64-bit ints)
-__global__ void maxabs_kernel(const double *__restrict__ V, int64_t n, int g, const double *__restrict__ centre,
-                              unsigned long long *__restrict__ out_bits)
-{
-    double m = 0.0;
-    const int64_t tot = n * g;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (int64_t)gridDim.x * blockDim.x) {
-        const double a = fabs(V[i] - centre[i % g]);
-        if (a > m) m = a;                                   // NaN never wins
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double other = __shfl_xor(m, o, 64);
-        m = other > m ? other : m;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
-}
-
-hipError_t maxabs_launch(const double *V, int64_t n, int g, const double *centre, unsigned long long *out_bits, hipStream_t st)
-{
-    hipLaunchKernelGGL(maxabs_kernel, dim3(2048), dim3(256), 0, st, V, n, g, centre, out_bits);
-    return hipGetLastError();
-}
-
 template <int KC, int R, int EPL, int ROWN>
 static hipError_t hlaunch_one(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,

@@ -304,6 +304,16 @@ void l2q_topk_geometry(int kc, int *rows_per_wg, int *wg_per_cu, int *lkeep_max)
     *lkeep_max = L2Q_ROW < 32 ? L2Q_ROW : 32;
 }
 
+// steps of 16 slots of the f16x3 operands for g components: 3 (g + 1) slots, instantiated values only (pack.hip)
+int l2q_pick_kc(int g)
+{
+    const int need = (3 * (g + 1) + 15) / 16;
+    const int inst[] = {2, 4, 6, 8, 10, 12};
+    for (int v : inst)
+        if (need <= v) return v;
+    return -1;          // g >= 64: the fp32 kernel
+}
+
 // steps of 16 slots of the one-product operands (g components + two norm slots + the error slot), even (KS = KC / 2
 // steps of 32 slots), instantiated values only
 int l2q_pick_kc1(int g)

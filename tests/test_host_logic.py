@@ -88,3 +88,45 @@ def test_list_entries_order_as_doubles_like_their_fp32_keys():
     m = np.maximum(ent[a], ent[b])                               # the maximum's key is the larger key
     assert np.array_equal((m.view(np.uint64) >> np.uint64(32)).astype(np.uint32).view(np.float32) >= np.maximum(keys[a], keys[b]),
                           np.ones(a.shape[0], dtype=bool))
+
+
+# ---- the launch planner (nabo_query_plan: a pure function of shapes and options -- no index, no device) -----------------------
+def test_query_plan_fills_the_chip_and_follows_the_list_rules():
+    """api.hip: plan_l2 through nabo_query_plan.  BASELINE's shapes: the default first pass is the one-product kernel in the
+    geometry its lists want; a query with enough work is cut into at least as many workgroups as the part has CUs
+    (configs[1], 100k x 100k, was 131 workgroups on 256 CUs in round 3); list lengths, split bounds and the tournament
+    follow their documented rules; the fp32 / f16x3 modes and the exact route are planned, not discovered on the device."""
+    from nabo_amd import _knn
+    P = _knn.query_plan
+    c2 = P(1000000, 50, 1000000, 15)                                      # BASELINE configs[2]
+    assert c2["kernel"].startswith("l2c_topk_kernel<2,1,23,6,32,4,2>") and c2["first_pass"] == 0 and c2["geometry"] == 1
+    assert c2["lkeep"] == 15 + 8 and c2["list_len"] == 32 and c2["rows_per_wg"] == 384 and c2["resident_workgroups"] == 512
+    assert c2["workgroups_main"] % 512 == 0 and c2["workgroups_tail"] * c2["splits_tail"] <= 512
+    assert c2["workgroups_main"] * 384 + c2["workgroups_tail"] * 384 == c2["rows_padded"] >= 1000000
+    assert 0 < c2["tournament_tiles"] <= c2["tiles_per_split"] // 4 and c2["tournament_tiles"] % c2["tournament_group"] == 0
+    c1 = P(100000, 50, 100000, 15)                                        # BASELINE configs[1]
+    assert c1["workgroups"] >= 256, c1
+    for m, n in ((3000, 3000), (20000, 100000), (700, 200000), (64, 1000000)):
+        p = P(n, 50, m, 15)
+        # few rows: reference splits fill the chip as far as the rules allow (>= 16 tiles per split, <= 1024 / list length
+        # lists per row for the refine step's merge)
+        reach = p["workgroups_main"] * min(32, max(1, ((n + 31) // 32) // 16))
+        assert p["workgroups"] >= 0.6 * min(256, reach), (m, n, p)
+        assert p["splits"] * p["tiles_per_split"] >= (n + 31) // 32 and p["splits"] * p["list_len"] <= 1024
+    c4 = P(5000000, 100, 1000000, 50, metric=2)                           # BASELINE configs[4]: cosine, d = 100, k = 50
+    assert c4["kernel"].startswith("l2c_topk_kernel<4,2,65,4,64,4,1>") and c4["lkeep"] == 64 and c4["list_len"] == 64
+    shard = P(125000, 50, 1000000, 15, n_cand=12)                         # one rank of eight: candidate mode, 12 emitted + 3 kept
+    assert shard["lkeep"] == 15 and P(125000, 50, 1000000, 15, n_cand=12, options={"cand_slack": 0})["lkeep"] == 12
+    assert P(1000000, 50, 1000, 15, l2_mode="f32")["kernel"].startswith("l2_topk_kernel") and P(1000000, 50, 1000, 15, l2_mode="f32")["first_pass"] == 2
+    assert P(1000000, 50, 1000, 15, l2_mode="f16x3")["kernel"].startswith("l2q_topk_kernel<10,")
+    assert P(1000000, 126, 1000, 15)["kernel"].startswith("l2_topk_kernel")               # beyond the one-product operands
+    assert P(1000000, 200, 1000, 15)["first_pass"] == 4 and P(1000000, 50, 1000, 60)["first_pass"] == 4      # no-cliff limits
+    # options: the caller's split count, the geometry pin, the tournament switch; unknown names are refused
+    assert P(100000, 50, 5000, 15, options={"splits": 7})["splits"] == 7
+    assert P(100000, 50, 5000, 15, options={"l2c_geo": 0})["kernel"].startswith("l2c_topk_kernel<2,1,33,8,64,4,1>")
+    assert P(1000000, 50, 1000000, 15, options={"prepass": 0})["tournament_tiles"] == 0
+    assert P(200000000, 50, 1000, 15)["splits"] >= 6                      # 25 bits of offset per split: > 2^25 references need more
+    with pytest.raises(ValueError):
+        P(1000, 50, 1000, 15, options={"no_such_option": 1})
+    with pytest.raises(ValueError):
+        P(1000, 50, 1000, 15, metric=1)

@@ -193,11 +193,7 @@ def test_reference_splits_do_not_change_results(gpu_lib):
     X = pca_like(300, 50, seed=32)
     base = None
     for s in ("1", "2", "5", "8"):
-        os.environ["NABO_SPLITS"] = s
-        try:
-            r = gpu_lib.knn(X, Y, 15, metric=0)
-        finally:
-            del os.environ["NABO_SPLITS"]
+        r = gpu_lib.knn(X, Y, 15, metric=0, options={"splits": int(s)})
         if base is None:
             base = r
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1])
@@ -392,11 +388,7 @@ def test_canberra_tail_round_rows_are_exact(gpu_lib):
     rows = np.concatenate([np.arange(0, 40), np.arange(2048 * 16 - 20, 2048 * 16 + 20), np.arange(m - 40, m)])
     oi, od = oracle.knn(X[rows], Y, k, 1, 0.25, nthreads=8)
     _check(gi[rows], gd[rows], oi, od)
-    os.environ["NABO_TAIL_SPLIT"] = "0"
-    try:
-        hi, hd = gpu_lib.knn(X, Y, k, metric=1, dist_factor=0.25)
-    finally:
-        del os.environ["NABO_TAIL_SPLIT"]
+    hi, hd = gpu_lib.knn(X, Y, k, metric=1, dist_factor=0.25, options={"tail_split": 0})
     assert np.array_equal(gi, hi) and np.array_equal(gd, hd)
 
 
@@ -467,15 +459,15 @@ def test_zero_target_rows_is_a_no_op(gpu_lib):
                                           (64, 3000, 100, 11, False)])
 def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
     """The Euclidean filter runs on the f16 matrix pipe -- the one-product first pass (l2c_topk.hip, the default where it
-    is instantiated: g < 64 and k + drop + 4 <= 32; rows it cannot certify go through the f16x3 pass), the f16x3 split as the
-    first pass (NABO_L2_MODE=f16x3; three kernels: 16x16x32 MFMA shape, 32x32x16 per-wave, 32x32x16 with shared LDS tiles) --
-    or on the fp32 MFMA (everything else, or NABO_L2_MODE=f32): the float64 refine + certification make all of them
-    return exactly what the oracle does."""
+    is instantiated: g <= 125 and k + drop + 4 <= 64; rows it cannot certify go on to the seeded pass and the filter behind
+    it), the f16x3 split as the first pass (NABO_L2_MODE=f16x3: l2q_topk.hip, g < 64 and k' <= 28) -- or on the fp32 MFMA
+    (everything else, or NABO_L2_MODE=f32): the float64 refine + certification make all of them return exactly what the
+    oracle does.  (The 32x32x16 kernels of rounds 1-2, l2h_topk.hip / l2s_topk.hip, live in the experiments build.)"""
     Y = pca_like(n, g, seed=1000 + n + g)
     X = Y[:m].copy() if drop else pca_like(m, g, seed=2000 + m + g)
     oi, od = oracle.knn(X, Y, k, 0, drop_first=drop, nthreads=8)
     kernels = {}
-    for mode in ("f16x1", "f16x1h", "f16x3", "f16x3h", "f16x3q", "f16x3s", "f32", None):
+    for mode in ("f16x1", "f16x3", "f32", None):
         if mode:
             os.environ["NABO_L2_MODE"] = mode
         try:
@@ -490,73 +482,20 @@ def test_both_filter_kernels_give_the_same_bits(gpu_lib, m, n, g, k, drop):
         assert st["fallback_rows"] == 0
     assert "l2_topk_kernel" in kernels["f32"]
     assert kernels[None] == kernels["f16x1"]                       # the one-product first pass is the default
-    # per-wave kernel (l2h) for g < 64 and k' + 4 <= 32; shared-tile kernel (l2s) for g <= 52 and k' + 4 <= 28
     kk = k + drop
-    h_ok, s_ok = (g < 64 and kk + 4 <= 32), (g <= 52 and kk + 4 <= 28)
-    assert kernels["f16x3h"].startswith("l2h_topk" if h_ok else "l2_topk"), kernels
-    assert kernels["f16x3s"].startswith("l2s_topk" if (g <= 52 and kk + 4 <= 24) else ("l2h_topk", "l2_topk")), kernels
-    assert kernels["f16x3q"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels          # 16x16x32 MFMA shape
-    assert kernels["f16x3"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels                 # the default f16x3 kernel
+    h_ok = g < 64 and kk + 4 <= 32
+    assert kernels["f16x3"].startswith("l2q_topk" if h_ok else "l2_topk"), kernels          # 16x16x32 MFMA shape
     # the one-product pass: g <= 125 and k' + 4 <= 64 (lists of 23 / 32 / 64 kept entries: geometries B / A / C of l2c_topk.hip)
     c_ok = g <= 125 and kk + 4 <= 64
     assert kernels["f16x1"].startswith("l2c_topk" if c_ok else "l2_topk") and ("one-product" in kernels["f16x1"]) == c_ok, kernels
-    assert kernels["f16x1h"].startswith("l2h_topk" if h_ok else ("l2c_topk" if c_ok else "l2_topk")), kernels
-
-
-@pytest.mark.parametrize("flags", ["7", "3", "1", "2"])
-@pytest.mark.parametrize("m,n,g,k,drop,metric,masked", [
-    (140000, 20000, 50, 15, False, 0, False),        # 274 workgroups on 256 slots: main launch + split tail round
-    (3000, 70000, 30, 11, False, 0, True),           # few rows: reference splits, every split with its own home pre-pass
-    (2500, 2500, 20, 9, True, 0, False),             # positional drop
-    (5000, 40000, 40, 12, False, 2, False),          # cosine (extension): keys from the unit-length rows, no centring
-    (900, 600, 7, 20, False, 0, True),               # fewer tiles than four pre-passes: no pre-pass
-])
-def test_locality_ordered_streaming_gives_the_same_bits(gpu_lib, flags, m, n, g, k, drop, metric, masked):
-    """order.hip (NABO_L2Q_ORDER, off by default -- measured slower, profiles/r3_order_experiment.txt): references and /
-    or targets packed in key order, home pre-pass per wave; positions are mapped back in the refine step, so indices,
-    distances, tie order, the ignore mask and the candidate-mode outputs are the caller's."""
+    # the planner says the same without a device (nabo_query_plan)
     from nabo_amd import _knn
-    Y = pca_like(n, g, seed=3100 + n)
-    Y[7] = Y[3]                                            # an exact tie: (distance, ORIGINAL index) order must survive the permutation
-    X = Y[:m].copy() if drop else pca_like(m, g, seed=3200 + m)
-    mask = None
-    if masked:
-        mask = (np.random.default_rng(n).random(n) < 0.3).astype(np.uint8)
-    oi, od = oracle.knn(X, Y, k, metric, 0.25, ref_mask=mask, drop_first=drop, nthreads=8)
-    os.environ["NABO_L2Q_ORDER"] = flags
-    try:
-        ix = gpu_lib.KnnIndex(n, g, metric=metric, ref_index_base=1000).set_ref(Y, ref_mask=mask)
-    finally:
-        os.environ.pop("NABO_L2Q_ORDER", None)
-    gi, gd = ix.query(X, k, drop_first=drop)
-    assert "l2q_topk" in ix.last_kernel()
-    _check(gi - 1000, gd, oi, od)
-    # shard mode: the first entries of the order rows + a bound that really bounds the rest
-    nc = min(k, 12)
-    dx = _knn.DeviceBuffer(X.nbytes).upload(X)
-    di, dd, db = _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * nc * 8), _knn.DeviceBuffer(m * 8)
-    ix.query_candidates_device(dx.ptr, m, nc, di.ptr, dd.ptr, db.ptr)
-    ci, cd, cb = di.download((m, nc), np.int64), dd.download((m, nc), np.float64), db.download((m,), np.float64)
-    ix.close()
-    for b in (dx, di, dd, db):
-        b.free()
-    o2i, o2d = oracle.knn(X, Y, nc + 1, metric, 0.25, ref_mask=mask, nthreads=8)
-    # A candidate list holds the nc smallest FILTER scores, re-evaluated exactly and sorted: two references whose exact
-    # distances differ by less than the filter's error may change places across the END of the list (or exact ties: the
-    # filter does not order them).  What the protocol relies on, and what must hold for EVERY row: the emitted entries are
-    # exact and sorted, and `bound` bounds everything that was not emitted.  Almost all rows are the oracle's prefix itself.
-    same = (ci - 1000 == o2i[:, :nc]).all(axis=1) & (cd == o2d[:, :nc]).all(axis=1)
-    assert same.mean() > 0.999, same.mean()
-    assert (np.diff(cd, axis=1) >= 0).all()
-    left_out = np.array([next(d for j, d in zip(o2i[r], o2d[r]) if j not in set(ci[r] - 1000)) for r in range(m)])
-    assert (cb <= left_out ** 2 * (1 + 1e-12)).all()
-    for r in np.nonzero(~same)[0][:50]:                      # the rows that differ: a permutation of near-ties only
-        exact = oracle.pairwise(X[r:r + 1], Y[ci[r] - 1000], metric, 0.25)[0]
-        assert np.array_equal(exact, cd[r])
-        assert set(ci[r, :nc - 1] - 1000) <= set(o2i[r]) and abs(cd[r, -1] - o2d[r, nc - 1]) <= 1e-4 * o2d[r, nc - 1]
+    assert _knn.query_plan(n, g, m, k, drop_first=drop)["kernel"] == kernels[None]
+    assert _knn.query_plan(n, g, m, k, drop_first=drop, l2_mode="f16x3")["kernel"] == kernels["f16x3"]
+    assert _knn.query_plan(n, g, m, k, drop_first=drop, l2_mode="f32")["kernel"] == kernels["f32"]
 
 
-@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3s", 274), ("f16x3h", 274), ("f16x3q", 274)])
+@pytest.mark.parametrize("mode,full_round", [("f32", 547), ("f16x3", 274)])
 def test_tail_round_split_rows_are_exact(gpu_lib, mode, full_round):
     """More target workgroups than resident slots: the last, partially filled round is launched with its
     own reference split (api.hip "tail round").  Rows of BOTH launches must match the oracle."""
@@ -834,18 +773,13 @@ def test_tie_heavy_rows_take_the_wide_second_chance(gpu_lib):
     X = Y[rng.choice(interior, 600, replace=False)] + 0.0                                                     # on lattice sites
     k = 15
     oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
-    os.environ["NABO_SPLITS"] = "1"
-    try:
-        ix = gpu_lib.KnnIndex(len(Y), 4, metric=0).set_ref(Y)
-        gi, gd = ix.query(X, k)
-        with_retry = ix.last_stats()["fallback_rows"]
-        os.environ["NABO_WIDE_RETRY"] = "0"
-        hi, hd = ix.query(X, k)
-        without = ix.last_stats()["fallback_rows"]
-        ix.close()
-    finally:
-        os.environ.pop("NABO_SPLITS", None)
-        os.environ.pop("NABO_WIDE_RETRY", None)
+    ix = gpu_lib.KnnIndex(len(Y), 4, metric=0, options={"splits": 1}).set_ref(Y)
+    gi, gd = ix.query(X, k)
+    with_retry = ix.last_stats()["fallback_rows"]
+    ix.set_option("wide_retry", 0)
+    hi, hd = ix.query(X, k)
+    without = ix.last_stats()["fallback_rows"]
+    ix.close()
     _check(gi, gd, oi, od)
     _check(hi, hd, oi, od)
     assert without >= 16                 # the situation really arises on this input
@@ -912,20 +846,16 @@ def test_partly_overflowing_targets_never_reach_the_filter_as_nan(gpu_lib, split
     X[big[:3], 5] *= 1e42                    # one component
     X[big[3:5], ::2] *= -1e45                # every other component, negative
     X[big[5:], :] *= 1e60                    # the whole row
-    os.environ["NABO_SPLITS"] = splits
-    try:
-        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
-        gi, gd = ix.query(X, k)
-        st = ix.last_stats()
-        # shard mode: the bound of such a row must be -inf (unknown), never a number
-        dx = _knn_buf(gpu_lib, X)
-        di, dd, db = (_knn_mod().DeviceBuffer(300 * 12 * 8), _knn_mod().DeviceBuffer(300 * 12 * 8),
-                      _knn_mod().DeviceBuffer(300 * 8))
-        ix.query_candidates_device(dx.ptr, 300, 12, di.ptr, dd.ptr, db.ptr)
-        cb = db.download((300,), np.float64)
-        ix.close()
-    finally:
-        del os.environ["NABO_SPLITS"]
+    ix = gpu_lib.KnnIndex(n, g, metric=0, options={"splits": int(splits)} if splits else None).set_ref(Y)
+    gi, gd = ix.query(X, k)
+    st = ix.last_stats()
+    # shard mode: the bound of such a row must be -inf (unknown), never a number
+    dx = _knn_buf(gpu_lib, X)
+    di, dd, db = (_knn_mod().DeviceBuffer(300 * 12 * 8), _knn_mod().DeviceBuffer(300 * 12 * 8),
+                  _knn_mod().DeviceBuffer(300 * 8))
+    ix.query_candidates_device(dx.ptr, 300, 12, di.ptr, dd.ptr, db.ptr)
+    cb = db.download((300,), np.float64)
+    ix.close()
     oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
     _check(gi, gd, oi, od)
     assert st["fallback_rows"] == big.size
@@ -961,23 +891,17 @@ def test_one_product_pass_chain_equals_the_oracle(gpu_lib, geo, offset):
     Y = _offset_clusters(n, g, 11, offset)
     X = _offset_clusters(m, g, 12, offset)
     oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
-    os.environ["NABO_L2C_GEO"] = geo
-    try:
-        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
-        gi, gd = ix.query(X, k)
-        st, kern = ix.last_stats(), ix.last_kernel()
-        os.environ["NABO_SEEDED_PASS"] = "0"             # the chain without its seeded link ...
-        os.environ["NABO_COARSE_ADAPT"] = "0"            # ... and with the first pass even where the first query found it weak
-        hi, hd = ix.query(X, k)
-        st2 = ix.last_stats()
-        ix.close()
-    finally:
-        os.environ.pop("NABO_L2C_GEO", None)
-        os.environ.pop("NABO_SEEDED_PASS", None)
-        os.environ.pop("NABO_COARSE_ADAPT", None)
+    ix = gpu_lib.KnnIndex(n, g, metric=0, options={"l2c_geo": {"a": 0, "b": 1}[geo]}).set_ref(Y)
+    gi, gd = ix.query(X, k)
+    st, kern = ix.last_stats(), ix.last_kernel()
+    ix.set_option("seeded_pass", 0)              # the chain without its seeded link ...
+    ix.set_option("coarse_adapt", 0)             # ... and with the first pass even where the first query found it weak
+    hi, hd = ix.query(X, k)
+    st2 = ix.last_stats()
+    ix.close()
     _check(gi, gd, oi, od)
     _check(hi, hd, oi, od)
-    assert kern.startswith("l2c_topk_kernel<2,1,%s>" % ("33,8,64,4" if geo == "a" else "23,6,32,8")), kern
+    assert kern.startswith("l2c_topk_kernel<2,1,%s>" % ("33,8,64,4,1" if geo == "a" else "23,6,32,4,2")), kern
     assert st2["seeded_pass_rows"] == 0 and st2["second_pass_rows"] == st["seeded_pass_rows"]
     if offset <= 0.5:
         assert st["seeded_pass_rows"] < m // 10          # well-centred data: the first pass answers (nearly) everything
@@ -990,23 +914,18 @@ def test_one_product_pass_chain_equals_the_oracle(gpu_lib, geo, offset):
 
 
 def test_seeded_pass_serves_most_of_what_the_first_pass_leaves(gpu_lib):
-    """Lists without slack (NABO_LKEEP = k': the threshold IS the k'-th kept one-product score, which lies below the k'-th exact
+    """Lists without slack (option lkeep = k': the threshold IS the k'-th kept one-product score, which lies below the k'-th exact
     distance) make the first pass fail nearly every row; the seeded pass -- every row starts from the threshold its failed
     certificate implies -- answers them without the f16x3 pass."""
     n, m, g, k = 60000, 5000, 50, 15
     Y = pca_like(n, g, seed=71)
     X = pca_like(m, g, seed=72)
     oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
-    os.environ["NABO_LKEEP"] = str(k)
-    os.environ["NABO_SPLITS"] = "1"                  # (one reference split: S splits would hand refine S lists per row)
-    try:
-        ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
-        gi, gd = ix.query(X, k)
-        st = ix.last_stats()
-        ix.close()
-    finally:
-        os.environ.pop("NABO_LKEEP", None)
-        os.environ.pop("NABO_SPLITS", None)
+    # (one reference split: S splits would hand refine S lists per row)
+    ix = gpu_lib.KnnIndex(n, g, metric=0, options={"lkeep": k, "splits": 1}).set_ref(Y)
+    gi, gd = ix.query(X, k)
+    st = ix.last_stats()
+    ix.close()
     _check(gi, gd, oi, od)
     assert st["seeded_pass_rows"] > m // 10, st
     assert st["second_pass_rows"] <= st["seeded_pass_rows"] // 20, st
@@ -1044,10 +963,9 @@ def test_large_reference_sets_take_more_splits(gpu_lib, monkeypatch, m, mode):
     X = pca_like(m, g, seed=92)
     rows = np.arange(m) if m <= 2000 else np.random.default_rng(3).choice(m, 600, replace=False)
     oi, od = oracle.knn(X[rows], Y, k, 0, nthreads=8)
-    monkeypatch.setenv("NABO_SPLIT_REFS_MAX", "5000")
     if mode:
         monkeypatch.setenv("NABO_L2_MODE", mode)
-    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
+    ix = gpu_lib.KnnIndex(n, g, metric=0, options={"split_refs_max": 5000}).set_ref(Y)
     gi, gd = ix.query(X, k)
     st = ix.last_stats()
     ix.close()
@@ -1084,7 +1002,7 @@ def test_one_product_pass_wide_lists_and_many_components(gpu_lib, m, n, g, k, dr
         return
     if g <= 125:
         ks = (g + 3 + 31) // 32
-        geo = "1,23,6,32,8" if (kk + 8 <= 23 and ks <= 2) else ("1,33,8,64,4" if kk <= 24 else "2,65,4,64,4")
+        geo = "1,23,6,32,4,2" if (kk + 8 <= 23 and ks <= 2) else ("1,33,8,64,4,1" if kk <= 24 else "2,65,4,64,4,1")
         assert kern.startswith("l2c_topk_kernel<%d,%s>" % (ks, geo)), kern
     else:
         assert kern.startswith("l2_topk_kernel"), kern
@@ -1182,7 +1100,7 @@ def test_row_pass_record_names_the_pass_that_answered_each_row(gpu_lib, monkeypa
 @pytest.mark.parametrize("m,n,g,k,drop,metric,splits", [(3000, 60000, 50, 15, 0, 0, "0"), (700, 200000, 50, 15, 0, 0, "0"),
                                                        (2500, 90000, 30, 40, 1, 0, "0"), (1500, 70000, 100, 50, 0, 2, "0"),
                                                        (900, 50000, 50, 15, 0, 0, "3"), (1200, 40000, 80, 11, 1, 2, "2")])
-def test_tournament_seeds_change_no_result(gpu_lib, monkeypatch, m, n, g, k, drop, metric, splits):
+def test_tournament_seeds_change_no_result(gpu_lib, m, n, g, k, drop, metric, splits):
     """l2c_pre_kernel (the one-product pass starts every list from an upper bound of its lkeep-th smallest score among the
     split's first references instead of +inf): results with it, with four times the planned tournament and without it are
     the same bits as the oracle's -- all three geometries, one to four operand steps, reference splits, the tail launch,
@@ -1190,11 +1108,9 @@ def test_tournament_seeds_change_no_result(gpu_lib, monkeypatch, m, n, g, k, dro
     Y = pca_like(n, g, seed=51)
     X = pca_like(m, g, seed=52) if not drop else Y[:m]
     oi, od = oracle.knn(X, Y, k, metric, drop_first=bool(drop), nthreads=16)
-    monkeypatch.setenv("NABO_SPLITS", splits)
     res = {}
     for pre in ("100", "400", "0"):
-        monkeypatch.setenv("NABO_PREPASS", pre)
-        ix = gpu_lib.KnnIndex(n, g, metric=metric).set_ref(Y)
+        ix = gpu_lib.KnnIndex(n, g, metric=metric, options={"splits": int(splits), "prepass": int(pre)}).set_ref(Y)
         gi, gd = ix.query(X, k, drop_first=bool(drop))
         res[pre] = ix.last_stats()
         assert "l2c_topk_kernel" in ix.last_kernel()
