@@ -54,16 +54,29 @@ constexpr int CBB_NW = 16;                // waves per workgroup (four per SIMD)
 constexpr int CBB_WLN = 128;              // work-list ring of a wave (entries)
 constexpr int CBB_DIM_BYTES = CBB_ROWS * 256;                          // the rows of one dimension of one block: 16 KiB
 constexpr int CBB_PAIR_BYTES = 2 * CBB_DIM_BYTES;                      // ... of a pair of dimensions: contiguous in the table
-constexpr int CBB_PIECES = CBB_PAIR_BYTES / 1024;                      // 1-KiB LDS-DMA pieces per pair: two per wave
+constexpr int CBB_PIECES = CBB_PAIR_BYTES / 1024;                      // 1-KiB LDS-DMA pieces per pair: two per wave (64 buckets)
 constexpr int CBB_ZERO_OFF = CBB_PAIR_BYTES;                           // the zero row ("row 0") behind the pair, never overwritten
 constexpr int CBB_BUF_BYTES = CBB_PAIR_BYTES + 256;                    // a row buffer in LDS
 constexpr int CBB_BUF1 = 65536;                                        // LDS offset of the second row buffer (one address bit)
-static_assert(CBB_PAIR_BYTES % 1024 == 0 && CBB_PIECES == 2 * CBB_NW, "two whole DMA pieces per wave and pair");
+static_assert(CBB_PAIR_BYTES % 1024 == 0, "whole DMA pieces");
+// Who requests the table pieces: waves 0 .. DMAW-1, CBB_PPW CONSECUTIVE 1-KiB pieces each (one M0 write, the instruction's
+// immediate offset moves the global AND the LDS address of the pieces behind the first).
+// (Tried in round 4 and dropped: an L2 prefetch of the pair three steps ahead -- a dword per lane and 128-byte line by LDS-DMA
+// into a scratch row, vmcnt leaving it in flight for a step: 544 -> 571 ms.  The pass is not waiting for table misses; its
+// SIMDs issue an instruction every 4.9 cycles, 82 % of what they can: what counts is the instruction count.)
+#ifndef NABO_CBB_DMAW
+#define NABO_CBB_DMAW 8          // (16 waves x 2 pieces: 527 ms at 1M x 1M; 8 x 4: 507)
+#endif
+constexpr int CBB_DMAW = NABO_CBB_DMAW;                                // waves 0 .. DMAW-1 request the table pieces
+constexpr int CBB_PPW = CBB_PIECES / CBB_DMAW;                         // consecutive pieces a DMA wave requests per pair
+static_assert(CBB_PIECES % CBB_DMAW == 0 && CBB_DMAW <= CBB_NW && CBB_PPW >= 1 && CBB_PPW <= 4, "pieces per DMA wave (13-bit immediate offset)");
 static_assert(CBB_BUF_BYTES <= CBB_BUF1 && CBB_BUF_BYTES <= 65536, "row addresses (16 bits) and the buffer bit must not overlap");
-// per-wave LDS block: ro2 [gp/2][T] uint2 | keys, idx [T][CAP] | tau, tidx, cnt, thr [T] | wl [WLN] u32 | wl_t [WLN] u8
-// (kept + pending list entries: 16 pending per 32 kept)
-constexpr int cbb_cap(int gp, int epl) { return 32 * epl + 16 * epl; }
-constexpr int cbb_wave_bytes(int gp, int epl) { return (gp / 2) * CBB_T * 8 + CBB_T * cbb_cap(gp, epl) * 8 + CBB_T * 16 + CBB_WLN * 5; }
+// per-wave LDS block: ro2 [npair <= gp/2][T] uint2 | keys, idx [T][CAP] | tau, tidx, cnt, thr [T] | wl [WLN] u32 | wl_t [WLN] u8
+// (kept + pending list entries: 16 (12) pending per 32 kept; ro2 entry npair repeats entry 0 -- gp / 2 entries hold it for every
+// g the kernel is instantiated for: g <= 63 < gp whenever gp / 2 == npair would be needed)
+constexpr int cbb_cap(int gp, int epl) { return 32 * epl + (gp >= 64 ? 12 : 16) * epl; }   // (gp = 64: the LDS budget)
+constexpr int cbb_ro2_pairs(int gp) { return gp / 2 + 1; }
+constexpr int cbb_wave_bytes(int gp, int epl) { return cbb_ro2_pairs(gp) * CBB_T * 8 + CBB_T * cbb_cap(gp, epl) * 8 + CBB_T * 16 + CBB_WLN * 5; }
 constexpr size_t cbb_lds_bytes(int gp, int epl)
 {
     const int wbytes = cbb_wave_bytes(gp, epl);
@@ -71,12 +84,15 @@ constexpr size_t cbb_lds_bytes(int gp, int epl)
     return (size_t)CBB_BUF1 + CBB_BUF_BYTES + (size_t)(CBB_NW > na ? CBB_NW - na : 0) * wbytes;
 }
 
+constexpr int cbb_gpad(int g) { return (g + 1) & ~1; }                 // dimensions per block in the table
 int cbb_buckets() { return CBB_B; }
 int cbb_rows_per_wg() { return CBB_T * CBB_NW; }
 size_t cbb_table_bytes(int64_t n, int g)
 {
-    // (+ one dimension of slack: with an odd g the kernel stages dimension g of the last block -- never used)
-    return ((size_t)((n + CBB_BLK - 1) / CBB_BLK) * g + 1) * CBB_ROWS * 64 * sizeof(uint32_t);
+    // a block holds an EVEN number of dimensions (an odd g: one dimension nobody writes or uses -- every target's rows there
+    // are (0, 0), the empty mask), so that the kernel's fetch pointer advances by one pair per step and nothing else;
+    // + one pair of slack: the step behind the last one requests a pair too
+    return ((size_t)((n + CBB_BLK - 1) / CBB_BLK) * cbb_gpad(g) + 2) * CBB_ROWS * 64 * sizeof(uint32_t);
 }
 size_t cbb_valid_bytes(int64_t n) { return (size_t)((n + CBB_BLK - 1) / CBB_BLK) * 64 * sizeof(uint32_t); }
 
@@ -108,7 +124,7 @@ __global__ __launch_bounds__(64) void cbb_pack_table_kernel(const double *__rest
     }
     // stored row r - 1 = cumulative row r = buckets 0 .. r - 1 (cumulative row 0, the empty set, is not stored)
     uint32_t acc = 0u;
-    uint32_t *o = tab + ((size_t)(blk * g + d) * CBB_ROWS) * 64 + w;
+    uint32_t *o = tab + ((size_t)(blk * cbb_gpad(g) + d) * CBB_ROWS) * 64 + w;
     for (int r = 0; r < CBB_B; ++r) {
         acc |= eq[r][w];
         o[(size_t)r * 64] = acc;
@@ -173,18 +189,39 @@ __device__ __forceinline__ float cbb_compact(float *kb, uint32_t *ib, int count,
     return __shfl(key[(L - 1) >> 6], (L - 1) & 63, 64);
 }
 
-// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to lds_dst + lane * 16 (M0 is written in the statement that
-// reads it and declared clobbered; hipcc neither counts nor drains this load -- the kernel waits for it itself: cbb_dma_wait).
-// (scalar base + 32-bit per-lane byte offset: the piece's address costs no vector instruction)
+// LDS-DMA: NP consecutive pieces of 64 lanes x 16 bytes from gbase + lane_off (+ 1024 per piece) to lds_dst + lane * 16 (+ 1024
+// per piece): M0 is written once, in the statement that reads it, and declared clobbered; the immediate offset of the
+// instruction is added to the global and to the LDS address alike.  hipcc neither counts nor drains these loads -- the
+// kernel waits for them itself (cbb_dma_wait).
+template <int NP>
 __device__ __forceinline__ void cbb_glds16(const void *gbase /* wave-uniform */, uint32_t lane_off, uint32_t lds_dst)
 {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
-                 : "v"(lane_off), "s"(gbase), "s"(lds_dst)
-                 : "memory", "m0");
+    static_assert(NP >= 1 && NP <= 4, "immediate offsets up to 3072");
+#ifdef NABO_CBB_M0PER            // (A/B: the immediate offset moving the global address only)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory", "m0");
+#pragma unroll
+    for (int pc = 1; pc < NP; ++pc)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" : : "v"(lane_off), "s"(gbase), "s"(lds_dst + pc * 1024u), "n"(pc * 1024) : "memory", "m0");
+#else
+    if constexpr (NP == 1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory", "m0");
+    else if constexpr (NP == 2)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                     : : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     : : "v"(lane_off), "s"(gbase), "s"(lds_dst) : "memory", "m0");
+    static_assert(NP != 3, "1, 2 or 4 pieces");
+#endif
 }
 __device__ __forceinline__ void cbb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+#ifdef NABO_CBB_NOBARRIER         // timing experiment (garbage results): the steps run without their workgroup barrier
+#define CBB_STEP_BARRIER() do { } while (0)
+#else
+#define CBB_STEP_BARRIER() __syncthreads()
+#endif
 typedef uint32_t cbb_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t cbb_u32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const cbb_u32x4 cbb_lds_u4;
@@ -224,11 +261,11 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     // LDS map: [0, BUF_BYTES) row buffer 0 | blocks of waves 0 .. NA-1 | [BUF1, BUF1 + BUF_BYTES) row buffer 1 | the other
     // waves' blocks.  A row buffer holds a PAIR of dimensions of the current block (2 x 65 rows x 256 B, padded to whole
     // 1-KiB DMA pieces); buffer 1 starts at 2^16 so that "which buffer" is one address bit that ORs with row and lane bits.
-    // per wave: ro2 [GP/2][T] uint2 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
+    // per wave: ro2 [GP/2 + 1][T] uint2 | keys [T][CAP] f32 | idx [T][CAP] u32 | tau [T] f32 | tidx [T] u32 | cnt [T] i32 | thr [T] u32 |
     //           wl [WLN] u32 | wl_t [WLN] u8
     unsigned char *wb = smem_raw + (wave < NA ? CBB_BUF_BYTES + wave * WAVE_BYTES : CBB_BUF1 + CBB_BUF_BYTES + (wave - NA) * WAVE_BYTES);
     uint2 *ro2 = reinterpret_cast<uint2 *>(wb);
-    float *keys = reinterpret_cast<float *>(ro2 + (GP / 2) * T);
+    float *keys = reinterpret_cast<float *>(ro2 + cbb_ro2_pairs(GP) * T);
     uint32_t *idxs = reinterpret_cast<uint32_t *>(keys + T * CAP);
     float *tau = reinterpret_cast<float *>(idxs + T * CAP);
     uint32_t *tidx = reinterpret_cast<uint32_t *>(tau + T);
@@ -261,8 +298,10 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     auto row_addr = [](uint32_t r, uint32_t half) -> uint32_t {
         return r ? (r - 1u) * 256u + half * (uint32_t)CBB_DIM_BYTES : (uint32_t)CBB_ZERO_OFF;
     };
-    for (int e = lane; e < (GP / 2) * T; e += 64) {
-        const int dp = e / T, t = e - dp * T;
+    const int npair = (g + 1) / 2;
+    for (int e = lane; e < (npair + 1) * T; e += 64) {       // entry npair = entry 0: the step behind a block's last is the next block's first
+        const int de = e / T, t = e - de * T;
+        const int dp = de == npair ? 0 : de;
         const int64_t row = row0 + t;
         uint32_t xa = 0u, xc = 0u;
         if (row < m) { xa = rowoff[row * GP + 2 * dp]; xc = rowoff[row * GP + 2 * dp + 1]; }
@@ -346,38 +385,44 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     int64_t b_end = b_begin + blocks_per_split;
     if (b_end > n_blocks) b_end = n_blocks;
     // The rows of dimensions 2 dp, 2 dp + 1 of block blk -- contiguous in the table, 32 KiB -- go to the row buffer the
-    // previous step has finished with as 32 LDS-DMA pieces of 1 KiB (wave w issues pieces w and w + 16): requested at the top
-    // of a step, waited for (every wave for its own pieces) in front of the step's ONE barrier.
-    // g odd: the last pair's second half is whatever follows in the table, with every target's rows (0, 0): an empty mask.
-    // The fetch stream is its own little state machine in scalar registers (the pairs are visited in table order): fsrc =
-    // this wave's first piece of the next pair to fetch, fdp its pair number inside its block, fleft the pairs still to fetch.
-    const int npair = (g + 1) / 2;
-    const unsigned char *fsrc = reinterpret_cast<const unsigned char *>(tab) + ((size_t)b_begin * g * ROWW) * 4 + wave * 1024;
-    int fdp = 0;
-    int fleft = b_begin < b_end ? (int)(b_end - b_begin) * npair : 0;       // (< 2^31: a split has < 2^26 blocks of <= 32 pairs)
+    // previous step has finished with as 32 LDS-DMA pieces of 1 KiB (DMA wave w: pieces PPW w .. PPW w + PPW - 1): requested
+    // at the top of a step, waited for (every wave for its own pieces) in front of the step's ONE barrier.  A block holds
+    // an even number of dimensions in the table (cbb_gpad) and the pairs are visited in table order, so the fetch stream is
+    // ONE scalar pointer that moves on by a pair per step; the step behind the split's last requests a pair nobody reads
+    // (the next split's first, or the table's slack).
+    const unsigned char *fsrc = reinterpret_cast<const unsigned char *>(tab) + ((size_t)b_begin * cbb_gpad(g) * ROWW) * 4 +
+                                (size_t)wave * (CBB_PPW * 1024);
     const uint32_t lane_off = (uint32_t)lane * 16u;
+    const bool dma_wave = CBB_DMAW == CBB_NW || wave < CBB_DMAW;
+    const uint32_t fdst = (uint32_t)wave * (uint32_t)(CBB_PPW * 1024);
+#ifdef NABO_CBB_NODMA            // timing experiment (garbage results): only the very first pair is ever fetched
+    bool fetched = false;
+#endif
     auto fetch = [&](int buf) {
-        if (fleft <= 0) return;
-        --fleft;
-        const uint32_t dst = ((uint32_t)buf << 16) + (uint32_t)wave * 1024u;
-        cbb_glds16(fsrc, lane_off, dst);
-        cbb_glds16(fsrc + NW * 1024, lane_off, dst + (uint32_t)NW * 1024u);
+#ifdef NABO_CBB_NODMA
+        if (!fetched)
+#endif
+        if (dma_wave) cbb_glds16<CBB_PPW>(fsrc, lane_off, ((uint32_t)buf << 16) + fdst);
+#ifdef NABO_CBB_DMA2X            // timing experiment (same results): every piece is requested twice
+        if (dma_wave) cbb_glds16<CBB_PPW>(fsrc, lane_off, ((uint32_t)buf << 16) + fdst);
+#endif
+#ifdef NABO_CBB_NODMA
+        fetched = true;
+#endif
         fsrc += CBB_PAIR_BYTES;
-        if (++fdp == npair) {                                // the next pair opens the next block: an odd g shares its last
-            fdp = 0;                                         // pair's second half with it
-            if (g & 1) fsrc -= CBB_DIM_BYTES;
-        }
     };
-    fetch(0);
+    if (b_begin < b_end) fetch(0);                           // (an empty split requests nothing: its range may lie past the table)
     cbb_u32x2 rnx[TS];                                      // row addresses of the step about to run (CBB_STEP)
 #pragma unroll
     for (int s = 0; s < TS; ++s) rnx[s] = cbb_u32x2{0u, 0u};
     cbb_dma_wait();
     __syncthreads();                                         // (also: ro2 and the zero rows are written)
+    const uint32_t ro_q = ro2_off + (uint32_t)(q * 8);       // this lane group's column of ro2
 #pragma unroll
-    for (int s = 0; s < TS; ++s) rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(ro2_off + (uint32_t)((4 * s + q) * 8));
+    for (int s = 0; s < TS; ++s) rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(ro_q + (uint32_t)(4 * s * 8));
     int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
+        uint32_t rp = ro_q;                                  // ro2 entry of the current group of steps (DPI = 0)
         uint32_t pl[TS][4][6];                               // bit-sliced counters: pl[s][w][b] = bit b of the 32 counts of word w
         uint32_t c2a[TS][4], c4a[TS][4];                     // carries waiting for their partner (weight 2, weight 4)
 #pragma unroll
@@ -391,9 +436,8 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
         // One step = one pair of dimensions.  ROLE: 0 / 2 first of two (the weight-2 carry waits), 1 second of two and first
         // of four (the weight-4 carry waits), 3 last of four (weight-8 carry ripples through planes 3..5), 5 second of two at
         // the end of an odd number of pairs-of-steps (the weight-4 carry ripples through planes 2..5), 4 a lone last step.
-#define CBB_STEP(DP, ROLE)                                                                                                   \
+#define CBB_STEP(DPI, ROLE)                                                                                                  \
         {                                                                                                                    \
-            const int dp_ = (DP);                                                                                            \
             /* the row addresses come from rnx, read from ro2 BEFORE the previous step's barrier: all eight row reads of the  \
                step leave at once, the table rows of the next step are requested while they fly, slot 1's rows arrive under   \
                slot 0's arithmetic */                                                                                        \
@@ -406,11 +450,9 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                 hB[s] = *(cbb_lds_u4 *)(uintptr_t)((rnx[s].y >> 16) | lb);                                                   \
             }                                                                                                                \
             fetch(buf ^ 1);                                                                                                  \
-            {   /* ro2 of the NEXT step (wave-private: no barrier needed) */                                                 \
-                const int dn_ = dp_ + 1 < npair ? dp_ + 1 : 0;                                                               \
-                _Pragma("unroll") for (int s = 0; s < TS; ++s)                                                               \
-                    rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(ro2_off + (uint32_t)((dn_ * T + 4 * s + q) * 8));                    \
-            }                                                                                                                \
+            /* ro2 of the NEXT step (wave-private: no barrier needed; constant offsets from the group's pointer) */          \
+            _Pragma("unroll") for (int s = 0; s < TS; ++s)                                                                   \
+                rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(rp + (uint32_t)((((DPI) + 1) * T + 4 * s) * 8));                         \
             _Pragma("unroll") for (int s = 0; s < TS; ++s) {                                                                 \
                 const uint32_t la_[4] = {lA[s].x, lA[s].y, lA[s].z, lA[s].w}, ha_[4] = {hA[s].x, hA[s].y, hA[s].z, hA[s].w}; \
                 const uint32_t lb_[4] = {lB[s].x, lB[s].y, lB[s].z, lB[s].w}, hb_[4] = {hB[s].x, hB[s].y, hB[s].z, hB[s].w}; \
@@ -461,43 +503,46 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                 __builtin_amdgcn_sched_barrier(0);                                                                           \
             }                                                                                                                \
             cbb_dma_wait();                                                                                                  \
-            __syncthreads();                                                                                                 \
+            CBB_STEP_BARRIER();                                                                                              \
             buf ^= 1;                                                                                                        \
         }
         int dp0 = 0;
         for (; dp0 + 4 <= npair; dp0 += 4) {
-            CBB_STEP(dp0, 0)
-            CBB_STEP(dp0 + 1, 1)
-            CBB_STEP(dp0 + 2, 2)
-            CBB_STEP(dp0 + 3, 3)
+            CBB_STEP(0, 0)
+            CBB_STEP(1, 1)
+            CBB_STEP(2, 2)
+            CBB_STEP(3, 3)
+            rp += (uint32_t)(4 * T * 8);
         }
         if (dp0 + 2 <= npair) {
-            CBB_STEP(dp0, 0)
-            CBB_STEP(dp0 + 1, 5)
+            CBB_STEP(0, 0)
+            CBB_STEP(1, 5)
+            rp += (uint32_t)(2 * T * 8);
             dp0 += 2;
         }
-        if (dp0 < npair) CBB_STEP(dp0, 4)
+        if (dp0 < npair) CBB_STEP(0, 4)
 #undef CBB_STEP
-        // inw >= thr ?  bit-sliced comparator per (slot, word) -- the threshold is the lane group's target's --, then the
-        // survivors into the ring, slot by slot and word by word
+        // inw >= thr ?  Adding K = 64 - thr to the six-plane count carries out of plane 5 exactly when inw + K >= 64: ONE
+        // majority per plane (the threshold's bits are per lane group: a register each, all ones or zero) instead of a
+        // greater / equal pair per plane.  thr = 0: everything survives (K = 64 has no bits below 64); thr >= 64: nothing.
         uint32_t gev[TS][4];
         const uint4 vmask = reinterpret_cast<const uint4 *>(vbits)[blk * 16 + sub];
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             const uint32_t thr_in = thr_l[4 * s + q];
-            uint32_t tb[6];
+            const uint32_t kk = (64u - thr_in) & 63u;
+            uint32_t kb[6];
 #pragma unroll
-            for (int b = 0; b < 6; ++b) tb[b] = (uint32_t)__builtin_amdgcn_sbfe((int)thr_in, b, 1);       // all ones where bit b is set
-            const uint32_t vm_[4] = {vmask.x, vmask.y, vmask.z, vmask.w};
+            for (int b = 0; b < 6; ++b) kb[b] = (uint32_t)__builtin_amdgcn_sbfe((int)kk, b, 1);           // all ones where bit b of K is set
+            const uint32_t all = thr_in == 0u ? 0xFFFFFFFFu : 0u;
+            const uint32_t some = thr_in < 64u ? 0xFFFFFFFFu : 0u;        // (selects, not branches: the lane groups differ)
+            const uint32_t vm_[4] = {vmask.x & some, vmask.y & some, vmask.z & some, vmask.w & some};
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                uint32_t gt = 0u, eq = 0xFFFFFFFFu;
+                uint32_t c = pl[s][w][0] & kb[0];
 #pragma unroll
-                for (int b = 5; b >= 0; --b) {
-                    gt |= eq & pl[s][w][b] & ~tb[b];
-                    eq &= ~(pl[s][w][b] ^ tb[b]);
-                }
-                gev[s][w] = thr_in < 64u ? ((gt | eq) & vm_[w]) : 0u;
+                for (int b = 1; b < 6; ++b) c = __builtin_amdgcn_bitop3_b32(pl[s][w][b], kb[b], c, 0xE8);
+                gev[s][w] = __builtin_amdgcn_bitop3_b32(c, all, vm_[w], 0xA8);      // (c | all) & vm
             }
         }
 #pragma unroll
@@ -524,6 +569,7 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
             }
         }
     }
+    cbb_dma_wait();                                          // (no LDS-DMA may outlive the workgroup's LDS)
     while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);
     // flush: the L smallest (key, index) per target; tau = L-th key if anything was ever dropped
     for (int t = 0; t < t_cnt; ++t) {
