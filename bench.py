@@ -439,6 +439,8 @@ def main():
                 line["alt_f16x3"] = alt_block(nabo_amd, _knn, "f16x3", dev, n, m, d, k, lay.dY, lay.dXb, gi, gd, lay.sync)
         if extras and a.metric == "euclidean" and (m, n) == (1000000, 1000000):
             line["canberra"] = canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, lay.dY, lay.dXb, X, Yfull, lay.sync)
+        if extras and a.metric == "euclidean" and (m, n) == (1000000, 1000000) and os.environ.get("NABO_BENCH_CONFIG4", "1") != "0":
+            line["config4_one_gpu"] = config4_block()
         if not a.no_cpu_baseline and kind == "single":
             line["cpu_baseline"] = cpu_baseline(d, k, metric_id)
             if extras:
@@ -448,6 +450,22 @@ def main():
     if comm is not None:
         comm.barrier()
         comm.close()
+
+
+def config4_block():
+    """BASELINE configs[4] run WHOLE on this one GPU (tools/config4_one_gpu.py: 5M x 5M, d=100, k=50, cosine -- unsharded, then
+    through nabo_sharded_query with 8 loopback shard-ranks, all rows compared -- the SNN graph and the 1000-permutation null
+    of the mapping scores on its ~190M edges).  Both are EXTENSIONS (no reference output exists for either): the times are
+    reported, parity is this build's own oracle's (tests/test_configs_gpu.py).  ~40 s; NABO_BENCH_CONFIG4=0 skips it."""
+    import importlib.util
+    try:
+        spec = importlib.util.spec_from_file_location("config4_one_gpu", os.path.join(REPO, "tools", "config4_one_gpu.py"))
+        c4 = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(c4)
+        rep, _ = c4.run(5000000, 5000000, 100, 50, ranks=8, perms=1000, keep=False)
+        return rep
+    except Exception as e:                      # (never costs the headline line)
+        return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
 def lay_n_shard(n, shards):

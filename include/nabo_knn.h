@@ -165,9 +165,11 @@ int nabo_index_last_row_pass(const nabo_index *ix, uint8_t *out, int64_t m);
  * (-1: another kernel), [2] target rows per workgroup, [3] / [4] workgroups (x) of the main / tail launch, [5] / [6] their
  * reference splits, [7] kept list entries, [8] emitted list length, [9] reference tiles per split, [10] / [11] tournament
  * tiles and tiles per group (0: no tournament), [12] workgroups resident at once, [13] workgroups launched in all,
- * [14] padded target rows, [15] operand steps of 16 slots.  kernel (optional): the kernel's name as nabo_index_last_kernel
+ * [14] padded target rows, [15] operand steps of 16 slots, [16] 1 when the launch is cut into PIECES (fewer column-
+ * workgroups than slots: [13] workgroups work through equal chunks of the (column, reference tile) space, [5] = lists per
+ * row, [9] = the longest a piece can be), [17] tiles per chunk.  kernel (optional): the kernel's name as nabo_index_last_kernel
  * reports it. */
-#define NABO_PLAN_FIELDS 16
+#define NABO_PLAN_FIELDS 18
 int nabo_query_plan(int64_t n_ref, int32_t g, int32_t metric, int64_t m, int32_t k, int32_t drop_first, int32_t n_cand,
                     int32_t n_cu, const char *l2_mode, const char *options, int64_t out[NABO_PLAN_FIELDS], char *kernel,
                     size_t kernel_len);

@@ -53,7 +53,7 @@ def knn(X, Y, k, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=F
 
 PLAN_FIELDS = ("first_pass", "geometry", "rows_per_wg", "workgroups_main", "workgroups_tail", "splits", "splits_tail", "lkeep",
                "list_len", "tiles_per_split", "tournament_tiles", "tournament_group", "resident_workgroups", "workgroups",
-               "rows_padded", "operand_steps")
+               "rows_padded", "operand_steps", "pieces", "piece_tiles")
 
 
 def query_plan(n_ref, g, m, k, metric=EUCLIDEAN, drop_first=False, n_cand=0, n_cu=256, l2_mode=None, options=None):

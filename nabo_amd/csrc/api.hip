@@ -38,12 +38,14 @@ int l2q_pick_kc1(int g);
 hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride = 0,
-                           int64_t tau_row0 = 0);
+                           int64_t tau_row0 = 0, const L2cPieces *pieces = nullptr);
 // tournament seeds for the one-product pass (l2c_topk.hip: l2c_pre_kernel)
 void l2c_pre_plan(int kc, int lkeep, int tiles_per_split, int scale_pct, int *pre_tiles, int *gt);
 hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                           int64_t rows, int64_t tile_off, int pre_tiles, int gt, int64_t pad_tile, hipStream_t st,
-                          int64_t rows_valid, float *tau_out);
+                          int64_t rows_valid, float *tau_out, const int *ranges = nullptr, int rows_per_col = 0);
+hipError_t merge_lists_launch(const uint32_t *cand_idx, const float *cand_key, const float *cand_tau, int64_t rows, int S, int L,
+                              int lkeep, uint32_t *out_idx, float *out_tau, hipStream_t st);
 int l2c_pick_kc(int g);
 int l2c_geometry(int kc, int lkeep_want, int pin);
 void l2c_topk_geometry(int kc, int lkeep_want, int pin, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
@@ -234,6 +236,8 @@ struct Options {
     int wide_retry = 1;        //   rows the 32-entry lists fail get 64-entry lists before the exact kernels
     int refine_overlap = 1;    // the refine of the main launch's rows runs beside the filter's tail launch
     int prepass = 100;         // tournament seeds: percent of the planned length (0: lists start from +inf)
+    int pieces = 1;            // fewer column-workgroups than slots: the launch is cut into equal pieces of (column, tile) space
+    int merge_lists = 1;       // several lists per row are merged by their filter keys before the float64 re-evaluation
     int l2c_geo = -1;          // pin the one-product kernel's geometry: 0 = A, 1 = B, 2 = C (-1: by list length)
     int l2_r1 = -1;            // fp32 filter: one row-block per wave (-1 auto, 0 never, 1 always)
     int split_refs_max = 0;    // lower the 2^25-references-per-split bound (tests see the rule at ordinary sizes)
@@ -247,7 +251,7 @@ const OptionName OPTION_NAMES[] = {
     {"splits", &Options::splits}, {"tail_split", &Options::tail_split}, {"lkeep", &Options::lkeep},
     {"coarse_slack", &Options::coarse_slack}, {"cand_slack", &Options::cand_slack}, {"seeded_pass", &Options::seeded_pass},
     {"coarse_adapt", &Options::coarse_adapt}, {"wide_retry", &Options::wide_retry}, {"refine_overlap", &Options::refine_overlap},
-    {"prepass", &Options::prepass}, {"l2c_geo", &Options::l2c_geo}, {"l2_r1", &Options::l2_r1},
+    {"prepass", &Options::prepass}, {"pieces", &Options::pieces}, {"merge_lists", &Options::merge_lists}, {"l2c_geo", &Options::l2c_geo}, {"l2_r1", &Options::l2_r1},
     {"split_refs_max", &Options::split_refs_max}, {"cosine_centre", &Options::cosine_centre},
     {"coarse_kernel_q", &Options::coarse_kernel_q}, {"order_flags", &Options::order_flags},
 };
@@ -347,6 +351,9 @@ struct nabo_index {
     DevBuf xfail, tmpi, tmpd, exact_d, fails2;
     DevBuf xfailp[2], tmpip[2], tmpdp[2], failsp[2], seedp[2], failseed;      // the same for passes 1 and 2 (the passes nest)
     DevBuf taupre, taupre2;                   // tournament seeds of the main / tail launch of the one-product pass [rows][S]
+    DevBuf cand_key, cand_key2, cand_mi, cand_mt, cand_mi2, cand_mt2;   // filter keys of the lists; merged lists (merge_lists_kernel)
+    DevBuf piecebuf;                          // a launch cut into pieces: pieces | ranges (int32)
+    std::vector<int> piece_host;              // ... its host image (alive until the query's last synchronisation)
     int64_t pre_tiles_last = 0;               // reference tiles per split the last query's tournament looked at (0: none)
     int cand_slack = 3;                       // candidate mode on the one-product pass: kept entries beyond the emitted ones
     int64_t pass_rows[3] = {0, 0, 0};         // rows of the last query sent to the seeded pass / the f16x3 pass / the 64-entry lists
@@ -823,9 +830,68 @@ struct L2Plan {
     int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = 32, lkeep = 16, want = 16;
     int S = 1, S2 = 1;                   // reference splits of the main / tail launch
     bool forced = false;                 // the split count is the caller's (option "splits")
+    bool pieces = false;                 // the launch is cut into pieces (cut_pieces): piece_wgs workgroups of ~piece_len tiles, S = lists per row
+    int piece_wgs = 0;
+    int64_t piece_len = 0;
     int64_t gx = 0, gx_main = 0, gx_tail = 0, rows_pad = 0, tps = 0, tps2 = 0;
     char kernel[160] = "";
 };
+
+// A launch with fewer column-workgroups (gx) than the chip has slots, cut into pieces: the linear space (column, reference
+// tile) of gx x T tiles goes to n_wg <= slots workgroups in equal chunks of ~C tiles (at least min_len: every piece warms
+// its lists up on its own), a chunk that crosses a column boundary is two pieces, and a boundary that would leave a sliver of
+// a column (< tiny tiles) is moved onto the column boundary.  Out: pieces (column, slot, t0, t1) in workgroup order,
+// wg_first [chunks + 1] (which pieces a chunk holds), count [gx] pieces per column, *n_wg_out pieces in all (one workgroup
+// each, l2c_topk.hip); returns the largest count (= lists per row, S).
+static int cut_pieces(int64_t gx, int64_t T, int64_t slots, int64_t min_len, int max_per_col, std::vector<int> *pieces,
+                      std::vector<int> *wg_first, std::vector<int> *count, int *n_wg_out, int64_t *len_out)
+{
+    const int64_t total = gx * T;
+    // (a column is cut at most floor(T / C) + 2 ways: chunks long enough that a row never has more than max_per_col lists)
+    if (max_per_col >= 3 && min_len < (T + max_per_col - 3) / (max_per_col - 2)) min_len = (T + max_per_col - 3) / (max_per_col - 2);
+    int64_t n_wg = total / (min_len > 0 ? min_len : 1);
+    if (n_wg > slots) n_wg = slots;
+    if (n_wg < gx) n_wg = gx < slots ? gx : slots;
+    if (n_wg < 1) n_wg = 1;
+    int64_t C = (total + n_wg - 1) / n_wg;
+    C = (C + 3) & ~(int64_t)3;
+    if (C > T && gx >= n_wg) C = T;                       // (one column per workgroup at most when there is nothing to balance)
+    const int64_t tiny = std::max<int64_t>(8, std::min<int64_t>(T / 4, C / 6));
+    std::vector<int64_t> cutpos;                          // chunk boundaries in linear tile space
+    cutpos.push_back(0);
+    for (int64_t b = C; b < total; b += C) {
+        int64_t bb = b;
+        const int64_t pos = bb % T;
+        if (pos != 0 && pos < tiny) bb -= pos;
+        else if (pos != 0 && T - pos < tiny) bb += T - pos;
+        if (bb > cutpos.back() && bb < total) cutpos.push_back(bb);
+    }
+    cutpos.push_back(total);
+    if (pieces) pieces->clear();
+    if (wg_first) wg_first->clear();
+    std::vector<int> cnt((size_t)gx, 0);
+    int np = 0, smax = 0;
+    for (size_t w = 0; w + 1 < cutpos.size(); ++w) {
+        if (wg_first) wg_first->push_back(np);
+        int64_t lin = cutpos[w];
+        while (lin < cutpos[w + 1]) {
+            const int64_t col = lin / T, t0 = lin % T;
+            const int64_t t1 = std::min<int64_t>(T, t0 + (cutpos[w + 1] - lin));
+            const int slot = cnt[(size_t)col]++;
+            if (pieces) { pieces->push_back((int)col); pieces->push_back(slot); pieces->push_back((int)t0); pieces->push_back((int)t1); }
+            ++np;
+            if (slot + 1 > smax) smax = slot + 1;
+            lin += t1 - t0;
+        }
+    }
+    if (wg_first) wg_first->push_back(np);
+    if (count) *count = cnt;
+    if (n_wg_out) *n_wg_out = np;                          // one workgroup per piece (chunks + column crossings)
+    if (len_out) *len_out = C;
+    return smax;
+}
+// shortest chunk of a cut launch, in reference tiles (30k x 30k, d = 50: four pieces of 234 tiles per column beat six and eight)
+static const int64_t PIECE_MIN_TILES = 192;
 
 static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_mode, L2Plan *P)
 {
@@ -922,7 +988,19 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
     int S2 = 1;
     int S = ix->opt.splits;
     const bool forced = S > 0;
-    if (!forced) {
+    bool pieces = false;
+    int piece_wgs = 0;
+    int64_t piece_len = 0;
+    if (!forced && on_l2c && ix->opt.pieces != 0 && ix->pass_level == 0 && !ix->wide_retry && gx < slots &&
+        ix->ref_tiles >= 64 && ix->ref_tiles * 32 < NABO_LIST_SPLIT_REFS &&
+        (ix->opt.split_refs_max < 64 || ix->ref_tiles * 32 < ix->opt.split_refs_max)) {
+        const int sp = cut_pieces(gx, ix->ref_tiles, slots, PIECE_MIN_TILES, 1024 / L, nullptr, nullptr, nullptr, &piece_wgs, &piece_len);
+        if (sp * L <= 1024) {                             // (merge / refine handle up to 1024 candidates per row)
+            pieces = true;
+            S = sp;
+        }
+    }
+    if (!forced && !pieces) {
         S = 1;
         if (gx < slots) {
             // Fewer workgroups than the chip holds: pick the split count from a cost model.  A workgroup costs
@@ -975,9 +1053,9 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
         if (S < s_min) S = (int)s_min;
         if (gx_tail > 0 && S2 < s_min) S2 = (int)s_min;
     }
-    const int64_t tps = (ix->ref_tiles + S - 1) / S;
+    const int64_t tps = pieces ? ix->ref_tiles : (ix->ref_tiles + S - 1) / S;      // (pieces: the longest a piece can be)
     const int64_t tps2 = (ix->ref_tiles + S2 - 1) / S2;
-    if (tps * S > ix->ref_tiles_alloc || tps2 * S2 > ix->ref_tiles_alloc)
+    if ((!pieces && tps * S > ix->ref_tiles_alloc) || tps2 * S2 > ix->ref_tiles_alloc)
         return fail(NABO_E_INVALID, "internal: split padding exceeds allocation");
 
     P->epl = epl; P->L = L;
@@ -985,6 +1063,7 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
     P->geo = geo; P->kcq = kcq; P->slack1 = slack1; P->cslack = cslack;
     P->rows_per_wg = rows_per_wg; P->wg_per_cu = wg_per_cu; P->lkeep_max = lkeep_max; P->lkeep = lkeep; P->want = want;
     P->S = S; P->S2 = S2; P->forced = forced;
+    P->pieces = pieces; P->piece_wgs = piece_wgs; P->piece_len = piece_len;
     P->gx = gx; P->gx_main = gx_main; P->gx_tail = gx_tail; P->rows_pad = rows_pad; P->tps = tps; P->tps2 = tps2;
     {
         // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
@@ -1159,6 +1238,9 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
         HIP_TRY(hipEventRecord(ix->ev[1], st));
         bool seedable = false;               // the l2c kernel ran: its failed rows can go through a seeded pass
         bool refine_beside_tail = false;
+        bool merge_main = false, merge_tail = false;
+        int64_t pieces_wgs = 0;
+        float *key_main = nullptr, *key_tail = nullptr;
 #ifdef NABO_EXPERIMENTS
         if (use_c) {
             if (gx_main > 0)
@@ -1177,7 +1259,77 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const bool coarse_on_q = !on_l2c;
             seedable = use_1 && !coarse_on_q && !cand_mode && ix->opt.seeded_pass != 0;
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
-            if (use_1 && !coarse_on_q) {
+            // Several lists per row (reference splits, pieces, the tail round): the l2c kernel also emits the entries' filter
+            // keys and merge_lists_kernel reduces the lists to the ONE a single stream would have kept (refine.hip)
+            merge_main = on_l2c && S > 1 && gx_main > 0 && ix->opt.merge_lists != 0;
+            merge_tail = on_l2c && S2 > 1 && gx_tail > 0 && ix->opt.merge_lists != 0;
+            if (merge_main) {
+                if ((rc = ix->cand_key.reserve((size_t)rows_main * S * L * sizeof(float)))) return rc;
+                if ((rc = ix->cand_mi.reserve((size_t)rows_main * L * sizeof(uint32_t)))) return rc;
+                if ((rc = ix->cand_mt.reserve((size_t)rows_main * sizeof(float)))) return rc;
+                key_main = ix->cand_key.as<float>();
+            }
+            if (merge_tail) {
+                if ((rc = ix->cand_key2.reserve((size_t)rows_tail * S2 * L * sizeof(float)))) return rc;
+                if ((rc = ix->cand_mi2.reserve((size_t)rows_tail * L * sizeof(uint32_t)))) return rc;
+                if ((rc = ix->cand_mt2.reserve((size_t)rows_tail * sizeof(float)))) return rc;
+                key_tail = ix->cand_key2.as<float>();
+            }
+            if (use_1 && !coarse_on_q && P.pieces) {
+                // A launch cut into pieces (cut_pieces): the tables go to the device, unused list slots read as empty lists
+                // with threshold +inf, every piece's tournament looks at its own first tiles.
+                std::vector<int> pcs_h, first_h, count_h;
+                int n_wg = 0;
+                int64_t plen = 0;
+                const int sp = cut_pieces(gx_main, ix->ref_tiles, (int64_t)ix->n_cu * P.wg_per_cu, PIECE_MIN_TILES, 1024 / L, &pcs_h, &first_h, &count_h, &n_wg, &plen);
+                if (sp != S) return fail(NABO_E_INVALID, "internal: piece plan changed between planning and launch");
+                std::vector<int> ranges_h((size_t)gx_main * S * 4, 0);
+                const int pre_pct = ix->opt.prepass;
+                bool any_pre = false;
+                for (size_t i = 0; i + 3 < pcs_h.size(); i += 4) {
+                    int pt = 0, gt = 2;
+                    if (pre_pct > 0) nabo::l2c_pre_plan(kcq, lkeep, pcs_h[i + 3] - pcs_h[i + 2], pre_pct, &pt, &gt);
+                    int *r = &ranges_h[((size_t)pcs_h[i] * S + pcs_h[i + 1]) * 4];
+                    r[0] = pcs_h[i + 2]; r[1] = pcs_h[i + 3]; r[2] = pt; r[3] = gt;
+                    any_pre = any_pre || pt > 0;
+                }
+                // one workgroup per piece, longest first (the slots that finish a short piece pick up the next one)
+                std::vector<int> order(pcs_h.size() / 4);
+                for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                    return pcs_h[4 * a + 3] - pcs_h[4 * a + 2] > pcs_h[4 * b + 3] - pcs_h[4 * b + 2];
+                });
+                std::vector<int> &img = ix->piece_host;        // (alive until the query's last synchronisation)
+                img.clear();
+                for (int i : order) img.insert(img.end(), pcs_h.begin() + 4 * i, pcs_h.begin() + 4 * i + 4);
+                const size_t off_ranges = img.size();
+                img.insert(img.end(), ranges_h.begin(), ranges_h.end());
+                if ((rc = ix->piecebuf.reserve(img.size() * sizeof(int)))) return rc;
+                HIP_TRY(hipMemcpyAsync(ix->piecebuf.p, img.data(), img.size() * sizeof(int), hipMemcpyHostToDevice, st));
+                L2cPieces pcs;
+                pcs.pieces = ix->piecebuf.as<int>();
+                pcs.n_pieces = (int)order.size();
+                pieces_wgs = pcs.n_pieces;
+                pcs.ranges = ix->piecebuf.as<int>() + off_ranges;
+                pcs.rows_per_col = rows_per_wg;
+                HIP_TRY(hipMemsetAsync(ix->cand_idx.p, 0xFF, (size_t)rows_main * S * L * sizeof(uint32_t), st));
+                HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->cand_tau.p), 0x7F800000, (size_t)rows_main * S, st));
+                const float *seeds_main = nullptr;
+                int stride_main = 0;
+                if (ix->pass_level == 0 && !ix->wide_retry) ix->pre_tiles_last = 0;
+                if (any_pre) {
+                    if ((rc = ix->taupre.reserve((size_t)rows_main * S * sizeof(float)))) return rc;
+                    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ix->taupre.p), 0x7F800000, (size_t)rows_main * S, st));
+                    HIP_TRY(nabo::l2c_pre_launch(kcq, lkeep, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, rows_main, 0, 0, 2,
+                                                 ix->ref_tiles_alloc - 1, st, m, ix->taupre.as<float>(), pcs.ranges, rows_per_wg));
+                    seeds_main = ix->taupre.as<float>();
+                    stride_main = S;
+                    if (ix->pass_level == 0 && !ix->wide_retry) ix->pre_tiles_last = ranges_h[2];
+                }
+                HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
+                                              ix->cand_idx.as<uint32_t>(), key_main, ix->cand_tau.as<float>(),
+                                              ix->ref_tiles_alloc - 1, st, m, seeds_main, stride_main, 0, &pcs));
+            } else if (use_1 && !coarse_on_q) {
                 // Tournament seeds (l2c_topk.hip: l2c_pre_kernel): every (row, split) list starts from an upper bound of its
                 // lkeep-th smallest score among the split's first references instead of +inf -- not for a pass that has its
                 // seeds already.  NABO_PREPASS: 0 off, otherwise percent of the planned length (A/B runs; same bits always).
@@ -1207,7 +1359,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 }
                 if (gx_main > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps, S, (int)gx_main, 0, lkeep,
-                                                  ix->cand_idx.as<uint32_t>(), nullptr, ix->cand_tau.as<float>(),
+                                                  ix->cand_idx.as<uint32_t>(), key_main, ix->cand_tau.as<float>(),
                                                   ix->ref_tiles_alloc - 1, st, m, seeds_main, stride_main, 0));
                 // the tail launch (a fraction of a round, reference splits) leaves most CUs idle: the refine of the main
                 // launch's rows (an HBM gather) runs beside it on the second stream
@@ -1217,7 +1369,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                 }
                 if (gx_tail > 0)
                     HIP_TRY(nabo::l2c_topk_launch(kcq, geo, ix->xpk.as<unsigned char>(), ytiles, (int)tps2, S2, (int)gx_tail,
-                                                  rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), nullptr,
+                                                  rows_main / 32, lkeep, ix->cand_idx2.as<uint32_t>(), key_tail,
                                                   ix->cand_tau2.as<float>(), ix->ref_tiles_alloc - 1, st, m, seeds_tail, stride_tail,
                                                   rows_main));
             } else {
@@ -1275,13 +1427,31 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
         const double tau_scale = use_h ? 1.0 / (ix->hscale * ix->hscale) : 1.0 / (ix->fscale * ix->fscale);
         const double ymax_sqrt = use_h ? ix->ymax_sqrt_c : ix->ymax_sqrt;
         const int64_t m_main = rows_main < m ? rows_main : m;
+        // what the float64 re-evaluation reads: the filter's lists, or ONE merged list per row (merge_lists_kernel)
+        const uint32_t *ci_main = ix->cand_idx.as<uint32_t>(), *ci_tail = ix->cand_idx2.as<uint32_t>();
+        const float *ct_main = ix->cand_tau.as<float>(), *ct_tail = ix->cand_tau2.as<float>();
+        int S_main = S, S_tail = S2;
+        auto merge_lists = [&](bool tail, hipStream_t sm) -> hipError_t {
+            if (tail) {
+                hipError_t e = nabo::merge_lists_launch(ix->cand_idx2.as<uint32_t>(), key_tail, ix->cand_tau2.as<float>(), m - rows_main, S2, L,
+                                                        lkeep, ix->cand_mi2.as<uint32_t>(), ix->cand_mt2.as<float>(), sm);
+                ci_tail = ix->cand_mi2.as<uint32_t>(); ct_tail = ix->cand_mt2.as<float>(); S_tail = 1;
+                return e;
+            }
+            hipError_t e = nabo::merge_lists_launch(ix->cand_idx.as<uint32_t>(), key_main, ix->cand_tau.as<float>(), m_main, S, L, lkeep,
+                                                    ix->cand_mi.as<uint32_t>(), ix->cand_mt.as<float>(), sm);
+            ci_main = ix->cand_mi.as<uint32_t>(); ct_main = ix->cand_mt.as<float>(); S_main = 1;
+            return e;
+        };
         if (cand_mode) {
-            HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(),
-                                             S, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
+            if (merge_main) HIP_TRY(merge_lists(false, st));
+            if (merge_tail) HIP_TRY(merge_lists(true, st));
+            HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ci_main, ct_main,
+                                             S_main, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
                                              n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0, lkeep, rperm, tperm));
             if (gx_tail > 0)
-                HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
-                                                 ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
+                HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ci_tail,
+                                                 ct_tail, S_tail, L, ix->xnorm.as<double>(), err_coef,
                                                  ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st,
                                                  cosine ? 2 : 0, lkeep, rperm, tperm));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
@@ -1311,15 +1481,17 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             st_main = ix->stream2;
             HIP_TRY(hipStreamWaitEvent(st_main, ix->ev_main, 0));
         }
-        HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ix->cand_idx.as<uint32_t>(), ix->cand_tau.as<float>(), S, L,
+        if (merge_main) HIP_TRY(merge_lists(false, st_main));
+        HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ci_main, ct_main, S_main, L,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st_main, cosine ? 2 : 0, 0.0, 0.0f,
                                     lkeep, rperm, tperm, fail_seed));
         if (refine_beside_tail) HIP_TRY(hipEventRecord(ix->ev_ref, st_main));
+        if (merge_tail) HIP_TRY(merge_lists(true, st));
         if (gx_tail > 0)
-            HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ix->cand_idx2.as<uint32_t>(),
-                                        ix->cand_tau2.as<float>(), S2, L, ix->xnorm.as<double>(), err_coef,
+            HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ci_tail,
+                                        ct_tail, S_tail, L, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
                                         ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep, rperm, tperm,
@@ -1411,7 +1583,7 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
                                             d_oidx, d_odist, ix->exact_d.as<double>(), (unsigned int)d_rows, st));
         }
         HIP_TRY(hipEventRecord(ix->ev[4], st));
-        n_wg = gx_main * S + gx_tail * S2;
+        n_wg = pieces_wgs ? pieces_wgs : gx_main * S + gx_tail * S2;
         if (retried) { ix->ms_keep[0] = ms_first[0]; ix->ms_keep[1] = ms_first[1]; ix->ms_keep[2] = ms_first[2]; ix->ms_keep_valid = true; }
     } else {
         const int64_t n_chunks = (ix->n + 63) / 64;
@@ -1699,7 +1871,7 @@ int nabo_query_plan(int64_t n_ref, int32_t g, int32_t metric, int64_t m, int32_t
     int rc = plan_l2(&ix, m, kq, cand ? 0 : drop, cand, &P);
     if (rc) return rc;
     int pt = 0, gt = 0;
-    if (P.on_l2c && ix.opt.prepass > 0) nabo::l2c_pre_plan(P.kcq, P.lkeep, (int)P.tps, ix.opt.prepass, &pt, &gt);
+    if (P.on_l2c && ix.opt.prepass > 0) nabo::l2c_pre_plan(P.kcq, P.lkeep, (int)(P.pieces ? P.piece_len : P.tps), ix.opt.prepass, &pt, &gt);
     out[0] = P.use_1 ? NABO_PASS_ONE_PRODUCT : NABO_PASS_SECOND;
     out[1] = P.geo;
     out[2] = P.rows_per_wg;
@@ -1713,9 +1885,11 @@ int nabo_query_plan(int64_t n_ref, int32_t g, int32_t metric, int64_t m, int32_t
     out[10] = pt;
     out[11] = gt;
     out[12] = (int64_t)n_cu * P.wg_per_cu;
-    out[13] = P.gx_main * P.S + P.gx_tail * P.S2;
+    out[13] = P.pieces ? P.piece_wgs : P.gx_main * P.S + P.gx_tail * P.S2;
     out[14] = P.rows_pad;
     out[15] = P.kcq;
+    out[16] = P.pieces ? 1 : 0;
+    out[17] = P.piece_len;
     if (kernel && kernel_len) snprintf(kernel, kernel_len, "%s", P.kernel);
     return NABO_OK;
 }

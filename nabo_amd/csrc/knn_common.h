@@ -8,6 +8,13 @@
 // split, all ones = "no reference"; api.hip raises the split count of larger sets
 #define NABO_LIST_SPLIT_REFS (((int64_t)1 << 25) - 1)
 
+// A filter launch cut into PIECES (l2c_topk.hip; api.hip: cut_pieces): device arrays.
+//   pieces   [n_pieces] int4 (column-workgroup, list slot of that column, first reference tile, end tile), one workgroup each,
+//            longest first
+//   ranges   [columns x S] int4 (first tile, end tile, tournament tiles, tiles per tournament group) per (column, slot);
+//            an unused slot is (0, 0, 0, 0)
+struct L2cPieces { const int *pieces; int n_pieces; const int *ranges = nullptr; int rows_per_col = 0; };
+
 namespace nabo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

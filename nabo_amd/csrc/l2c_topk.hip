@@ -285,7 +285,7 @@ __device__ __forceinline__ void cstage2(const cacc &acc, const cmins &m, int p, 
 // 2: 256 registers, a ring of two).  Geometry B is WAVES = 4, WPS = 2: TWO 384-row workgroups per CU -- the same occupancy
 // as one 768-row workgroup of eight waves, at half the granularity: 100k target rows are 261 workgroups on 512 slots (every
 // CU busy, each wave alone on its SIMD) instead of 131 on 256 (half the chip idle), and the last round of a long query is cut finer.
-template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES, int WPS>
+template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES, int WPS, bool PCS = false>
 __global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigned char *__restrict__ Xpk,
                                                           const unsigned char *__restrict__ Ypk,
                                                           int tiles_per_split, int64_t tile_off, int lkeep,
@@ -293,8 +293,15 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigne
                                                           float *__restrict__ cand_key,
                                                           float *__restrict__ cand_tau, int64_t pad_tile, int dbg_arg,
                                                           int64_t rows_valid, const float *__restrict__ tau_init,
-                                                          int tau_stride, int64_t tau_row0)
+                                                          int tau_stride, int64_t tau_row0,
+                                                          const int4 *__restrict__ pieces, int piece_S)
 {
+    // PIECES (api.hip: cut_pieces): with fewer column-workgroups than the chip has slots a launch of (columns x splits)
+    // workgroups either leaves slots empty or spills a few workgroups into a second round that costs as much as the first.
+    // Instead the linear space (column, reference tile) is cut into ~`slots` equal chunks, a chunk that crosses a column
+    // boundary into two pieces, and the launch is ONE WORKGROUP PER PIECE = (column, list slot of the column, first tile, end
+    // tile), longest first: the slots that finish a short piece pick up the next one.  Every piece has its own lists,
+    // thresholds and emitted list (row, slot) of piece_S.
     // dbg: timing ablations of the experiment builds (knn_common.h: debug_ablate; the shipped library always passes 0).
     // The four-step kernel on the 64-entry lists keeps it a RUN-TIME value in the product build too: with the ablation
     // selects compiled in -- a few scalar instructions and never-taken branches per tile, same loads, same waits, same
@@ -317,9 +324,14 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigne
     const int lane = lane_id();
     const int lq = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int split = blockIdx.y;
-    const int S = gridDim.y;
-    const int64_t ltile0 = ((int64_t)blockIdx.x * WAVES + wave) * (NB / 2);  // in 32-row tiles
+    // (PCS: its own instantiation; one workgroup per piece, longest pieces first -- a loop over a chunk's pieces inside the
+    // kernel kept every kernel argument alive to the end and cost the 256-register geometry spills in its staging path)
+    int4 piece = make_int4((int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.y * tiles_per_split, ((int)blockIdx.y + 1) * tiles_per_split);
+    if (PCS) piece = pieces[blockIdx.x];
+    const int colx = PCS ? __builtin_amdgcn_readfirstlane(piece.x) : (int)blockIdx.x;
+    const int split = PCS ? __builtin_amdgcn_readfirstlane(piece.y) : (int)blockIdx.y;
+    const int S = PCS ? piece_S : (int)gridDim.y;
+    const int64_t ltile0 = ((int64_t)colx * WAVES + wave) * (NB / 2);        // in 32-row tiles
     const int64_t ttile0 = tile_off + ltile0;
 
     f16x8 xb[NB][KS];
@@ -360,7 +372,9 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigne
         tauv[rb] = r < rows_valid ? ((tau_init && !(dbg & 1)) ? seed_of(r) : tau0) : -__builtin_inff();
     }
     uint32_t scnt = 0;
-    lists_init<C>(wl, lkeep, tau0, (uint32_t)split * (uint32_t)tiles_per_split * 32u);
+    const int t_begin = PCS ? __builtin_amdgcn_readfirstlane(piece.z) : split * tiles_per_split;
+    const int t_end = PCS ? __builtin_amdgcn_readfirstlane(piece.w) : t_begin + tiles_per_split;
+    lists_init<C>(wl, lkeep, tau0, (uint32_t)t_begin * 32u);
     {
         const int64_t nv = rows_valid - row0;            // valid rows of this wave
         if (nv < C::NROWS)
@@ -383,8 +397,6 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigne
         }
     }
 
-    const int t_begin = split * tiles_per_split;
-    const int t_end = t_begin + tiles_per_split;
     // past the split's last tile: an all-padding tile (+inf norms, nothing passes) -- the loop runs in fours (twos)
     auto tile_ptr = [&](int ts) {
         const int64_t tc = ts < t_end ? (int64_t)ts : pad_tile;
@@ -543,7 +555,8 @@ __global__ __launch_bounds__(64 * WAVES, WPS) void l2c_topk_kernel(const unsigne
 template <int KS, int NB, int QM>
 __global__ __launch_bounds__(256) void l2c_pre_kernel(const unsigned char *__restrict__ Xpk, const unsigned char *__restrict__ Ypk,
                                                       int tiles_per_split, int64_t tile_off, int64_t rows, int pre_tiles, int gt,
-                                                      int q, int64_t pad_tile, int64_t rows_valid, float *__restrict__ tau_out)
+                                                      int q, int64_t pad_tile, int64_t rows_valid, float *__restrict__ tau_out,
+                                                      const int4 *__restrict__ ranges, int rows_per_col)
 {
     constexpr int NP = NB / 2;
     constexpr int TB = 2 * KS * 1024;
@@ -567,7 +580,18 @@ __global__ __launch_bounds__(256) void l2c_pre_kernel(const unsigned char *__res
     for (int rb = 0; rb < NB; ++rb)
 #pragma unroll
         for (int j = 0; j < QM; ++j) srt[rb][j] = __builtin_inff();
-    const int t_begin = split * tiles_per_split, t_end = t_begin + tiles_per_split;
+    int t_begin = split * tiles_per_split, t_end = t_begin + tiles_per_split;
+    if (ranges) {
+        // a launch cut into pieces: the tournament of (column, slot) looks at the first tiles of THAT piece (a wave's rows lie
+        // in one column: the columns are whole multiples of a wave's rows); no tournament for a short or unused piece --
+        // its seeds stay +inf (the caller's fill)
+        const int4 r = ranges[(ltile0 * 32 / rows_per_col) * S + split];
+        t_begin = __builtin_amdgcn_readfirstlane(r.x);
+        t_end = __builtin_amdgcn_readfirstlane(r.y);
+        pre_tiles = __builtin_amdgcn_readfirstlane(r.z);
+        gt = __builtin_amdgcn_readfirstlane(r.w);
+        if (pre_tiles <= 0) return;
+    }
     auto tile_load = [&](f16x8(&a)[2][KS], int ts) {
         const f16x8 *p = reinterpret_cast<const f16x8 *>(Ypk + (ts < t_end ? (int64_t)ts : pad_tile) * TB);
 #pragma unroll
@@ -624,11 +648,13 @@ __global__ __launch_bounds__(256) void l2c_pre_kernel(const unsigned char *__res
 template <int KS, int NB, int QM>
 static hipError_t cpre_launch(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int64_t rows,
                               int64_t tile_off, int pre_tiles, int gt, int q, int64_t pad_tile, hipStream_t st,
-                              int64_t rows_valid, float *tau_out)
+                              int64_t rows_valid, float *tau_out, const int *ranges, int rows_per_col)
 {
     const int64_t gx = (rows + 4 * NB * 16 - 1) / (4 * NB * 16);
+    if (ranges && (rows_per_col <= 0 || rows_per_col % (NB * 16) != 0)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((l2c_pre_kernel<KS, NB, QM>), dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, Xpk, Ypk, tiles_per_split,
-                       tile_off, rows, pre_tiles, gt, q, pad_tile, rows_valid, tau_out);
+                       tile_off, rows, pre_tiles, gt, q, pad_tile, rows_valid, tau_out, reinterpret_cast<const int4 *>(ranges),
+                       rows_per_col);
     return hipGetLastError();
 }
 
@@ -654,17 +680,18 @@ void l2c_pre_plan(int kc, int lkeep, int tiles_per_split, int scale_pct, int *pr
 // tau_out [rows][S] (rows local to this launch: row tile_off * 32 of the query is row 0), rows_valid as in l2c_topk_launch
 hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                           int64_t rows, int64_t tile_off, int pre_tiles, int gt, int64_t pad_tile, hipStream_t st,
-                          int64_t rows_valid, float *tau_out)
+                          int64_t rows_valid, float *tau_out, const int *ranges, int rows_per_col)
 {
     const int q = (lkeep + 3) / 4;
-    if (pre_tiles <= 0 || gt < 2 || (gt & 1) || pre_tiles % gt || pre_tiles > tiles_per_split || q < 1 || q > 16 || rows <= 0)
-        return hipErrorInvalidValue;
+    // (ranges: every (column, slot) brings its own tournament length -- l2c_pre_plan's, checked by the planner)
+    if (!ranges && (pre_tiles <= 0 || gt < 2 || (gt & 1) || pre_tiles % gt || pre_tiles > tiles_per_split)) return hipErrorInvalidValue;
+    if (q < 1 || q > 16 || rows <= 0) return hipErrorInvalidValue;
 #define NABO_PRE(KSV)                                                                                                               \
     case 2 * KSV:                                                                                                                   \
         return q <= 8 ? cpre_launch<KSV, (KSV <= 2 ? 8 : 4), 8>(Xpk, Ypk, tiles_per_split, S, rows, tile_off, pre_tiles, gt, q, pad_tile, \
-                                                              st, rows_valid, tau_out)                                             \
+                                                              st, rows_valid, tau_out, ranges, rows_per_col)                       \
                       : cpre_launch<KSV, 4, 16>(Xpk, Ypk, tiles_per_split, S, rows, tile_off, pre_tiles, gt, q, pad_tile, st,     \
-                                                rows_valid, tau_out);
+                                                rows_valid, tau_out, ranges, rows_per_col);
     switch (kc) {
         NABO_PRE(1) NABO_PRE(2) NABO_PRE(3) NABO_PRE(4)
     default: return hipErrorInvalidValue;
@@ -676,17 +703,28 @@ template <int KS, int EPL, int ROWN, int NBv, int NRECv, int WAVES, int WPS>
 static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
-                              int64_t tau_row0)
+                              int64_t tau_row0, const L2cPieces &pcs)
 {
     const int dbg = debug_ablate();
     constexpr size_t lds = (size_t)WAVES * ListCfg<EPL, ROWN, NBv, NRECv, 16, (ROWN >= 64)>::BYTES;
     static_assert(lds <= 163840, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    dim3 grid(gx, S), block(64 * WAVES);
-    hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS>), grid, block, lds, st, Xpk, Ypk, tiles_per_split, tile_off, lkeep,
-                       cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride, tau_row0);
+    dim3 block(64 * WAVES);
+    if (pcs.pieces) {
+        // pieces: one workgroup per chunk of the (column, tile) space; gx / S then only describe the emitted lists
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, true>), dim3(pcs.n_pieces, 1), block, lds, st, Xpk, Ypk,
+                           tiles_per_split, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride,
+                           tau_row0, reinterpret_cast<const int4 *>(pcs.pieces), S);
+    } else {
+        hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, false>), dim3(gx, S), block, lds, st, Xpk, Ypk,
+                           tiles_per_split, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride,
+                           tau_row0, nullptr, S);
+    }
 #ifdef NABO_LISTS_PROF
     {
         unsigned long long h[8];
@@ -703,18 +741,18 @@ template <int KS>
 static hipError_t claunch_one(int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S, int gx,
                               int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                               int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
-                              int64_t tau_row0)
+                              int64_t tau_row0, const L2cPieces &pcs)
 {
     if constexpr (KS <= 2) {
         if (geo == 1)
             return claunch_geo<KS, 1, L2C_ROW_B, 6, L2C_NREC_B, 4, 2>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx,
-                                                                  cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+                                                                  cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
     }
     if (geo == 2)
         return claunch_geo<KS, 2, L2C_ROW_C, 4, L2C_NREC, 4, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key,
-                                                            cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+                                                            cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
     return claunch_geo<KS, 1, L2C_ROW, 8, L2C_NREC, 4, 1>(Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau,
-                                                      pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+                                                      pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
 }
 
 // Which geometry serves lists of `lkeep_want` kept entries: 1 = B (two waves per SIMD) up to 23 entries and KS <= 2 (its
@@ -751,16 +789,18 @@ int l2c_pick_kc(int g)
 hipError_t l2c_topk_launch(int kc, int geo, const unsigned char *Xpk, const unsigned char *Ypk, int tiles_per_split, int S,
                            int gx, int64_t tile_off, int lkeep, uint32_t *cand_idx, float *cand_key, float *cand_tau,
                            int64_t pad_tile, hipStream_t st, int64_t rows_valid, const float *tau_init, int tau_stride,
-                           int64_t tau_row0)
+                           int64_t tau_row0, const L2cPieces *pieces)
 {
+    const L2cPieces pcs = pieces ? *pieces : L2cPieces{nullptr, 0, nullptr, 0};
+    if (pcs.pieces && pcs.n_pieces < 1) return hipErrorInvalidValue;
     if ((int64_t)tiles_per_split * 32 >= NABO_LIST_SPLIT_REFS) return hipErrorInvalidValue;   // topk_lists.h: 25 bits of offset per entry
     if (geo < 0 || geo > 2 || (geo == 1 && (kc > 4 || lkeep > L2C_ROW_B)) || (geo == 0 && lkeep > 32) || lkeep > 64)
         return hipErrorInvalidValue;
     switch (kc) {
-    case 2: return claunch_one<1>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
-    case 4: return claunch_one<2>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
-    case 6: return claunch_one<3>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
-    case 8: return claunch_one<4>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0);
+    case 2: return claunch_one<1>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
+    case 4: return claunch_one<2>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
+    case 6: return claunch_one<3>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
+    case 8: return claunch_one<4>(geo, Xpk, Ypk, tiles_per_split, S, gx, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, st, rows_valid, tau_init, tau_stride, tau_row0, pcs);
     default: return hipErrorInvalidValue;
     }
 }

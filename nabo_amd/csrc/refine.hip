@@ -141,6 +141,34 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 // STAGE (NCL == 1, g <= 64): candidate rows are fetched by the whole wave, one coalesced g*8-byte read per candidate,
 // into a wave-private LDS block and each lane then evaluates ITS candidate from LDS, in the reference's component
 // order -- a lane walking its own row in global memory moved 8 bytes per 64-byte request (1.15 TB/s at 1M rows).
+// The staged gather of refine_kernel / refine_cand_kernel: the candidates' rows (lane `src` of `live` holds candidate myj),
+// g * 8 coalesced bytes each, into rows 0, 1, .. of the wave's LDS block -- EIGHT rows requested before the first one is
+// stored.  (One load, its wait, its store per candidate made a row's refine 23 memory latencies long: 7 ms for the 1M rows of
+// the headline where the bytes moved need ~2.5.)
+__device__ __forceinline__ void stage_rows_to_lds(const double *__restrict__ Y, int g, int gp, double *stg, int stage_rows,
+                                                  uint32_t myj, uint64_t live)
+{
+    const int lane = lane_id();
+    for (int c0 = 0; live != 0; c0 += 8) {
+        double v[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            ok[u] = live != 0 && c0 + u < stage_rows;           // (wave-uniform)
+            uint32_t j = 0;
+            if (live != 0) {
+                const int src = __builtin_ctzll(live);
+                live &= live - 1;
+                j = (uint32_t)__builtin_amdgcn_readlane((int)myj, src);
+            }
+            v[u] = (ok[u] && lane < g) ? Y[(int64_t)j * g + lane] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (ok[u] && lane < g) stg[(c0 + u) * gp + lane] = v[u];
+    }
+}
+
 template <int NCL, int MET, bool STAGE>
 __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ X, int64_t row0, int64_t m,
                                                      const double *__restrict__ Y, int g,
@@ -179,12 +207,7 @@ __global__ __launch_bounds__(256) void refine_kernel(const double *__restrict__ 
         // sizing the block for all S * L kept the kernel at three waves per SIMD)
         uint64_t live = __builtin_amdgcn_ballot_w64(myj != 0xFFFFFFFFu);
         const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-        for (int c = 0; live != 0; ++c) {
-            const int src = __builtin_ctzll(live);
-            live &= live - 1;
-            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)myj, src);
-            if (c < stage_rows && lane < g) stg[c * gp + lane] = Y[(int64_t)j * g + lane];
-        }
+        stage_rows_to_lds(Y, g, gp, stg, stage_rows, myj, live);
         key[0] = __builtin_inf();
         val[0] = 0xFFFFFFFFu;
         if (myj != 0xFFFFFFFFu) {
@@ -346,12 +369,7 @@ __global__ __launch_bounds__(256) void refine_cand_kernel(const double *__restri
         // sizing the block for all S * L kept the kernel at three waves per SIMD)
         uint64_t live = __builtin_amdgcn_ballot_w64(myj != 0xFFFFFFFFu);
         const int slot = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u));
-        for (int c = 0; live != 0; ++c) {
-            const int src = __builtin_ctzll(live);
-            live &= live - 1;
-            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)myj, src);
-            if (c < stage_rows && lane < g) stg[c * gp + lane] = Y[(int64_t)j * g + lane];
-        }
+        stage_rows_to_lds(Y, g, gp, stg, stage_rows, myj, live);
         key[0] = __builtin_inf();
         val[0] = 0xFFFFFFFFu;
         if (myj != 0xFFFFFFFFu) {
@@ -597,6 +615,69 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (uint32_t)i;
+}
+
+// ---- several lists per row merged by their FILTER keys ---------------------------------------------------------------------
+// A row whose references were streamed in S pieces (reference splits, the pieces of a cut launch, the tail round) arrives
+// with S lists of up to lkeep entries each, and the exact float64 re-evaluation of all S lkeep candidates was what the
+// split cost (100k x 100k: refine 0.37 ms with one list per row, 1.07 with two).  One streamed list would have kept the
+// lkeep smallest SCORES of the union, so that is what goes on: the union is sorted by (score, index), the first lkeep stay,
+// and the merged threshold is  min(every list's threshold, the first score cut here)  -- each reference that is not in
+// the merged list was either dropped by its own list (score >= that list's threshold) or cut here (score >= the first
+// one cut).  refine.hip's certificate reads nothing else.  One wave per row.
+template <int NCL>
+__global__ __launch_bounds__(256) void merge_lists_kernel(const uint32_t *__restrict__ cand_idx, const float *__restrict__ cand_key,
+                                                          const float *__restrict__ cand_tau, int64_t rows, int S, int L,
+                                                          int lkeep, uint32_t *__restrict__ out_idx, float *__restrict__ out_tau)
+{
+    const int lane = lane_id();
+    const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lrow >= rows) return;
+    const int ncand = S * L;
+    float key[NCL];
+    uint32_t val[NCL];
+#pragma unroll
+    for (int r = 0; r < NCL; ++r) {
+        const int e = r * 64 + lane;
+        key[r] = __builtin_inff();
+        val[r] = 0xFFFFFFFFu;
+        if (e < ncand) {
+            const uint32_t j = cand_idx[lrow * ncand + e];
+            if (j != 0xFFFFFFFFu) { val[r] = j; key[r] = cand_key[lrow * ncand + e]; }
+        }
+    }
+    wave_sort_f32<NCL>(key, val);
+    float tmin = __builtin_inff();
+    for (int s2 = lane; s2 < S; s2 += 64) tmin = fminf(tmin, cand_tau[lrow * S + s2]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+    if (lkeep < 64 * NCL) {                                 // the first entry cut (+inf: a sentinel, nothing was cut)
+        float cut = __builtin_inff();
+#pragma unroll
+        for (int r = 0; r < NCL; ++r)
+            if ((lkeep >> 6) == r) cut = __shfl(key[r], lkeep & 63, 64);
+        tmin = fminf(tmin, cut);
+    }
+    if (lane < L) out_idx[lrow * L + lane] = lane < lkeep ? val[0] : 0xFFFFFFFFu;       // (L <= 64: the first register)
+    if (lane == 0) out_tau[lrow] = tmin;
+}
+
+hipError_t merge_lists_launch(const uint32_t *cand_idx, const float *cand_key, const float *cand_tau, int64_t rows, int S, int L,
+                              int lkeep, uint32_t *out_idx, float *out_tau, hipStream_t st)
+{
+    if (rows <= 0) return hipSuccess;
+    const int ncl = (S * L + 63) / 64;
+    if (L > 64 || lkeep > L || lkeep < 1 || S < 1) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define NABO_ML(N) hipLaunchKernelGGL((merge_lists_kernel<N>), grid, block, 0, st, cand_idx, cand_key, cand_tau, rows, S, L, lkeep, out_idx, out_tau)
+    if (ncl <= 1) NABO_ML(1);
+    else if (ncl <= 2) NABO_ML(2);
+    else if (ncl <= 4) NABO_ML(4);
+    else if (ncl <= 8) NABO_ML(8);
+    else if (ncl <= 16) NABO_ML(16);
+    else return hipErrorInvalidValue;
+#undef NABO_ML
+    return hipGetLastError();
 }
 
 hipError_t iota_launch(uint32_t *out, int64_t n, hipStream_t st)
