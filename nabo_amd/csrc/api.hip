@@ -236,8 +236,9 @@ struct Options {
     int wide_retry = 1;        //   rows the 32-entry lists fail get 64-entry lists before the exact kernels
     int refine_overlap = 1;    // the refine of the main launch's rows runs beside the filter's tail launch
     int prepass = 100;         // tournament seeds: percent of the planned length (0: lists start from +inf)
-    int pieces = 1;            // fewer column-workgroups than slots: the launch is cut into equal pieces of (column, tile) space
+    int pieces = 0;            // fewer column-workgroups than slots: the launch is cut into equal pieces of (column, tile) space (measured slower than the split grid so far: off)
     int merge_lists = 1;       // several lists per row are merged by their filter keys before the float64 re-evaluation
+    int one_round = 1;         // fewer column-workgroups than slots: splits (+ a tail launch) chosen to fill ONE round of workgroups
     int l2c_geo = -1;          // pin the one-product kernel's geometry: 0 = A, 1 = B, 2 = C (-1: by list length)
     int l2_r1 = -1;            // fp32 filter: one row-block per wave (-1 auto, 0 never, 1 always)
     int split_refs_max = 0;    // lower the 2^25-references-per-split bound (tests see the rule at ordinary sizes)
@@ -251,7 +252,7 @@ const OptionName OPTION_NAMES[] = {
     {"splits", &Options::splits}, {"tail_split", &Options::tail_split}, {"lkeep", &Options::lkeep},
     {"coarse_slack", &Options::coarse_slack}, {"cand_slack", &Options::cand_slack}, {"seeded_pass", &Options::seeded_pass},
     {"coarse_adapt", &Options::coarse_adapt}, {"wide_retry", &Options::wide_retry}, {"refine_overlap", &Options::refine_overlap},
-    {"prepass", &Options::prepass}, {"pieces", &Options::pieces}, {"merge_lists", &Options::merge_lists}, {"l2c_geo", &Options::l2c_geo}, {"l2_r1", &Options::l2_r1},
+    {"prepass", &Options::prepass}, {"pieces", &Options::pieces}, {"merge_lists", &Options::merge_lists}, {"one_round", &Options::one_round}, {"l2c_geo", &Options::l2c_geo}, {"l2_r1", &Options::l2_r1},
     {"split_refs_max", &Options::split_refs_max}, {"cosine_centre", &Options::cosine_centre},
     {"coarse_kernel_q", &Options::coarse_kernel_q}, {"order_flags", &Options::order_flags},
 };
@@ -830,6 +831,7 @@ struct L2Plan {
     int rows_per_wg = 256, wg_per_cu = 1, lkeep_max = 32, lkeep = 16, want = 16;
     int S = 1, S2 = 1;                   // reference splits of the main / tail launch
     bool forced = false;                 // the split count is the caller's (option "splits")
+    bool one_round = false;              // fewer column-workgroups than slots: splits (+ a tail launch on long streams) fill one round
     bool pieces = false;                 // the launch is cut into pieces (cut_pieces): piece_wgs workgroups of ~piece_len tiles, S = lists per row
     int piece_wgs = 0;
     int64_t piece_len = 0;
@@ -1000,7 +1002,40 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
             S = sp;
         }
     }
-    if (!forced && !pieces) {
+    // Fewer column-workgroups than slots, one-product kernel, lists merged before the float64 step (so a row's list count
+    // costs the refine nothing): ONE round of workgroups at full occupancy -- all the columns with floor(slots / gx) uniform
+    // splits when that fills at least 80 % of the slots.  On LONG reference streams (>= 8192 tiles) also one split more on
+    // the floor(slots / S) columns that fit, the columns left over as a tail launch with more splits (the main / tail pair
+    // of the long queries): 120k x 1M: 256 x 2 + 57 x 8, 13.3 instead of 16.1 ms.  On short streams a tail costs more than
+    // the idle slots (100k x 100k: 256 x 2 + 5 x 16 behind the main launch 2.44 ms, beside it on the second stream 2.55,
+    // 261 x 1 2.42), and so does cutting the (column, tile) space into equal chunks ("pieces", off): workgroups of a uniform
+    // split stream the same tiles at the same time and share them in L2, unaligned pieces do not (49k x 100k: kernel
+    // 1.99 ms as 603 pieces, 1.10 ms as 128 x 4).
+    bool one_round = false;
+    if (!forced && !pieces && on_l2c && ix->opt.one_round != 0 && ix->opt.merge_lists != 0 && ix->pass_level == 0 && !ix->wide_retry &&
+        gx < slots) {
+        int64_t s_cap = ix->ref_tiles / 16 > 0 ? ix->ref_tiles / 16 : 1;     // >= 16 tiles per split
+        if (s_cap > 1024 / L) s_cap = 1024 / L;
+        int64_t s_exact = slots / gx;
+        if (s_exact > s_cap) s_exact = s_cap;
+        S = (int)s_exact;
+        const double occ = (double)(gx * s_exact) / (double)slots;
+        if (occ < 0.8 && s_exact + 1 <= s_cap && ix->opt.tail_split != 0 && ix->ref_tiles >= 8192) {
+            const int64_t s_up = s_exact + 1, cols = slots / s_up, rest = gx - cols;
+            if (cols >= 1 && rest >= 1 && rest * 4 <= gx) {           // (the tail is a quarter of the columns at most)
+                int64_t s2 = slots / rest;
+                if (s2 > s_cap) s2 = s_cap;
+                if (s2 > 16) s2 = 16;
+                if (s2 < s_up) s2 = s_up;
+                S = (int)s_up;
+                S2 = (int)s2;
+                gx_main = cols;
+                gx_tail = rest;
+            }
+        }
+        one_round = occ >= 0.8 || gx_tail > 0;               // (otherwise the cost model below decides)
+    }
+    if (!forced && !pieces && !one_round) {
         S = 1;
         if (gx < slots) {
             // Fewer workgroups than the chip holds: pick the split count from a cost model.  A workgroup costs
@@ -1063,7 +1098,7 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
     P->geo = geo; P->kcq = kcq; P->slack1 = slack1; P->cslack = cslack;
     P->rows_per_wg = rows_per_wg; P->wg_per_cu = wg_per_cu; P->lkeep_max = lkeep_max; P->lkeep = lkeep; P->want = want;
     P->S = S; P->S2 = S2; P->forced = forced;
-    P->pieces = pieces; P->piece_wgs = piece_wgs; P->piece_len = piece_len;
+    P->pieces = pieces; P->piece_wgs = piece_wgs; P->piece_len = piece_len; P->one_round = one_round;
     P->gx = gx; P->gx_main = gx_main; P->gx_tail = gx_tail; P->rows_pad = rows_pad; P->tps = tps; P->tps2 = tps2;
     {
         // (the locality-ordered stream and NABO_COARSE_KERNEL_Q run the one-product operands through the l2q kernel)
@@ -1261,8 +1296,11 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             const float *seeds = (seedable && ix->pass_level == 1) ? ix->seed_tau : nullptr;
             // Several lists per row (reference splits, pieces, the tail round): the l2c kernel also emits the entries' filter
             // keys and merge_lists_kernel reduces the lists to the ONE a single stream would have kept (refine.hip)
-            merge_main = on_l2c && S > 1 && gx_main > 0 && ix->opt.merge_lists != 0;
-            merge_tail = on_l2c && S2 > 1 && gx_tail > 0 && ix->opt.merge_lists != 0;
+            // (first pass only: a seeded pass WANTS every list re-evaluated -- its rows have more than one list's worth of
+            // references below their seeds: cosine d = 100, k = 50 with the merge there: 86 instead of 16 ms of later passes)
+            const bool merging = on_l2c && ix->opt.merge_lists != 0 && ix->pass_level == 0 && !ix->wide_retry;
+            merge_main = merging && S > 1 && gx_main > 0;
+            merge_tail = merging && S2 > 1 && gx_tail > 0;
             if (merge_main) {
                 if ((rc = ix->cand_key.reserve((size_t)rows_main * S * L * sizeof(float)))) return rc;
                 if ((rc = ix->cand_mi.reserve((size_t)rows_main * L * sizeof(uint32_t)))) return rc;

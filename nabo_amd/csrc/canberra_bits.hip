@@ -317,6 +317,9 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     // fp32 lower bound of `nb` (<= 64) work-list pairs, one per lane, then list insertion (canberra_f32.hip: drain);
     // the target's packed (x, thr) row comes from global memory here (rare: 3e-3 of the pairs).  A list accepts
     // (key, j) < (tau, tidx) lexicographically: arrival order does not matter (header).
+    // (Round 4, tried and dropped: the survivor's reference row requested up front -- one word per 128-byte line before the
+    // loop -- and ONE run-time copy of the extraction loop instead of eight: 507 -> 532 / 556 ms.  A drain is not what the
+    // step barrier waits for.)
     auto drain = [&](int nb) {
         const bool act = lane < nb;
         const int slot = (wl_head + lane) & (WLN - 1);
@@ -326,16 +329,6 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
         wl_n -= nb;
         const float4 *xp = reinterpret_cast<const float4 *>(xq + (row0 + t_p) * GP);     // (x, thr) of two dimensions
         const float4 *yp = reinterpret_cast<const float4 *>(yrow + (int64_t)j * GP);     // four dimensions
-        // The survivor's reference row is a random 4 GP bytes of HBM in up to three 128-byte lines: one word of EACH is
-        // requested before the loop, which then waits for one memory latency instead of one per eight dimensions (the
-        // workgroup's other fifteen waves stand at the step barrier meanwhile).  (The whole row in registers up front, with
-        // the loop unrolled, spilled a thousand registers; volatile: the values are not used.)
-        {
-            const volatile float *yl = yrow + (int64_t)j * GP;
-            (void)yl[0];
-            if (GP > 32) (void)yl[32];
-            (void)yl[GP - 1];
-        }
         float lb = 0.0f;
         int no_p = 0;
 #pragma unroll 1
@@ -555,50 +548,12 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
                 gev[s][w] = __builtin_amdgcn_bitop3_b32(c, all, vm_[w], 0xA8);      // (c | all) & vm
             }
         }
-#ifdef NABO_CBB_XLOOP
-        // (every mask is computed before the first survivor leaves: the count planes are dead from here on and their
-        // registers hold a drain's reference rows)
-#pragma unroll
-        for (int s = 0; s < TS; ++s)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(gev[s][w]));
-        // ONE copy of the extraction loop and of the drain behind it: the (slot, word) mask is selected at run time
-        // (eight copies of a drain with its rows in flight are more code than the instruction cache holds)
-#pragma unroll 1
-        for (int sw = 0; sw < TS * 4; ++sw) {
-            uint32_t ge = 0u;
-#pragma unroll
-            for (int i = 0; i < TS * 4; ++i) ge = (sw == i) ? gev[i >> 2][i & 3] : ge;
-            const int t_mine = 4 * (sw >> 2) + q;                // this lane group's target in slot sw / 4
-            const int w = sw & 3;
-            if (t_mine >= t_cnt) ge = 0u;
-            uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
-            while (anyb != 0) {                                  // every lane with survivors hands over its lowest one
-                const bool has = ge != 0u;
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(anyb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)anyb, 0u));
-                if (has) {
-                    const int r = __builtin_ctz(ge);
-                    const int slot = (wl_head + wl_n + rank) & (WLN - 1);
-                    wl[slot] = (uint32_t)(blk * CBB_BLK + sub * 128 + w * 32 + r);
-                    wl_t[slot] = (unsigned char)t_mine;
-                    ge &= ge - 1u;
-                }
-                wl_n += __popcll(anyb);
-                while (wl_n >= 64) drain(64);
-                anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
-            }
-        }
-    }
-#else
 #pragma unroll
         for (int s = 0; s < TS; ++s) {
             const int t_mine = 4 * s + q;                        // this lane group's target in slot s
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 uint32_t ge = t_mine < t_cnt ? gev[s][w] : 0u;
-#ifdef NABO_CBB_NOSURV           // timing experiment (garbage results): no survivor leaves the count
-                ge = 0u;
-#endif
                 uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
                 while (anyb != 0) {                              // every lane with survivors hands over its lowest one
                     const bool has = ge != 0u;
@@ -617,7 +572,6 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
             }
         }
     }
-#endif
     cbb_dma_wait();                                          // (no LDS-DMA may outlive the workgroup's LDS)
     while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);
     // flush: the L smallest (key, index) per target; tau = L-th key if anything was ever dropped

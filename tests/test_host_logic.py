@@ -108,13 +108,15 @@ def test_query_plan_fills_the_chip_and_follows_the_list_rules():
     assert c1["workgroups"] >= 256, c1
     # fewer column-workgroups than slots: the (column, reference tile) space is cut into ~slots equal chunks, a chunk that
     # crosses a column boundary into two pieces, one workgroup per piece (261 columns x 3125 tiles on 512 slots)
+    assert c1["pieces"] == 0                                              # (option "pieces": off by default -- measured slower so far)
+    c1 = P(100000, 50, 100000, 15, options={"pieces": 1})
     assert c1["pieces"] == 1 and c1["resident_workgroups"] == 512 and 500 <= c1["workgroups"] <= 512 + 261
     assert abs(c1["piece_tiles"] - 261 * 3125 / 512) <= 8 and c1["splits"] * c1["list_len"] <= 1024
     assert 2 <= c1["splits"] <= 4 and c1["tiles_per_split"] == 3125
     assert P(100000, 50, 100000, 15, options={"pieces": 0})["pieces"] == 0
-    assert P(1000000, 50, 1000000, 15)["pieces"] == 0                    # enough columns: whole rounds + the tail launch
+    assert P(1000000, 50, 1000000, 15, options={"pieces": 1})["pieces"] == 0      # enough columns: whole rounds + the tail launch
     for m, n in ((3000, 3000), (30000, 30000), (49152, 100000), (150000, 100000), (190000, 400000), (64, 1000000), (5000, 2000)):
-        p = P(n, 50, m, 15)
+        p = P(n, 50, m, 15, options={"pieces": 1})
         if p["pieces"]:
             cols, T = p["workgroups_main"], (n + 31) // 32
             chunks = -(-cols * T // p["piece_tiles"])

@@ -1121,17 +1121,18 @@ def test_tournament_seeds_change_no_result(gpu_lib, m, n, g, k, drop, metric, sp
 
 @pytest.mark.parametrize("m,n,g,k,drop,metric", [(5000, 20000, 50, 15, 0, 0), (30000, 30000, 50, 15, 1, 0), (20000, 100000, 50, 15, 0, 0),
                                                  (9000, 50000, 100, 50, 0, 2), (2000, 150000, 30, 40, 1, 0), (700, 3000, 50, 15, 0, 0),
-                                                 (45000, 9000, 20, 11, 0, 0)])
+                                                 (45000, 9000, 20, 11, 0, 0), (101000, 40000, 50, 15, 0, 0)])
 def test_cut_launches_and_merged_lists_change_no_result(gpu_lib, m, n, g, k, drop, metric):
     """Fewer column-workgroups than slots: the one-product launch is cut into equal pieces of the (column, reference tile)
     space (api.hip: cut_pieces; every piece its own lists and tournament) and the several lists of a row are merged by their
-    filter keys before the float64 re-evaluation (refine.hip: merge_lists_kernel).  The cut launch, the uncut one, merged and
-    unmerged lists and caller-chosen splits return the same bits; rows sampled against the oracle (all three geometries,
+    filter keys before the float64 re-evaluation (refine.hip: merge_lists_kernel); by default such a query is cut into ONE round
+    of workgroups -- uniform splits, the columns that do not fit as a tail launch (api.hip: plan_l2, one_round).  The cut
+    launch, the one-round plan, the cost model's plan, merged and unmerged lists and caller-chosen splits return the same bits; rows sampled against the oracle (all three geometries,
     cosine, the positional self-drop)."""
     Y = pca_like(n, g, seed=61)
     X = pca_like(m, g, seed=62) if not drop else (Y[:m] if m <= n else np.concatenate([Y, pca_like(m - n, g, seed=63)]))
     ref = None
-    for opts in ({}, {"pieces": 0}, {"merge_lists": 0}, {"pieces": 0, "merge_lists": 0}, {"splits": 3}, {"splits": 3, "merge_lists": 0}):
+    for opts in ({"pieces": 1}, {}, {"one_round": 0}, {"merge_lists": 0}, {"pieces": 1, "merge_lists": 0}, {"splits": 3}, {"splits": 3, "merge_lists": 0}):
         ix = gpu_lib.KnnIndex(n, g, metric=metric, options=opts).set_ref(Y)
         gi, gd = ix.query(X, k, drop_first=bool(drop))
         st = ix.last_stats()
@@ -1140,9 +1141,9 @@ def test_cut_launches_and_merged_lists_change_no_result(gpu_lib, m, n, g, k, dro
         if ref is None:
             ref = (gi, gd, st)
         assert np.array_equal(gi, ref[0]) and np.array_equal(gd, ref[1]), opts
-    plan = _knn_mod().query_plan(n, g, m, k, metric=metric, drop_first=bool(drop))
+    plan = _knn_mod().query_plan(n, g, m, k, metric=metric, drop_first=bool(drop), options={"pieces": 1})
     if plan["pieces"]:
-        assert ref[2]["workgroups"] == plan["workgroups"] <= plan["resident_workgroups"] and ref[2]["splits"] == plan["splits"]
+        assert ref[2]["workgroups"] == plan["workgroups"] and ref[2]["splits"] == plan["splits"]
     rows = np.random.default_rng(5).choice(m, min(m, 400), replace=False)
     oi, od = oracle.knn(X[rows], Y, k, metric, drop_first=bool(drop), nthreads=16)
     _check(ref[0][rows], ref[1][rows], oi, od)
