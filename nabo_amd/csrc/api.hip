@@ -45,7 +45,7 @@ hipError_t l2c_pre_launch(int kc, int lkeep, const unsigned char *Xpk, const uns
                           int64_t rows, int64_t tile_off, int pre_tiles, int gt, int64_t pad_tile, hipStream_t st,
                           int64_t rows_valid, float *tau_out, const int *ranges = nullptr, int rows_per_col = 0);
 hipError_t merge_lists_launch(const uint32_t *cand_idx, const float *cand_key, const float *cand_tau, int64_t rows, int S, int L,
-                              int lkeep, uint32_t *out_idx, float *out_tau, hipStream_t st);
+                              int lkeep, int Lout, uint32_t *out_idx, float *out_tau, hipStream_t st);
 int l2c_pick_kc(int g);
 int l2c_geometry(int kc, int lkeep_want, int pin);
 void l2c_topk_geometry(int kc, int lkeep_want, int pin, int *rows_per_wg, int *wg_per_cu, int *lkeep_max);
@@ -1274,6 +1274,8 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
         bool seedable = false;               // the l2c kernel ran: its failed rows can go through a seeded pass
         bool refine_beside_tail = false;
         bool merge_main = false, merge_tail = false;
+        int merge_keep = 0, merge_L = 0, keep_tail = 0;
+        bool merge_seeded = false;
         int64_t pieces_wgs = 0;
         float *key_main = nullptr, *key_tail = nullptr;
 #ifdef NABO_EXPERIMENTS
@@ -1298,18 +1300,25 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // keys and merge_lists_kernel reduces the lists to the ONE a single stream would have kept (refine.hip)
             // (first pass only: a seeded pass WANTS every list re-evaluated -- its rows have more than one list's worth of
             // references below their seeds: cosine d = 100, k = 50 with the merge there: 86 instead of 16 ms of later passes)
-            const bool merging = on_l2c && ix->opt.merge_lists != 0 && ix->pass_level == 0 && !ix->wide_retry;
+            // ... the SEEDED pass on 32-entry lists keeps up to 128: what lies below a seed is "a few more than one list", and
+            // 128 candidates are two per lane for the float64 step where S x 32 were four to sixteen per lane, each walking
+            // its own row (100k x 100k: refine of 108 rows' 1024 candidates 0.41 ms)
+            const bool seeded_merge = ix->pass_level == 1 && epl == 1 && !ix->wide_retry;
+            const bool merging = on_l2c && ix->opt.merge_lists != 0 && !ix->wide_retry && (ix->pass_level == 0 || seeded_merge);
+            merge_seeded = seeded_merge;
+            merge_keep = seeded_merge ? (S * L < 128 ? S * L : 128) : lkeep;
+            merge_L = seeded_merge ? merge_keep : L;
             merge_main = merging && S > 1 && gx_main > 0;
             merge_tail = merging && S2 > 1 && gx_tail > 0;
             if (merge_main) {
                 if ((rc = ix->cand_key.reserve((size_t)rows_main * S * L * sizeof(float)))) return rc;
-                if ((rc = ix->cand_mi.reserve((size_t)rows_main * L * sizeof(uint32_t)))) return rc;
+                if ((rc = ix->cand_mi.reserve((size_t)rows_main * merge_L * sizeof(uint32_t)))) return rc;
                 if ((rc = ix->cand_mt.reserve((size_t)rows_main * sizeof(float)))) return rc;
                 key_main = ix->cand_key.as<float>();
             }
             if (merge_tail) {
                 if ((rc = ix->cand_key2.reserve((size_t)rows_tail * S2 * L * sizeof(float)))) return rc;
-                if ((rc = ix->cand_mi2.reserve((size_t)rows_tail * L * sizeof(uint32_t)))) return rc;
+                if ((rc = ix->cand_mi2.reserve((size_t)rows_tail * (merge_seeded ? 128 : merge_L) * sizeof(uint32_t)))) return rc;
                 if ((rc = ix->cand_mt2.reserve((size_t)rows_tail * sizeof(float)))) return rc;
                 key_tail = ix->cand_key2.as<float>();
             }
@@ -1468,28 +1477,29 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
         // what the float64 re-evaluation reads: the filter's lists, or ONE merged list per row (merge_lists_kernel)
         const uint32_t *ci_main = ix->cand_idx.as<uint32_t>(), *ci_tail = ix->cand_idx2.as<uint32_t>();
         const float *ct_main = ix->cand_tau.as<float>(), *ct_tail = ix->cand_tau2.as<float>();
-        int S_main = S, S_tail = S2;
+        int S_main = S, S_tail = S2, L_main = L, L_tail = L;
         auto merge_lists = [&](bool tail, hipStream_t sm) -> hipError_t {
             if (tail) {
+                const int keep_t = merge_seeded ? (S2 * L < 128 ? S2 * L : 128) : merge_keep, lout_t = merge_seeded ? keep_t : merge_L;
                 hipError_t e = nabo::merge_lists_launch(ix->cand_idx2.as<uint32_t>(), key_tail, ix->cand_tau2.as<float>(), m - rows_main, S2, L,
-                                                        lkeep, ix->cand_mi2.as<uint32_t>(), ix->cand_mt2.as<float>(), sm);
-                ci_tail = ix->cand_mi2.as<uint32_t>(); ct_tail = ix->cand_mt2.as<float>(); S_tail = 1;
+                                                        keep_t, lout_t, ix->cand_mi2.as<uint32_t>(), ix->cand_mt2.as<float>(), sm);
+                ci_tail = ix->cand_mi2.as<uint32_t>(); ct_tail = ix->cand_mt2.as<float>(); S_tail = 1; L_tail = lout_t; keep_tail = keep_t;
                 return e;
             }
-            hipError_t e = nabo::merge_lists_launch(ix->cand_idx.as<uint32_t>(), key_main, ix->cand_tau.as<float>(), m_main, S, L, lkeep,
-                                                    ix->cand_mi.as<uint32_t>(), ix->cand_mt.as<float>(), sm);
-            ci_main = ix->cand_mi.as<uint32_t>(); ct_main = ix->cand_mt.as<float>(); S_main = 1;
+            hipError_t e = nabo::merge_lists_launch(ix->cand_idx.as<uint32_t>(), key_main, ix->cand_tau.as<float>(), m_main, S, L, merge_keep,
+                                                    merge_L, ix->cand_mi.as<uint32_t>(), ix->cand_mt.as<float>(), sm);
+            ci_main = ix->cand_mi.as<uint32_t>(); ct_main = ix->cand_mt.as<float>(); S_main = 1; L_main = merge_L;
             return e;
         };
         if (cand_mode) {
             if (merge_main) HIP_TRY(merge_lists(false, st));
             if (merge_tail) HIP_TRY(merge_lists(true, st));
             HIP_TRY(nabo::refine_cand_launch(dX, 0, m_main, ix->dY, g, ci_main, ct_main,
-                                             S_main, L, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
+                                             S_main, L_main, ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, ix->base,
                                              n_valid, d_oidx, d_odist, out_bound, st, cosine ? 2 : 0, lkeep, rperm, tperm));
             if (gx_tail > 0)
                 HIP_TRY(nabo::refine_cand_launch(dX, rows_main, m, ix->dY, g, ci_tail,
-                                                 ct_tail, S_tail, L, ix->xnorm.as<double>(), err_coef,
+                                                 ct_tail, S_tail, L_tail, ix->xnorm.as<double>(), err_coef,
                                                  ymax_sqrt, tau_scale, k, ix->base, n_valid, d_oidx, d_odist, out_bound, st,
                                                  cosine ? 2 : 0, lkeep, rperm, tperm));
             HIP_TRY(hipEventRecord(ix->ev[3], st));
@@ -1520,19 +1530,19 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             HIP_TRY(hipStreamWaitEvent(st_main, ix->ev_main, 0));
         }
         if (merge_main) HIP_TRY(merge_lists(false, st_main));
-        HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ci_main, ct_main, S_main, L,
+        HIP_TRY(nabo::refine_launch(dX, 0, m_main, ix->dY, g, ci_main, ct_main, S_main, L_main,
                                     ix->xnorm.as<double>(), err_coef, ymax_sqrt, tau_scale, k, drop, ix->base, n_valid,
                                     ix->mlistbuf.as<uint32_t>(), tail_len(ix), d_oidx, d_odist,
                                     ix->fails.as<uint32_t>(), ix->failcnt.as<unsigned int>(), st_main, cosine ? 2 : 0, 0.0, 0.0f,
-                                    lkeep, rperm, tperm, fail_seed));
+                                    merge_main ? merge_keep : lkeep, rperm, tperm, fail_seed));
         if (refine_beside_tail) HIP_TRY(hipEventRecord(ix->ev_ref, st_main));
         if (merge_tail) HIP_TRY(merge_lists(true, st));
         if (gx_tail > 0)
             HIP_TRY(nabo::refine_launch(dX, rows_main, m, ix->dY, g, ci_tail,
-                                        ct_tail, S_tail, L, ix->xnorm.as<double>(), err_coef,
+                                        ct_tail, S_tail, L_tail, ix->xnorm.as<double>(), err_coef,
                                         ymax_sqrt, tau_scale, k, drop, ix->base, n_valid, ix->mlistbuf.as<uint32_t>(),
                                         tail_len(ix), d_oidx, d_odist, ix->fails.as<uint32_t>(),
-                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, lkeep, rperm, tperm,
+                                        ix->failcnt.as<unsigned int>(), st, cosine ? 2 : 0, 0.0, 0.0f, merge_tail ? keep_tail : lkeep, rperm, tperm,
                                         fail_seed));
         if (refine_beside_tail) HIP_TRY(hipStreamWaitEvent(st, ix->ev_ref, 0));
         HIP_TRY(hipEventRecord(ix->ev[3], st));

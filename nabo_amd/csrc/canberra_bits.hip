@@ -65,11 +65,11 @@ static_assert(CBB_PAIR_BYTES % 1024 == 0, "whole DMA pieces");
 // into a scratch row, vmcnt leaving it in flight for a step: 544 -> 571 ms.  The pass is not waiting for table misses; its
 // SIMDs issue an instruction every 4.9 cycles, 82 % of what they can: what counts is the instruction count.)
 #ifndef NABO_CBB_DMAW
-#define NABO_CBB_DMAW 8          // (16 waves x 2 pieces: 527 ms at 1M x 1M; 8 x 4: 507)
+#define NABO_CBB_DMAW 4          // (16 waves x 2 pieces: 527 ms at 1M x 1M; 8 x 4: 507; 4 x 8: 503; 2 x 16: 512)
 #endif
 constexpr int CBB_DMAW = NABO_CBB_DMAW;                                // waves 0 .. DMAW-1 request the table pieces
 constexpr int CBB_PPW = CBB_PIECES / CBB_DMAW;                         // consecutive pieces a DMA wave requests per pair
-static_assert(CBB_PIECES % CBB_DMAW == 0 && CBB_DMAW <= CBB_NW && CBB_PPW >= 1 && CBB_PPW <= 4, "pieces per DMA wave (13-bit immediate offset)");
+static_assert(CBB_PIECES % CBB_DMAW == 0 && CBB_DMAW <= CBB_NW && CBB_PPW >= 1 && (CBB_PPW <= 4 || CBB_PPW % 4 == 0), "pieces per DMA wave: up to four per statement (13-bit immediate offset)");
 static_assert(CBB_BUF_BYTES <= CBB_BUF1 && CBB_BUF_BYTES <= 65536, "row addresses (16 bits) and the buffer bit must not overlap");
 // per-wave LDS block: ro2 [npair <= gp/2][T] uint2 | keys, idx [T][CAP] | tau, tidx, cnt, thr [T] | wl [WLN] u32 | wl_t [WLN] u8
 // (kept + pending list entries: 16 (12) pending per 32 kept; ro2 entry npair repeats entry 0 -- gp / 2 entries hold it for every
@@ -405,7 +405,15 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
 #ifdef NABO_CBB_NODMA
         if (!fetched)
 #endif
-        if (dma_wave) cbb_glds16<CBB_PPW>(fsrc, lane_off, ((uint32_t)buf << 16) + fdst);
+        if (dma_wave) {
+            if constexpr (CBB_PPW <= 4) {
+                cbb_glds16<CBB_PPW>(fsrc, lane_off, ((uint32_t)buf << 16) + fdst);
+            } else {
+#pragma unroll
+                for (int q4 = 0; q4 < CBB_PPW / 4; ++q4)
+                    cbb_glds16<4>(fsrc + q4 * 4096, lane_off, ((uint32_t)buf << 16) + fdst + (uint32_t)(q4 * 4096));
+            }
+        }
 #ifdef NABO_CBB_DMA2X            // timing experiment (same results): every piece is requested twice
         if (dma_wave) cbb_glds16<CBB_PPW>(fsrc, lane_off, ((uint32_t)buf << 16) + fdst);
 #endif

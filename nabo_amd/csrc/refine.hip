@@ -628,7 +628,8 @@ __global__ void iota_kernel(uint32_t *__restrict__ out, int64_t n)
 template <int NCL>
 __global__ __launch_bounds__(256) void merge_lists_kernel(const uint32_t *__restrict__ cand_idx, const float *__restrict__ cand_key,
                                                           const float *__restrict__ cand_tau, int64_t rows, int S, int L,
-                                                          int lkeep, uint32_t *__restrict__ out_idx, float *__restrict__ out_tau)
+                                                          int lkeep, int Lout, uint32_t *__restrict__ out_idx,
+                                                          float *__restrict__ out_tau)
 {
     const int lane = lane_id();
     const int64_t lrow = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -658,18 +659,24 @@ __global__ __launch_bounds__(256) void merge_lists_kernel(const uint32_t *__rest
             if ((lkeep >> 6) == r) cut = __shfl(key[r], lkeep & 63, 64);
         tmin = fminf(tmin, cut);
     }
-    if (lane < L) out_idx[lrow * L + lane] = lane < lkeep ? val[0] : 0xFFFFFFFFu;       // (L <= 64: the first register)
+#pragma unroll
+    for (int r = 0; r < (NCL < 2 ? NCL : 2); ++r) {              // (Lout <= 128: the first two registers)
+        const int e = r * 64 + lane;
+        if (e < Lout) out_idx[lrow * Lout + e] = e < lkeep ? val[r] : 0xFFFFFFFFu;
+    }
     if (lane == 0) out_tau[lrow] = tmin;
 }
 
+// lkeep entries stay, in rows of Lout (<= 128) -- Lout = L and lkeep = the lists' own length for a first pass; a seeded pass keeps
+// up to 128 of its S x 32 (api.hip)
 hipError_t merge_lists_launch(const uint32_t *cand_idx, const float *cand_key, const float *cand_tau, int64_t rows, int S, int L,
-                              int lkeep, uint32_t *out_idx, float *out_tau, hipStream_t st)
+                              int lkeep, int Lout, uint32_t *out_idx, float *out_tau, hipStream_t st)
 {
     if (rows <= 0) return hipSuccess;
     const int ncl = (S * L + 63) / 64;
-    if (L > 64 || lkeep > L || lkeep < 1 || S < 1) return hipErrorInvalidValue;
+    if (Lout > 128 || Lout > 64 * ncl || lkeep > Lout || lkeep < 1 || S < 1 || L < 1) return hipErrorInvalidValue;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-#define NABO_ML(N) hipLaunchKernelGGL((merge_lists_kernel<N>), grid, block, 0, st, cand_idx, cand_key, cand_tau, rows, S, L, lkeep, out_idx, out_tau)
+#define NABO_ML(N) hipLaunchKernelGGL((merge_lists_kernel<N>), grid, block, 0, st, cand_idx, cand_key, cand_tau, rows, S, L, lkeep, Lout, out_idx, out_tau)
     if (ncl <= 1) NABO_ML(1);
     else if (ncl <= 2) NABO_ML(2);
     else if (ncl <= 4) NABO_ML(4);

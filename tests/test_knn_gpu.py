@@ -1066,17 +1066,24 @@ def test_row_pass_record_names_the_pass_that_answered_each_row(gpu_lib, monkeypa
     Y = pca_like(n, g, seed=41)
     Y[:8000] = 300.0 + 2e-3 * rng.standard_normal((8000, g))
     X = np.concatenate([pca_like(1500, g, seed=42), Y[:1500] + 1e-5 * rng.standard_normal((1500, g))])
-    ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
-    gi, gd = ix.query(X, k)
-    st, rp = ix.last_stats(), ix.last_row_pass(X.shape[0])
-    with pytest.raises(ValueError):
-        ix.last_row_pass(X.shape[0] + 1)
-    ix.close()
     oi, od = oracle.knn(X, Y, k, 0, nthreads=8)
-    _check(gi, gd, oi, od)
-    assert int((rp >= 1).sum()) == st["seeded_pass_rows"] > 0 and int((rp >= 2).sum()) == st["second_pass_rows"]
-    assert int((rp == 4).sum()) == st["fallback_rows"]
-    assert {1, 2} <= set(np.unique(rp).tolist()), "the far-away tight cluster sends rows past the first pass and the seeded one"
+    # (merge_lists = 0: the seeded pass re-evaluates ALL its S x 32 list entries -- on this weak-bound data a seed has several
+    # hundred references below it -- and answers some rows itself; by default it keeps the 128 best-scored ones, what does not
+    # fit goes on to the f16x3 pass: the same results, fewer rows named 1)
+    seen = {}
+    for opts in ({"merge_lists": 0}, {}):
+        ix = gpu_lib.KnnIndex(n, g, metric=0, options=opts).set_ref(Y)
+        gi, gd = ix.query(X, k)
+        st, rp = ix.last_stats(), ix.last_row_pass(X.shape[0])
+        with pytest.raises(ValueError):
+            ix.last_row_pass(X.shape[0] + 1)
+        ix.close()
+        _check(gi, gd, oi, od)
+        assert int((rp >= 1).sum()) == st["seeded_pass_rows"] > 0 and int((rp >= 2).sum()) == st["second_pass_rows"]
+        assert int((rp == 4).sum()) == st["fallback_rows"]
+        seen[len(opts)] = set(np.unique(rp).tolist())
+    assert {1, 2} <= seen[1], "the far-away tight cluster sends rows past the first pass and the seeded one"
+    assert 2 in seen[0] and 1 not in seen[0] or {1, 2} <= seen[0]      # (on this data nothing is certified by the first pass)
     monkeypatch.setenv("NABO_L2_MODE", "f16x3")
     ix = gpu_lib.KnnIndex(n, g, metric=0).set_ref(Y)
     monkeypatch.delenv("NABO_L2_MODE")
