@@ -417,7 +417,7 @@ def main():
                 "clock_ghz_held": (rec or {}).get("clock_ghz_held")}
         else:
             dig = _lib.src_digest(_lib.KERNEL_SOURCES["canberra"])
-            line["roofline"] = canberra_roofline(pmc_record("canberra", workload, dig), t_kernel, kern, dig)
+            line["roofline"] = canberra_roofline(pmc_record("canberra", workload, dig), t_kernel, kern, dig, float(m) * n * d)
         if kind != "single":
             hx = [s for s in per_rank if "sharded" in s]
             # (what the TRANSPORT reports, not what was asked for: ncclCommCount of this rank's communicator)
@@ -473,7 +473,7 @@ def lay_n_shard(n, shards):
     return shard_bounds(n, shards, 0)[1]
 
 
-def canberra_roofline(rec, t_kernel, kern, dig=None):
+def canberra_roofline(rec, t_kernel, kern, dig=None, pair_dims=None):
     """The mod-Canberra filter is vector-ALU work (no contraction): the bound is the chip's vector ISSUE rate, and what
     is priced against it is the number of vector instructions the kernel ACTUALLY issued (SQ_INSTS_VALU of a
     rocprofv3 --pmc pass on this kernel's sources), so the fraction cannot exceed 1.  `frac` is against the issue peak
@@ -487,7 +487,12 @@ def canberra_roofline(rec, t_kernel, kern, dig=None):
             "peak_note": "issue rate measured for this pass's instruction kinds (tools/issue_lab.hip, profiles/r2_issue_lab.txt)",
             "nominal_peak": NOMINAL_VALU_GINST, "frac_of_nominal_issue_peak": ach / NOMINAL_VALU_GINST if ach else None,
             "valu_insts_per_step": insts, "pmc_record": rec, "kernel": kern, "kernel_ms": t_kernel * 1e3,
-            "kernel_src_digest": dig}
+            "kernel_src_digest": dig,
+            # (the issue fraction does not move when a change removes instructions and time alike -- rounds 3 and 4 both read
+            # 0.35 while the pass went 786 -> 504 ms: the work rate says what the kernel got faster by.  1M x 1M x d pair-
+            # dimensions per step; lane-instructions = 64 per vector wave-instruction.)
+            "pair_dimensions_per_s": pair_dims / t_kernel if pair_dims else None,
+            "vector_lane_instructions_per_pair_dimension": insts * 64.0 / pair_dims if insts and pair_dims else None}
 
 
 def canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, dY, dX, X, Yfull, sync):
@@ -518,7 +523,7 @@ def canberra_block(nabo_amd, _knn, _lib, dev, n, m, d, k, dY, dX, X, Yfull, sync
             "ms_per_step": best * 1e3, "value": m * n / best, "unit": "cell-pair distances/s",
             "phases_ms": {key: st[key] for key in ("ms_pack", "ms_topk", "ms_refine", "ms_fallback", "ms_total")},
             "fallback_rows": st["fallback_rows"], "sampled_rows_equal_oracle": same,
-            "roofline": canberra_roofline(pmc_record("canberra", workload, dig), st["ms_topk"] * 1e-3, kern, dig)}
+            "roofline": canberra_roofline(pmc_record("canberra", workload, dig), st["ms_topk"] * 1e-3, kern, dig, float(m) * n * d)}
 
 
 def executed_flops_factor(kern, d):
