@@ -142,18 +142,22 @@ __device__ void emit_masked_tail(const double *__restrict__ x, const double *__r
 // into a wave-private LDS block and each lane then evaluates ITS candidate from LDS, in the reference's component
 // order -- a lane walking its own row in global memory moved 8 bytes per 64-byte request (1.15 TB/s at 1M rows).
 // The staged gather of refine_kernel / refine_cand_kernel: the candidates' rows (lane `src` of `live` holds candidate myj),
-// g * 8 coalesced bytes each, into rows 0, 1, .. of the wave's LDS block -- EIGHT rows requested before the first one is
+// g * 8 coalesced bytes each, into rows 0, 1, .. of the wave's LDS block -- NABO_STAGE_BATCH rows requested before the first one is
 // stored.  (One load, its wait, its store per candidate made a row's refine 23 memory latencies long: 7 ms for the 1M rows of
 // the headline where the bytes moved need ~2.5.)
+#ifndef NABO_STAGE_BATCH
+#define NABO_STAGE_BATCH 8
+#endif
 __device__ __forceinline__ void stage_rows_to_lds(const double *__restrict__ Y, int g, int gp, double *stg, int stage_rows,
                                                   uint32_t myj, uint64_t live)
 {
     const int lane = lane_id();
-    for (int c0 = 0; live != 0; c0 += 8) {
-        double v[8];
-        bool ok[8];
+    constexpr int NB = NABO_STAGE_BATCH;
+    for (int c0 = 0; live != 0; c0 += NB) {
+        double v[NB];
+        bool ok[NB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < NB; ++u) {
             ok[u] = live != 0 && c0 + u < stage_rows;           // (wave-uniform)
             uint32_t j = 0;
             if (live != 0) {
@@ -164,7 +168,7 @@ __device__ __forceinline__ void stage_rows_to_lds(const double *__restrict__ Y, 
             v[u] = (ok[u] && lane < g) ? Y[(int64_t)j * g + lane] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < NB; ++u)
             if (ok[u] && lane < g) stg[(c0 + u) * gp + lane] = v[u];
     }
 }
