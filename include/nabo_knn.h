@@ -261,6 +261,18 @@ int nabo_sharded_query(nabo_comm *c, nabo_index *ix, const double *X, int64_t m,
  * (all ranks), [1] candidates per shard (0 under local certification), [2] unused, [3] protocol used (1 / 2). */
 int nabo_sharded_last_stats(const nabo_comm *c, double ms[8], int64_t counters[4]);
 
+/* nabo_knn with the reference rows sharded over several GPUs of ONE node, for a caller that has no threads, communicators
+ * or device buffers of its own (the devices[] form of the boundary; the call site is Mapping.calc_dist,
+ * nabo/_mapping.py:408-444 -> _calc_dist :48-148).  Host arrays in, host arrays out, same results as nabo_knn on one device
+ * (N shards = 1 shard bit for bit; rows with fewer than k + drop_first unmasked references in the whole set: see
+ * nabo_sharded_query).  Internally one host thread per device: rank r indexes reference rows [n r / N, n (r + 1) / N),
+ * uploads all m target rows, and the ranks meet in nabo_sharded_query.  transport 0 = RCCL (devices must differ),
+ * 1 = loopback (devices may repeat: the whole protocol on one GPU, rehearsal and tests).  n_devices = 1: nabo_knn.
+ * A rank that fails alone fails the call with its status and message; a collective failure: NABO_E_COMM. */
+int nabo_knn_devices(const double *X, int64_t m, const double *Y, int64_t n, int32_t g, int32_t k, int32_t metric,
+                     double dist_factor, const uint8_t *ref_mask, int32_t drop_first, const int32_t *devices,
+                     int32_t n_devices, int32_t transport, int64_t *out_idx, double *out_dist);
+
 /* ---- SNN edge counts on device (consumer of the top-k: nabo/_mapping.py:186-198) --------
  * t_idx [m,k], r_idx [n,k] int64 DEVICE arrays (first k of the order rows).  For every
  * (t, slot s) writes out_snn[t*k+s] = | set(t_idx[t]) & set(r_idx[t_idx[t,s]]) | (int32,

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libnabo_knn.so")
-SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "host_graph.hip"]
+SOURCES = ["api.hip", "pack.hip", "l2_topk.hip", "l2q_topk.hip", "l2c_topk.hip", "refine.hip", "canberra.hip", "canberra_f32.hip", "canberra_bits.hip", "score_null.hip", "csr_build.hip", "sharded.hip", "multi.hip", "host_graph.hip"]
 # kernels of the experiments build only (-DNABO_EXPERIMENTS, tools/ab: measured slower than the product's and kept for A/B runs):
 # the f16x3 split on the 32x32x16 MFMA shape per wave / with LDS-shared tiles, locality-ordered streaming
 EXPERIMENT_SOURCES = ["l2h_topk.hip", "l2s_topk.hip", "order.hip"]

@@ -51,6 +51,25 @@ def knn(X, Y, k, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=F
     return idx, dist
 
 
+def knn_devices(X, Y, k, devices, metric=EUCLIDEAN, dist_factor=0.25, ref_mask=None, drop_first=False, transport="rccl"):
+    """nabo_knn_devices: the same call with the reference rows sharded over `devices` (one host thread per device inside the
+    library; transport "loopback": devices may repeat -- the whole protocol on one GPU).  Same results as knn()."""
+    X, Y = _f64(X, "X"), _f64(Y, "Y")
+    if X.shape[1] != Y.shape[1]:
+        raise ValueError("ERROR: X and Y must have the same number of components")
+    m, n, g = X.shape[0], Y.shape[0], X.shape[1]
+    mk, mp = _mask(ref_mask, n)
+    dev = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    idx = np.empty((m, k), dtype=np.int64)
+    dist = np.empty((m, k), dtype=np.float64)
+    if transport not in ("rccl", "loopback"):
+        raise ValueError("ERROR: transport must be 'rccl' or 'loopback'")
+    _lib.check(_lib.lib().nabo_knn_devices(X.ctypes.data, m, Y.ctypes.data, n, g, int(k), int(metric), float(dist_factor), mp,
+                                           int(bool(drop_first)), dev, len(devices), 1 if transport == "loopback" else 0,
+                                           idx.ctypes.data, dist.ctypes.data))
+    return idx, dist
+
+
 PLAN_FIELDS = ("first_pass", "geometry", "rows_per_wg", "workgroups_main", "workgroups_tail", "splits", "splits_tail", "lkeep",
                "list_len", "tiles_per_split", "tournament_tiles", "tournament_group", "resident_workgroups", "workgroups",
                "rows_padded", "operand_steps", "pieces", "piece_tiles")

@@ -26,7 +26,7 @@ SYMBOLS = [
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize", "nabo_dev_mem_info",
     "nabo_comm_unique_id", "nabo_comm_create", "nabo_comm_create_all", "nabo_comm_create_loopback", "nabo_comm_destroy",
     "nabo_comm_rank", "nabo_comm_world", "nabo_comm_transport_ranks", "nabo_comm_abort", "nabo_comm_set_timeout", "nabo_comm_set_ref_shards", "nabo_comm_barrier", "nabo_comm_allreduce_max_f64", "nabo_candidates_per_shard",
-    "nabo_sharded_query", "nabo_sharded_last_stats",
+    "nabo_sharded_query", "nabo_sharded_last_stats", "nabo_knn_devices",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
     L.nabo_candidates_per_shard.argtypes = [i32, i32, i64]
     L.nabo_sharded_query.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, i32]
     L.nabo_sharded_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.nabo_knn_devices.argtypes = [vp, i64, vp, i64, i32, i32, i32, dbl, vp, i32, C.POINTER(i32), i32, i32, vp, vp]
     for name in SYMBOLS:
         if name not in ("nabo_version", "nabo_last_error"):
             getattr(L, name).restype = C.c_int

@@ -167,9 +167,11 @@ int fail(int code, const char *fmt, ...)
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \
-        if (e__ != hipSuccess)                                                                 \
+        if (e__ != hipSuccess) {                                                               \
+            (void)hipGetLastError(); /* (the thread's sticky copy: a later launch check must not report THIS failure) */ \
             return fail(e__ == hipErrorOutOfMemory ? NABO_E_NOMEM : NABO_E_HIP, "%s failed: %s", \
                         #expr, hipGetErrorString(e__));                                        \
+        }                                                                                      \
     } while (0)
 
 int use_device(int device)

@@ -88,9 +88,11 @@ using nabo::api_fail;
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e__ = (expr);                                                                   \
-        if (e__ != hipSuccess)                                                                     \
+        if (e__ != hipSuccess) {                                                                   \
+            (void)hipGetLastError(); /* (the thread's sticky copy: a later launch check must not report THIS failure) */ \
             return api_fail(e__ == hipErrorOutOfMemory ? NABO_E_NOMEM : NABO_E_HIP, "%s failed: %s", \
                             #expr, hipGetErrorString(e__));                                        \
+        }                                                                                          \
     } while (0)
 
 // ---- librccl.so, resolved at run time -------------------------------------------------------------------
@@ -580,8 +582,10 @@ int comm_alloc(nabo_comm **out, int kind, int device, int rank, int world)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int i = 0; i < 8 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev[i]);
     if (e != hipSuccess) {
+        (void)hipGetLastError();          // (the thread's sticky copy: a later launch check must not report THIS failure)
         delete c;
-        return api_fail(NABO_E_HIP, "communicator stream/event creation failed: %s", hipGetErrorString(e));
+        return api_fail(e == hipErrorInvalidDevice ? NABO_E_NODEVICE : NABO_E_HIP, "communicator on device %d: %s", device,
+                        hipGetErrorString(e));
     }
     *out = c;
     return NABO_OK;

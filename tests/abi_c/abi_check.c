@@ -23,7 +23,8 @@ int main(int argc, char **argv)
                           (void *)nabo_comm_unique_id, (void *)nabo_comm_create, (void *)nabo_comm_create_all,
                           (void *)nabo_comm_create_loopback, (void *)nabo_comm_destroy, (void *)nabo_comm_rank,
                           (void *)nabo_comm_world, (void *)nabo_comm_transport_ranks, (void *)nabo_comm_abort, (void *)nabo_comm_set_timeout, (void *)nabo_comm_set_ref_shards, (void *)nabo_comm_barrier, (void *)nabo_comm_allreduce_max_f64,
-                          (void *)nabo_candidates_per_shard, (void *)nabo_sharded_query, (void *)nabo_sharded_last_stats};
+                          (void *)nabo_candidates_per_shard, (void *)nabo_sharded_query, (void *)nabo_sharded_last_stats,
+                          (void *)nabo_knn_devices};
     printf("%s: %d entry points\n", nabo_version(), (int)(sizeof(syms) / sizeof(syms[0])));
     if (argc < 2 || strcmp(argv[1], "run") != 0) return 0;
     if (nabo_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 2; }

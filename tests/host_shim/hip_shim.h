@@ -13,7 +13,7 @@
 #include <cstring>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorInvalidValue = 1, hipErrorInvalidDevice = 101 };
 typedef struct shim_stream *hipStream_t;
 struct shim_event { std::chrono::steady_clock::time_point t; };
 typedef shim_event *hipEvent_t;

@@ -439,3 +439,30 @@ def test_bench_under_the_launcher_creates_its_communicator_without_torch():
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600, cwd=REPO)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "sharded == unsharded: True" in r.stdout and '"sharded"' in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,m,n,g,k,drop,metric", [(3, 700, 9000, 30, 11, 1, 0), (4, 1200, 20000, 50, 15, 0, 0), (2, 300, 5000, 20, 11, 0, 1),
+                                                   (8, 2000, 40000, 100, 50, 0, 2), (1, 500, 3000, 30, 11, 1, 0)])
+def test_knn_devices_one_call_from_host_arrays_equals_one_device(gpu_lib, N, m, n, g, k, drop, metric):
+    """nabo_knn_devices (multi.hip): host arrays in and out, the references sharded over `devices` inside the library -- one host
+    thread, one index and one communicator per device, met in nabo_sharded_query.  Loopback transport (the devices repeat):
+    N shards = one device bit for bit, and the oracle; a masked reference set; the error of a rank that fails alone."""
+    Y = pca_like(n, g, seed=91)
+    X = pca_like(m, g, seed=92) if not drop else Y[:m]
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[::7] = 1
+    for rm in (None, mask):
+        gi, gd = gpu_lib.knn_devices(X, Y, k, [0] * N, metric=metric, ref_mask=rm, drop_first=bool(drop), transport="loopback")
+        ri, rd = gpu_lib.knn(X, Y, k, metric=metric, ref_mask=rm, drop_first=bool(drop))
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd)
+    oi, od = oracle.knn(X, Y, k, metric, ref_mask=mask, drop_first=bool(drop), nthreads=8)
+    assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    if N > 1:
+        with pytest.raises(ValueError):                       # k beyond a shard's ... beyond the whole set: every rank refuses
+            gpu_lib.knn_devices(X, Y, 0, [0] * N, metric=metric, transport="loopback")
+        with pytest.raises(Exception):                        # a device that does not exist: that rank fails alone, the call fails
+            gpu_lib.knn_devices(X, Y, k, [0] * (N - 1) + [99], metric=metric, transport="loopback")
+        gi2, gd2 = gpu_lib.knn_devices(X, Y, k, [0] * N, metric=metric, transport="loopback")      # ... and the library is still usable
+        ri2, rd2 = gpu_lib.knn(X, Y, k, metric=metric)
+        assert np.array_equal(gi2, ri2) and np.array_equal(gd2, rd2)
