@@ -119,6 +119,17 @@ int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask);
 int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m,
                      int32_t k, int32_t drop_first,
                      int64_t *out_idx, double *out_dist, int32_t out_on_device);
+/* The same query WITHOUT waiting for it (an asynchronous form).  nabo_index_query_async returns as soon as the
+ * query has been handed to a host thread of its own (a query synchronises its stream between its passes -- the fail count
+ * of one pass sizes the next -- so "enqueue and return" needs that thread); nabo_index_query_wait returns the query's
+ * status (NABO_OK when nothing is in flight).  One query in flight per index; every other call on the index refuses with
+ * NABO_E_INVALID until the wait (nabo_index_destroy waits itself); X and the outputs must stay valid until then.  What it is
+ * for: the caller's thread goes on -- uploads the next target batch, runs the exchange of a sharded query's other half,
+ * drives another index on the same or another device (kernels of two indices overlap on one GPU as far as they leave
+ * each other room). */
+int nabo_index_query_async(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k,
+                           int32_t drop_first, int64_t *out_idx, double *out_dist, int32_t out_on_device);
+int nabo_index_query_wait(nabo_index *ix);
 
 /* Shard mode (reference rows sharded over GPUs with GLOBAL certification, nabo_sharded_query below): the first
  * n_cand (<= 32) entries of the shard's order rows WITHOUT a local verdict -- out_idx [m,n_cand] (global

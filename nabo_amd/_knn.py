@@ -152,6 +152,17 @@ class KnnIndex:
         _lib.check(_lib.lib().nabo_index_query(self._h, int(x_ptr), 1, int(m), int(k), int(bool(drop_first)),
                                                int(out_idx_ptr), int(out_dist_ptr), 1))
 
+    def query_device_async(self, x_ptr, m, k, drop_first, out_idx_ptr, out_dist_ptr):
+        """nabo_index_query_async: returns at once; wait() returns when the results are in the output buffers.  One query in
+        flight per index; every other call on it is refused until wait()."""
+        _lib.check(_lib.lib().nabo_index_query_async(self._h, int(x_ptr), 1, int(m), int(k), int(bool(drop_first)),
+                                                     int(out_idx_ptr), int(out_dist_ptr), 1))
+        return self
+
+    def wait(self):
+        _lib.check(_lib.lib().nabo_index_query_wait(self._h))
+        return self
+
     def query_candidates_device(self, x_ptr, m, n_cand, out_idx_ptr, out_dist_ptr, out_bound_ptr):
         """Shard mode: first n_cand order-row entries + the bound on everything else (device pointers)."""
         _lib.check(_lib.lib().nabo_index_query_candidates(self._h, int(x_ptr), 1, int(m), int(n_cand),

@@ -20,7 +20,7 @@ _lib = None
 # every symbol include/nabo_knn.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "nabo_version", "nabo_last_error", "nabo_device_count", "nabo_knn", "nabo_pairwise",
-    "nabo_index_create", "nabo_index_destroy", "nabo_index_set_option", "nabo_query_plan", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query",
+    "nabo_index_create", "nabo_index_destroy", "nabo_index_set_option", "nabo_query_plan", "nabo_index_set_ref", "nabo_index_set_mask", "nabo_index_query", "nabo_index_query_async", "nabo_index_query_wait",
     "nabo_index_query_candidates",
     "nabo_index_last_stats", "nabo_index_last_kernel", "nabo_index_last_passes", "nabo_index_last_row_pass", "nabo_merge_topk", "nabo_snn_counts", "nabo_pyset_order", "nabo_component_labels", "nabo_group_edges", "nabo_score_null", "nabo_score_null_edges", "nabo_dev_malloc", "nabo_dev_free",
     "nabo_memcpy_h2d", "nabo_memcpy_d2h", "nabo_dev_synchronize", "nabo_dev_mem_info",
@@ -56,6 +56,8 @@ def lib():
     L.nabo_index_set_ref.argtypes = [vp, vp, i32, vp]
     L.nabo_index_set_mask.argtypes = [vp, vp]
     L.nabo_index_query.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, i32]
+    L.nabo_index_query_async.argtypes = [vp, vp, i32, i64, i32, i32, vp, vp, i32]
+    L.nabo_index_query_wait.argtypes = [vp]
     L.nabo_index_query_candidates.argtypes = [vp, vp, i32, i64, i32, vp, vp, vp]
     L.nabo_index_last_stats.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
     L.nabo_index_last_kernel.argtypes = [vp, C.c_char_p, C.c_size_t]

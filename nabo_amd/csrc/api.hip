@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/nabo_knn.h"
@@ -377,6 +378,12 @@ struct nabo_index {
     double ms[5] = {0, 0, 0, 0, 0};
     int64_t counters[4] = {0, 0, 0, 0};
     char kernel[160] = "";          // dominant kernel of the last query (nabo_index_last_kernel)
+    // nabo_index_query_async: the query runs on a host thread of its own (it synchronises its stream between its passes);
+    // one in flight per index, joined by nabo_index_query_wait / any other call that needs the index
+    std::thread async_thread;
+    bool async_busy = false;
+    int async_rc = NABO_OK;
+    char async_msg[512] = "";
 };
 
 namespace nabo {
@@ -641,6 +648,7 @@ int nabo_index_create(nabo_index **out, int32_t device, int64_t n_ref, int32_t g
 int nabo_index_set_option(nabo_index *ix, const char *name, int64_t value)
 {
     if (!ix || !name) return fail(NABO_E_INVALID, "NULL argument");
+    if (ix->async_busy) return fail(NABO_E_INVALID, "an asynchronous query is in flight on this index: nabo_index_query_wait first");
     if (!option_set(ix->opt, name, value)) return fail(NABO_E_INVALID, "unknown option '%s'", name);
     if (strcmp(name, "order_flags") == 0) {
 #ifdef NABO_EXPERIMENTS
@@ -658,6 +666,7 @@ int nabo_index_set_option(nabo_index *ix, const char *name, int64_t value)
 int nabo_index_destroy(nabo_index *ix)
 {
     if (!ix) return NABO_OK;
+    if (ix->async_thread.joinable()) ix->async_thread.join();     // (an asynchronous query still in flight: its buffers are the index's)
     (void)hipSetDevice(ix->device);
     if (ix->stream) (void)hipStreamSynchronize(ix->stream);
     for (int i = 0; i < 6; ++i)
@@ -673,6 +682,7 @@ int nabo_index_destroy(nabo_index *ix)
 int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, const uint8_t *ref_mask)
 {
     if (!ix || !Y) return fail(NABO_E_INVALID, "NULL argument");
+    if (ix->async_busy) return fail(NABO_E_INVALID, "an asynchronous query is in flight on this index: nabo_index_query_wait first");
     int rc = use_device(ix->device);
     if (rc) return rc;
     hipStream_t st = ix->stream;
@@ -801,6 +811,7 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
 int nabo_index_set_mask(nabo_index *ix, const uint8_t *ref_mask)
 {
     if (!ix) return fail(NABO_E_INVALID, "NULL index");
+    if (ix->async_busy) return fail(NABO_E_INVALID, "an asynchronous query is in flight on this index: nabo_index_query_wait first");
     if (!ix->have_ref) return fail(NABO_E_INVALID, "nabo_index_set_ref has not been called");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -1852,15 +1863,55 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
     return NABO_OK;
 }
 
+// (every entry point that touches an index first waits for the asynchronous query it may have in flight and hands its
+// status to nabo_index_query_wait)
+static void async_join(nabo_index *ix)
+{
+    if (ix && ix->async_thread.joinable()) ix->async_thread.join();
+}
+
 int nabo_index_query(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k,
                      int32_t drop_first, int64_t *out_idx, double *out_dist, int32_t out_on_device)
 {
+    if (ix && ix->async_busy) return fail(NABO_E_INVALID, "an asynchronous query is in flight on this index: nabo_index_query_wait first");
     return query_impl(ix, X, x_on_device, m, k, drop_first, out_idx, out_dist, out_on_device, false, nullptr);
+}
+
+int nabo_index_query_async(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t k,
+                           int32_t drop_first, int64_t *out_idx, double *out_dist, int32_t out_on_device)
+{
+    if (!ix) return fail(NABO_E_INVALID, "NULL argument");
+    if (ix->async_busy) return fail(NABO_E_INVALID, "an asynchronous query is in flight on this index: nabo_index_query_wait first");
+    async_join(ix);
+    ix->async_busy = true;
+    ix->async_rc = NABO_OK;
+    ix->async_msg[0] = 0;
+    try {
+        ix->async_thread = std::thread([=]() {
+            const int rc = query_impl(ix, X, x_on_device, m, k, drop_first, out_idx, out_dist, out_on_device, false, nullptr);
+            ix->async_rc = rc;
+            if (rc) snprintf(ix->async_msg, sizeof(ix->async_msg), "%s", nabo_last_error());   // (this thread's message)
+        });
+    } catch (...) {
+        ix->async_busy = false;
+        return fail(NABO_E_NOMEM, "could not start the query's host thread");
+    }
+    return NABO_OK;
+}
+
+int nabo_index_query_wait(nabo_index *ix)
+{
+    if (!ix) return fail(NABO_E_INVALID, "NULL argument");
+    if (!ix->async_busy) return NABO_OK;
+    async_join(ix);
+    ix->async_busy = false;
+    return ix->async_rc ? fail(ix->async_rc, "%s", ix->async_msg) : NABO_OK;
 }
 
 int nabo_index_query_candidates(nabo_index *ix, const double *X, int32_t x_on_device, int64_t m, int32_t n_cand,
                                 int64_t *out_idx, double *out_dist, double *out_bound)
 {
+    if (ix && ix->async_busy) return fail(NABO_E_INVALID, "an asynchronous query is in flight on this index: nabo_index_query_wait first");
     return query_impl(ix, X, x_on_device, m, n_cand, 0, out_idx, out_dist, 1, true, out_bound);
 }
 

@@ -17,6 +17,7 @@ int main(int argc, char **argv)
     const void *syms[] = {(void *)nabo_version, (void *)nabo_last_error, (void *)nabo_device_count, (void *)nabo_knn,
                           (void *)nabo_pairwise, (void *)nabo_index_create, (void *)nabo_index_destroy, (void *)nabo_index_set_option, (void *)nabo_query_plan,
                           (void *)nabo_index_set_ref, (void *)nabo_index_set_mask, (void *)nabo_index_query,
+                          (void *)nabo_index_query_async, (void *)nabo_index_query_wait,
                           (void *)nabo_index_query_candidates, (void *)nabo_index_last_stats, (void *)nabo_index_last_kernel, (void *)nabo_index_last_passes, (void *)nabo_index_last_row_pass, (void *)nabo_dev_mem_info, (void *)nabo_merge_topk,
                           (void *)nabo_snn_counts, (void *)nabo_pyset_order, (void *)nabo_component_labels, (void *)nabo_group_edges, (void *)nabo_score_null, (void *)nabo_score_null_edges, (void *)nabo_dev_malloc, (void *)nabo_dev_free,
                           (void *)nabo_memcpy_h2d, (void *)nabo_memcpy_d2h, (void *)nabo_dev_synchronize,

@@ -1154,3 +1154,48 @@ def test_cut_launches_and_merged_lists_change_no_result(gpu_lib, m, n, g, k, dro
     rows = np.random.default_rng(5).choice(m, min(m, 400), replace=False)
     oi, od = oracle.knn(X[rows], Y, k, metric, drop_first=bool(drop), nthreads=16)
     _check(ref[0][rows], ref[1][rows], oi, od)
+
+
+def test_asynchronous_queries_overlap_and_return_the_same_bits(gpu_lib):
+    """nabo_index_query_async / _wait: the call returns before the query is done (the caller's thread is free), two indices on
+    one device have their queries in flight together, results equal the synchronous call's; while a query is in flight every
+    other call on that index is refused; an error of the query surfaces in wait()."""
+    import time
+    K = _knn_mod()
+    n, g, k = 300000, 50, 15
+    Y1, Y2 = pca_like(n, g, seed=101), pca_like(n, g, seed=102)
+    X = pca_like(60000, g, seed=103)
+    dx = _knn_buf(gpu_lib, X)
+    m = X.shape[0]
+    ixs = [K.KnnIndex(n, g, metric=0).set_ref(Y) for Y in (Y1, Y2)]
+    outs = [(K.DeviceBuffer(m * k * 8), K.DeviceBuffer(m * k * 8)) for _ in ixs]
+    sync = []
+    for ix, (di, dd) in zip(ixs, outs):
+        ix.query_device(dx.ptr, m, k, False, di.ptr, dd.ptr)
+        sync.append((di.download((m, k), np.int64), dd.download((m, k), np.float64)))
+    t_sync = []
+    for ix, (di, dd) in zip(ixs, outs):
+        t0 = time.perf_counter()
+        ix.query_device(dx.ptr, m, k, False, di.ptr, dd.ptr)
+        t_sync.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for ix, (di, dd) in zip(ixs, outs):
+        ix.query_device_async(dx.ptr, m, k, False, di.ptr, dd.ptr)
+    t_issue = time.perf_counter() - t0
+    with pytest.raises(ValueError):
+        ixs[0].query_device(dx.ptr, m, k, False, outs[0][0].ptr, outs[0][1].ptr)          # in flight: refused
+    with pytest.raises(ValueError):
+        ixs[0].set_mask(None)
+    for ix in ixs:
+        ix.wait()
+    assert t_issue < 0.5 * min(t_sync), (t_issue, t_sync)                                # returned long before a query's time
+    for (di, dd), (si, sd) in zip(outs, sync):
+        assert np.array_equal(di.download((m, k), np.int64), si) and np.array_equal(dd.download((m, k), np.float64), sd)
+    ixs[0].wait()                                                                         # nothing in flight: a no-op
+    ixs[0].query_device_async(dx.ptr, m, n + 5, False, outs[0][0].ptr, outs[0][1].ptr)    # k beyond the references
+    with pytest.raises(ValueError):
+        ixs[0].wait()
+    oi, od = oracle.knn(X[:200], Y1, k, 0, nthreads=8)
+    _check(sync[0][0][:200], sync[0][1][:200], oi, od)
+    for ix in ixs:
+        ix.close()
