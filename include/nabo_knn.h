@@ -94,7 +94,7 @@ int nabo_index_destroy(nabo_index *ix);
  * "cand_slack", "seeded_pass", "coarse_adapt", "wide_retry", "refine_overlap" (0 / 1: links of the pass chain), "prepass"
  * (tournament seeds, percent of the planned length; 0 = off), "merge_lists" (several lists per row are merged by their
  * filter keys before the float64 step), "one_round" (fewer column-workgroups than slots: splits chosen to fill one round of
- * workgroups), "pieces" (the same query cut into equal chunks of the (column, tile) space; off), "l2c_geo" (0 = A, 1 = B,
+ * workgroups), "pieces" (experiments builds: the same query cut into equal chunks of the (column, tile) space; a no-op otherwise), "l2c_geo" (0 = A, 1 = B,
  * 2 = C), "l2_r1", "split_refs_max", "cosine_centre" (takes effect at the next set_ref).  Unknown names: NABO_E_INVALID.
  * The library reads TWO environment variables, once, in nabo_index_create: NABO_L2_MODE = f32 | f16x3 (which Euclidean /
  * cosine filter runs first; default: the one-product pass) and NABO_CANBERRA_MODE = exact | swar | bits; the sharded

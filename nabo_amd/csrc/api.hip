@@ -239,7 +239,7 @@ struct Options {
     int wide_retry = 1;        //   rows the 32-entry lists fail get 64-entry lists before the exact kernels
     int refine_overlap = 1;    // the refine of the main launch's rows runs beside the filter's tail launch
     int prepass = 100;         // tournament seeds: percent of the planned length (0: lists start from +inf)
-    int pieces = 0;            // fewer column-workgroups than slots: the launch is cut into equal pieces of (column, tile) space (measured slower than the split grid so far: off)
+    int pieces = 0;            // (-DNABO_EXPERIMENTS builds) fewer column-workgroups than slots: the launch cut into equal pieces of (column, tile) space -- measured slower than uniform splits; a no-op in the product build
     int merge_lists = 1;       // several lists per row are merged by their filter keys before the float64 re-evaluation
     int one_round = 1;         // fewer column-workgroups than slots: splits (+ a tail launch) chosen to fill ONE round of workgroups
     int l2c_geo = -1;          // pin the one-product kernel's geometry: 0 = A, 1 = B, 2 = C (-1: by list length)
@@ -1006,6 +1006,7 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
     bool pieces = false;
     int piece_wgs = 0;
     int64_t piece_len = 0;
+#ifdef NABO_EXPERIMENTS                                     // (measured slower than uniform splits: section 4.6 of DESIGN.md; tools/ab builds only)
     if (!forced && on_l2c && ix->opt.pieces != 0 && ix->pass_level == 0 && !ix->wide_retry && gx < slots &&
         ix->ref_tiles >= 64 && ix->ref_tiles * 32 < NABO_LIST_SPLIT_REFS &&
         (ix->opt.split_refs_max < 64 || ix->ref_tiles * 32 < ix->opt.split_refs_max)) {
@@ -1015,6 +1016,7 @@ static int plan_l2(const nabo_index *ix, int64_t m, int k, int drop, bool cand_m
             S = sp;
         }
     }
+#endif
     // Fewer column-workgroups than slots, one-product kernel, lists merged before the float64 step (so a row's list count
     // costs the refine nothing): ONE round of workgroups at full occupancy -- all the columns with floor(slots / gx) uniform
     // splits when that fills at least 80 % of the slots.  On LONG reference streams (>= 8192 tiles) also one split more on

@@ -713,6 +713,9 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     dim3 block(64 * WAVES);
+#ifndef NABO_EXPERIMENTS
+    if (pcs.pieces) return hipErrorInvalidValue;        // (the launch cut into pieces lost to uniform splits: experiments build only)
+#else
     if (pcs.pieces) {
         // pieces: one workgroup per chunk of the (column, tile) space; gx / S then only describe the emitted lists
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, true>),
@@ -721,7 +724,9 @@ static hipError_t claunch_geo(const unsigned char *Xpk, const unsigned char *Ypk
         hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, true>), dim3(pcs.n_pieces, 1), block, lds, st, Xpk, Ypk,
                            tiles_per_split, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride,
                            tau_row0, reinterpret_cast<const int4 *>(pcs.pieces), S);
-    } else {
+    } else
+#endif
+    {
         hipLaunchKernelGGL((l2c_topk_kernel<KS, EPL, ROWN, NBv, NRECv, WAVES, WPS, false>), dim3(gx, S), block, lds, st, Xpk, Ypk,
                            tiles_per_split, tile_off, lkeep, cand_idx, cand_key, cand_tau, pad_tile, dbg, rows_valid, tau_init, tau_stride,
                            tau_row0, nullptr, S);

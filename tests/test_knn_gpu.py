@@ -1130,8 +1130,8 @@ def test_tournament_seeds_change_no_result(gpu_lib, m, n, g, k, drop, metric, sp
                                                  (9000, 50000, 100, 50, 0, 2), (2000, 150000, 30, 40, 1, 0), (700, 3000, 50, 15, 0, 0),
                                                  (45000, 9000, 20, 11, 0, 0), (101000, 40000, 50, 15, 0, 0)])
 def test_cut_launches_and_merged_lists_change_no_result(gpu_lib, m, n, g, k, drop, metric):
-    """Fewer column-workgroups than slots: the one-product launch is cut into equal pieces of the (column, reference tile)
-    space (api.hip: cut_pieces; every piece its own lists and tournament) and the several lists of a row are merged by their
+    """Fewer column-workgroups than slots.  (Experiments builds: the one-product launch cut into equal pieces of the (column,
+    reference tile) space -- api.hip: cut_pieces; option "pieces", a no-op in the product library.)  The several lists of a row are merged by their
     filter keys before the float64 re-evaluation (refine.hip: merge_lists_kernel); by default such a query is cut into ONE round
     of workgroups -- uniform splits, the columns that do not fit as a tail launch (api.hip: plan_l2, one_round).  The cut
     launch, the one-round plan, the cost model's plan, merged and unmerged lists and caller-chosen splits return the same bits; rows sampled against the oracle (all three geometries,
