@@ -1128,7 +1128,8 @@ def test_tournament_seeds_change_no_result(gpu_lib, m, n, g, k, drop, metric, sp
 
 @pytest.mark.parametrize("m,n,g,k,drop,metric", [(5000, 20000, 50, 15, 0, 0), (30000, 30000, 50, 15, 1, 0), (20000, 100000, 50, 15, 0, 0),
                                                  (9000, 50000, 100, 50, 0, 2), (2000, 150000, 30, 40, 1, 0), (700, 3000, 50, 15, 0, 0),
-                                                 (45000, 9000, 20, 11, 0, 0), (101000, 40000, 50, 15, 0, 0)])
+                                                 (45000, 9000, 20, 11, 0, 0), (101000, 40000, 50, 15, 0, 0),
+                                                 (110000, 300000, 50, 15, 0, 0)])      # (a long stream: one split more + a tail launch)
 def test_cut_launches_and_merged_lists_change_no_result(gpu_lib, m, n, g, k, drop, metric):
     """Fewer column-workgroups than slots.  (Experiments builds: the one-product launch cut into equal pieces of the (column,
     reference tile) space -- api.hip: cut_pieces; option "pieces", a no-op in the product library.)  The several lists of a row are merged by their
