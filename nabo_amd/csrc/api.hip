@@ -1315,10 +1315,10 @@ static int query_body(nabo_index *ix, const double *X, int32_t x_on_device, int6
             // keys and merge_lists_kernel reduces the lists to the ONE a single stream would have kept (refine.hip)
             // (first pass only: a seeded pass WANTS every list re-evaluated -- its rows have more than one list's worth of
             // references below their seeds: cosine d = 100, k = 50 with the merge there: 86 instead of 16 ms of later passes)
-            // ... the SEEDED pass on 32-entry lists keeps up to 128: what lies below a seed is "a few more than one list", and
+            // ... the SEEDED pass keeps up to 128: what lies below a seed is "a few more than one list", and
             // 128 candidates are two per lane for the float64 step where S x 32 were four to sixteen per lane, each walking
             // its own row (100k x 100k: refine of 108 rows' 1024 candidates 0.41 ms)
-            const bool seeded_merge = ix->pass_level == 1 && epl == 1 && !ix->wide_retry;
+            const bool seeded_merge = ix->pass_level == 1 && !ix->wide_retry;          // (32- and 64-entry lists alike)
             const bool merging = on_l2c && ix->opt.merge_lists != 0 && !ix->wide_retry && (ix->pass_level == 0 || seeded_merge);
             merge_seeded = seeded_merge;
             merge_keep = seeded_merge ? (S * L < 128 ? S * L : 128) : lkeep;
