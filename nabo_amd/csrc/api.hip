@@ -766,31 +766,62 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                 HIP_TRY(nabo::cbf_pack_refs_rows_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->yrow.as<float>(), st));
                 HIP_TRY(nabo::cbf_pack_refs8_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
                 HIP_TRY(hipStreamSynchronize(st));      // sc goes out of scope
-                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 128 blocks (262k cells:
+                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 24 blocks (49k cells; round 3, 128 blocks:
                 // measured 2.0x the SWAR pass at 1M x 1M, level with it at 100k x 100k where building its table costs
                 // what it saves; NABO_CANBERRA_MODE=swar pins the 7-bit SWAR pass, =bits the bitmaps at any size): per-dimension
                 // QUANTILE bucket edges from a strided sample of the references (any edges give correct results -- they
                 // only decide how sharp the count is), cumulative bitmaps per block of 2048 references.
                 ix->cb_bits = false;
-                const bool want_bits = ix->cb_mode ? ix->cb_mode == 3 : ix->n >= 128 * 2048;
+                // (round 4: from 24 blocks on -- with the four-words-per-lane kernel and the edge sorts on eight host threads
+                // (set_ref 3.9 -> 1.2 ms) the bitmaps win from ~50k references even with their table built inside the step:
+                // 100k x 100k 18.8 against 25.5 ms, 100k targets x 200k references 24.1 against 44.2, 100k x 60k 16.6
+                // against 17.6; 30k x 30k 4.9 against 3.7)
+                const bool want_bits = ix->cb_mode ? ix->cb_mode == 3 : ix->n >= 24 * 2048;
                 if (want_bits && nabo::cbb_available(G, ix->cb_gp, 1)) {
                     const int B = nabo::cbb_buckets();
                     int64_t ns = ix->n < 2048 ? ix->n : 2048;          // (32 sample values per bucket; the sort is host time inside set_ref)
                     const int64_t stride = ix->n / ns;
                     std::vector<double> smp((size_t)ns * G), col((size_t)ns), edges((size_t)G * (B - 1));
-                    HIP_TRY(hipMemcpy2DAsync(smp.data(), (size_t)G * sizeof(double), ix->dY, (size_t)stride * G * sizeof(double),
-                                             (size_t)G * sizeof(double), (size_t)ns, hipMemcpyDeviceToHost, st));
-                    HIP_TRY(hipStreamSynchronize(st));
-                    for (int k = 0; k < G; ++k) {
-                        size_t nf = 0;
-                        for (int64_t i = 0; i < ns; ++i) {
-                            const double v = smp[(size_t)i * G + k];
-                            if (std::isfinite(v)) col[nf++] = v;
-                        }
-                        std::sort(col.begin(), col.begin() + nf);
-                        for (int b = 1; b < B; ++b)
-                            edges[(size_t)k * (B - 1) + (b - 1)] = nf ? col[(size_t)((double)b * nf / B)] : 0.0;
+                    {   // the sample rows: gathered on the device, ONE contiguous copy back (a strided 2-D copy of 2048 short rows
+                        // to pageable memory took milliseconds)
+                        std::vector<uint32_t> rows_h((size_t)ns);
+                        for (int64_t i = 0; i < ns; ++i) rows_h[(size_t)i] = (uint32_t)(i * stride);
+                        if ((rc = ix->fails2.reserve((size_t)ns * sizeof(uint32_t)))) return rc;
+                        if ((rc = ix->xfail.reserve((size_t)ns * G * sizeof(double)))) return rc;
+                        HIP_TRY(hipMemcpyAsync(ix->fails2.p, rows_h.data(), (size_t)ns * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                        HIP_TRY(nabo::gather_rows_launch(ix->dY, ix->fails2.as<uint32_t>(), ns, G, ix->xfail.as<double>(), st));
+                        HIP_TRY(hipMemcpyAsync(smp.data(), ix->xfail.p, (size_t)ns * G * sizeof(double), hipMemcpyDeviceToHost, st));
+                        HIP_TRY(hipStreamSynchronize(st));
                     }
+                    // (one sort per dimension: a few host threads -- 50 sorts of 2048 values were 3.9 ms of every set_ref)
+                    auto edges_of = [&](int k0, int k1) {
+                        std::vector<double> colk((size_t)ns);
+                        for (int k = k0; k < k1; ++k) {
+                            size_t nf = 0;
+                            for (int64_t i = 0; i < ns; ++i) {
+                                const double v = smp[(size_t)i * G + k];
+                                if (std::isfinite(v)) colk[nf++] = v;
+                            }
+                            std::sort(colk.begin(), colk.begin() + nf);
+                            for (int b = 1; b < B; ++b)
+                                edges[(size_t)k * (B - 1) + (b - 1)] = nf ? colk[(size_t)((double)b * nf / B)] : 0.0;
+                        }
+                    };
+                    {
+                        const int nt = G >= 16 ? 8 : 1;
+                        std::vector<std::thread> th;
+                        bool threaded = nt > 1;
+                        if (threaded) {
+                            try {
+                                for (int t = 0; t < nt; ++t) th.emplace_back(edges_of, G * t / nt, G * (t + 1) / nt);
+                            } catch (...) {
+                                threaded = false;
+                            }
+                            for (std::thread &t : th) t.join();
+                        }
+                        if (!threaded) edges_of(0, G);           // (also after a failed thread start: every dimension again)
+                    }
+                    (void)col;
                     if ((rc = ix->cbedges.reserve(edges.size() * sizeof(double)))) return rc;
                     if ((rc = ix->cbtab.reserve(nabo::cbb_table_bytes(ix->n, G)))) return rc;
                     if ((rc = ix->cbvalid.reserve(nabo::cbb_valid_bytes(ix->n)))) return rc;
