@@ -766,17 +766,17 @@ int nabo_index_set_ref(nabo_index *ix, const double *Y, int32_t y_on_device, con
                 HIP_TRY(nabo::cbf_pack_refs_rows_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->yrow.as<float>(), st));
                 HIP_TRY(nabo::cbf_pack_refs8_launch(ix->dY, ix->n, ix->g, ix->cb_gp, ix->cbscale.as<double>(), ix->ych.p, st));
                 HIP_TRY(hipStreamSynchronize(st));      // sc goes out of scope
-                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 24 blocks (49k cells; round 3, 128 blocks:
+                // Bit-sliced counting pass (canberra_bits.hip), the default for reference sets of >= 12 blocks (25k cells; round 3, 128 blocks:
                 // measured 2.0x the SWAR pass at 1M x 1M, level with it at 100k x 100k where building its table costs
                 // what it saves; NABO_CANBERRA_MODE=swar pins the 7-bit SWAR pass, =bits the bitmaps at any size): per-dimension
                 // QUANTILE bucket edges from a strided sample of the references (any edges give correct results -- they
                 // only decide how sharp the count is), cumulative bitmaps per block of 2048 references.
                 ix->cb_bits = false;
-                // (round 4: from 24 blocks on -- with the four-words-per-lane kernel and the edge sorts on eight host threads
-                // (set_ref 3.9 -> 1.2 ms) the bitmaps win from ~50k references even with their table built inside the step:
-                // 100k x 100k 18.8 against 25.5 ms, 100k targets x 200k references 24.1 against 44.2, 100k x 60k 16.6
-                // against 17.6; 30k x 30k 4.9 against 3.7)
-                const bool want_bits = ix->cb_mode ? ix->cb_mode == 3 : ix->n >= 24 * 2048;
+                // (round 4: from 12 blocks on -- with the four-words-per-lane kernel, its lists seeded before the count starts and
+                // the edge sorts on eight host threads (set_ref 3.9 -> 1.2 ms) the bitmaps win from ~25k references even with
+                // their table built inside the step: 100k x 100k 13.2 against 25.5 ms, 30k x 30k 3.0 against 3.6; 10k x 10k
+                // 2.3 against 1.4 -- the same query time, the table build on top)
+                const bool want_bits = ix->cb_mode ? ix->cb_mode == 3 : ix->n >= 12 * 2048;
                 if (want_bits && nabo::cbb_available(G, ix->cb_gp, 1)) {
                     const int B = nabo::cbb_buckets();
                     int64_t ns = ix->n < 2048 ? ix->n : 2048;          // (32 sample values per bucket; the sort is host time inside set_ref)

@@ -64,6 +64,9 @@ static_assert(CBB_PAIR_BYTES % 1024 == 0, "whole DMA pieces");
 // (Tried in round 4 and dropped: an L2 prefetch of the pair three steps ahead -- a dword per lane and 128-byte line by LDS-DMA
 // into a scratch row, vmcnt leaving it in flight for a step: 544 -> 571 ms.  The pass is not waiting for table misses; its
 // SIMDs issue an instruction every 4.9 cycles, 82 % of what they can: what counts is the instruction count.)
+#ifndef NABO_CBB_SEED
+#define NABO_CBB_SEED 512
+#endif
 #ifndef NABO_CBB_DMAW
 #define NABO_CBB_DMAW 4          // (16 waves x 2 pieces: 527 ms at 1M x 1M; 8 x 4: 507; 4 x 8: 503; 2 x 16: 512)
 #endif
@@ -431,6 +434,35 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
     const uint32_t ro_q = ro2_off + (uint32_t)(q * 8);       // this lane group's column of ro2
 #pragma unroll
     for (int s = 0; s < TS; ++s) rnx[s] = *(cbb_lds_u2 *)(uintptr_t)(ro_q + (uint32_t)(4 * s * 8));
+    // SEED (round 4).  A split's lists start with threshold +inf, i.e. count threshold 0: EVERY reference of its first block
+    // survives the count and goes through the fp32 bound -- 2048 x 8 pairs, 256 drains per wave, as much as ~10 ordinary
+    // blocks (2 % of a 1M-reference stream, a fifth of a 100k one).  So the first CBB_SEED references of the split go through
+    // the bound BEFORE the count starts: the lists open with the 32 best of those (a threshold at their 6 % quantile), the
+    // first block's count then lets a fraction of its references through instead of all, and its extraction skips the seeded words.
+    // (Measured, same box: 1M x 1M kernel 504 -> 486 / 480 / 460-470 / 462 ms with 128 / 256 / 512 / 1024 seeds, 100k x 100k
+    // 16.3 -> 13.0 / 11.5 / 10.6 / 11.4: the later blocks gain from the tighter start too.)
+    constexpr int CBB_SEED = NABO_CBB_SEED;                  // references, a multiple of 128 (whole lanes of the block), <= 2048
+    static_assert(CBB_SEED % 128 == 0 && CBB_SEED >= 0 && CBB_SEED <= CBB_BLK, "seeded references: whole lanes of the first block");
+    if (CBB_SEED > 0 && b_begin < b_end) {
+        const int64_t j0 = b_begin * CBB_BLK;
+        for (int t = 0; t < t_cnt; ++t) {
+            for (int ch = 0; ch < CBB_SEED / 64; ++ch) {
+                const int64_t j = j0 + ch * 64 + lane;
+                // (valid bits: word (j - block start) / 32 of the block, bit j % 32)
+                const bool ok = j < n && ((vbits[b_begin * 64 + (ch * 64 + lane) / 32] >> (lane & 31)) & 1u) != 0u;
+                const uint64_t mk = __builtin_amdgcn_ballot_w64(ok);
+                if (ok) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+                    const int slot = (wl_head + wl_n + rank) & (WLN - 1);
+                    wl[slot] = (uint32_t)j;
+                    wl_t[slot] = (unsigned char)t;
+                }
+                wl_n += __popcll(mk);
+                while (wl_n >= 64) drain(64);
+            }
+        }
+        while (wl_n > 0) drain(wl_n < 64 ? wl_n : 64);       // (the count thresholds of the first block come from these lists)
+    }
     int buf = 0;
     for (int64_t blk = b_begin; blk < b_end; ++blk) {
         uint32_t rp = ro_q;                                  // ro2 entry of the current group of steps (DPI = 0)
@@ -562,6 +594,7 @@ void cbb_filter_kernel(const float2 *__restrict__ xq, const uint16_t *__restrict
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 uint32_t ge = t_mine < t_cnt ? gev[s][w] : 0u;
+                if (CBB_SEED > 0 && blk == b_begin && sub < CBB_SEED / 128) ge = 0u;       // (went through the bound as seeds)
                 uint64_t anyb = __builtin_amdgcn_ballot_w64(ge != 0u);
                 while (anyb != 0) {                              // every lane with survivors hands over its lowest one
                     const bool has = ge != 0u;

@@ -87,7 +87,7 @@ def test_canberra_knn_vs_oracle(gpu_lib, m, n, g, k, drop):
     (1500, 70000, 16, 9, False, 0.25, False),        # g = 16: two groups (even)
 ])
 def test_canberra_bit_sliced_count_gives_the_same_bits(gpu_lib, m, n, g, k, drop, f, masked):
-    """canberra_bits.hip (the default counting pass from 49k references on; NABO_CANBERRA_MODE=bits forces it at any
+    """canberra_bits.hip (the default counting pass from 25k references on; NABO_CANBERRA_MODE=bits forces it at any
     size): cumulative per-bucket bitmaps, carry-save count, bit-sliced comparator.  Same candidates' certificate, same
     float64 refine: the oracle's bits -- and the SWAR pass (NABO_CANBERRA_MODE=swar) on the same inputs too."""
     Y = pca_like(n, g, seed=4100 + n + g)
