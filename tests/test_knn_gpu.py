@@ -1189,7 +1189,7 @@ def test_asynchronous_queries_overlap_and_return_the_same_bits(gpu_lib):
         ixs[0].set_mask(None)
     for ix in ixs:
         ix.wait()
-    assert t_issue < 0.5 * min(t_sync), (t_issue, t_sync)                                # returned long before a query's time
+    assert t_issue < 0.8 * min(t_sync), (t_issue, t_sync)                                # returned before ONE query could have finished (blocking calls: the sum of two)
     for (di, dd), (si, sd) in zip(outs, sync):
         assert np.array_equal(di.download((m, k), np.int64), si) and np.array_equal(dd.download((m, k), np.float64), sd)
     ixs[0].wait()                                                                         # nothing in flight: a no-op
