@@ -1200,3 +1200,22 @@ def test_asynchronous_queries_overlap_and_return_the_same_bits(gpu_lib):
     _check(sync[0][0][:200], sync[0][1][:200], oi, od)
     for ix in ixs:
         ix.close()
+
+
+@pytest.mark.parametrize("m,n,expect", [(4000, 30000, "cbb_filter"), (3000, 120000, "cbb_filter"), (4000, 20000, "cbf_filter")])
+def test_canberra_default_counting_pass_by_size(gpu_lib, m, n, expect):
+    """Which counting pass a modified-Canberra index picks when nobody pins it (api.hip: the bitmaps from 12 blocks = 24 576
+    references on, round 4; the SWAR count below), a masked reference set included -- equal to the oracle either way."""
+    g, k = 50, 15
+    Y = pca_like(n, g, seed=111)
+    X = pca_like(m, g, seed=112)
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[5::11] = 1
+    ix = gpu_lib.KnnIndex(n, g, metric=1, dist_factor=0.25).set_ref(Y, ref_mask=mask)
+    gi, gd = ix.query(X, k)
+    kern = ix.last_kernel()
+    ix.close()
+    assert expect in kern, kern
+    rows = np.random.default_rng(3).choice(m, 600, replace=False)
+    oi, od = oracle.knn(X[rows], Y, k, 1, 0.25, ref_mask=mask, nthreads=16)
+    _check(gi[rows], gd[rows], oi, od)
